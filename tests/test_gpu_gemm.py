@@ -1,0 +1,165 @@
+"""GPU parity: tb_gemm (linear / conv3x3 gathers / epilogues) against plain torch fp32 references."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from textboost_amd import ops, _lib
+    return ops, _lib
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (616, 768, 768), (300, 320, 640), (1024, 2304, 832), (130, 70, 128)])
+def test_linear_plain(M, N, K):
+    ops, L = _ops()
+    torch.manual_seed(0)
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    bias = torch.randn(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    ops.gemm(A, W, out, bias=bias)
+    ref = A.float() @ W.float().T + bias
+    assert rel_err(out, ref) < 2e-3
+    # asymmetric / transpose-detecting: max abs error too
+    assert (out.float() - ref).abs().max().item() < 2e-2
+
+
+def test_linear_strided_two_source_residual_fp32_out():
+    ops, L = _ops()
+    torch.manual_seed(1)
+    M, N, K1, K2 = 616, 2304, 768, 64
+    Abuf = torch.randn(M, K1 + 40, device="cuda").half()   # lda > K
+    A = Abuf[:, :K1]
+    A2 = torch.randn(M, K2, device="cuda").half()
+    W = (torch.randn(N, K1, device="cuda") / 30).half()
+    W2 = (torch.randn(N, K2, device="cuda") / 30).half()
+    R = torch.randn(M, N, device="cuda")
+    Cbuf = torch.zeros(M, N + 16, device="cuda")
+    out = Cbuf[:, 8:8 + N]
+    ops.gemm(A, W, out, A2=A2, W2=W2, R=R, alpha=0.5, act=L.ACT_QUICK_GELU)
+    pre = 0.5 * (A.float() @ W.float().T + A2.float() @ W2.float().T) + R
+    ref = pre * torch.sigmoid(1.702 * pre)
+    assert rel_err(out, ref) < 1e-3
+    assert Cbuf[:, :8].abs().max() == 0 and Cbuf[:, 8 + N:].abs().max() == 0
+
+
+def test_linear_rowbias_f16_residual():
+    ops, L = _ops()
+    torch.manual_seed(2)
+    B, HW, N, K = 3, 100, 320, 320
+    A = torch.randn(B * HW, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / 18).half()
+    rb = torch.randn(B, N, device="cuda")
+    R = torch.randn(B * HW, N, device="cuda").half()
+    out = torch.empty(B * HW, N, device="cuda", dtype=torch.float16)
+    ops.gemm(A, W, out, rowbias=rb, rows_per_group=HW, R=R)
+    ref = A.float() @ W.float().T + rb.repeat_interleave(HW, 0) + R.float()
+    assert rel_err(out, ref) < 2e-3
+
+
+def pack_geglu(w):
+    """[2*inner, ...] rows (h rows then g rows) -> 32-row interleaved blocks [h0..31 | g0..31 | h32..63 | ...]."""
+    inner = w.shape[0] // 2
+    h, g = w[:inner], w[inner:]
+    hs = h.reshape(inner // 32, 32, *w.shape[1:])
+    gs = g.reshape(inner // 32, 32, *w.shape[1:])
+    return torch.stack([hs, gs], dim=1).reshape(w.shape)
+
+
+def test_geglu():
+    ops, L = _ops()
+    torch.manual_seed(3)
+    M, C = 384, 320
+    A = torch.randn(M, C, device="cuda").half()
+    W = (torch.randn(8 * C, C, device="cuda") / 18).half()
+    b = torch.randn(8 * C, device="cuda")
+    out = torch.empty(M, 4 * C, device="cuda", dtype=torch.float16)
+    raw = torch.empty(M, 8 * C, device="cuda", dtype=torch.float16)
+    ops.gemm(A, pack_geglu(W), out, bias=pack_geglu(b), act=L.ACT_GEGLU, C2=raw)
+    proj = A.float() @ W.float().T + b
+    h, g = proj.chunk(2, dim=-1)
+    ref = h * F.gelu(g)
+    assert rel_err(out, ref) < 3e-3
+    assert rel_err(raw, pack_geglu(proj.T).T) < 2e-3
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def pack_conv_w(w):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def pack_conv_w_dgrad(w):  # -> [Cin, 9*Cout] with k = (ky*3+kx)*Cout + co
+    return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 128, 16, 16), (1, 320, 320, 24, 20), (2, 128, 64, 7, 9)])
+def test_conv3x3_fwd_and_dgrad(B, Cin, Cout, H, W):
+    ops, L = _ops()
+    torch.manual_seed(4)
+    x = torch.randn(B, Cin, H, W, device="cuda").half()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    xn = nhwc(x).view(B * H * W, Cin)
+    out = torch.empty(B * H * W, Cout, device="cuda", dtype=torch.float16)
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cin, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=0)
+    ops.gemm(xn, pack_conv_w(w), out, bias=bias, conv=geo)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    assert rel_err(out.view(B, H, W, Cout), nhwc(ref)) < 2e-3
+    # dgrad: dX = conv_transpose(dY, w) == same kernel with sign=-1 on [Cin][tap][Cout] weights
+    dy = torch.randn(B, Cout, H, W, device="cuda").half()
+    dx = torch.empty(B * H * W, Cin, device="cuda", dtype=torch.float16)
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cout, Hout=H, Wout=W, stride=1, sign=-1, upsample=0, transposed=0)
+    ops.gemm(nhwc(dy).view(B * H * W, Cout), pack_conv_w_dgrad(w), dx, conv=geo)
+    ref = F.conv_transpose2d(dy.float(), w.float(), padding=1)
+    assert rel_err(dx.view(B, H, W, Cin), nhwc(ref)) < 2e-3
+
+
+def test_conv3x3_stride2_fwd_and_transposed_dgrad():
+    ops, L = _ops()
+    torch.manual_seed(5)
+    B, Ci, Co, H, W = 2, 64, 64, 16, 12
+    x = torch.randn(B, Ci, H, W, device="cuda").half()
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda") / 24).half()
+    Ho, Wo = H // 2, W // 2
+    out = torch.empty(B * Ho * Wo, Co, device="cuda", dtype=torch.float16)
+    geo = dict(B=B, Hin=H, Win=W, Cin=Ci, Hout=Ho, Wout=Wo, stride=2, sign=1, upsample=0, transposed=0)
+    ops.gemm(nhwc(x).view(-1, Ci), pack_conv_w(w), out, conv=geo)
+    ref = F.conv2d(x.float(), w.float(), stride=2, padding=1)
+    assert rel_err(out.view(B, Ho, Wo, Co), nhwc(ref)) < 2e-3
+    dy = torch.randn(B, Co, Ho, Wo, device="cuda").half()
+    dx = torch.empty(B * H * W, Ci, device="cuda", dtype=torch.float16)
+    geo = dict(B=B, Hin=Ho, Win=Wo, Cin=Co, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=1)
+    ops.gemm(nhwc(dy).view(-1, Co), pack_conv_w_dgrad(w), dx, conv=geo)
+    ref = F.conv_transpose2d(dy.float(), w.float(), stride=2, padding=1, output_padding=1)
+    assert rel_err(dx.view(B, H, W, Ci), nhwc(ref)) < 2e-3
+
+
+def test_conv3x3_upsample_folded():
+    ops, L = _ops()
+    torch.manual_seed(6)
+    B, Cc, H, W = 2, 128, 8, 6
+    x = torch.randn(B, Cc, H, W, device="cuda").half()
+    w = (torch.randn(Cc, Cc, 3, 3, device="cuda") / 34).half()
+    out = torch.empty(B * 4 * H * W, Cc, device="cuda", dtype=torch.float16)
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cc, Hout=2 * H, Wout=2 * W, stride=1, sign=1, upsample=1, transposed=0)
+    ops.gemm(nhwc(x).view(-1, Cc), pack_conv_w(w), out, conv=geo)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), padding=1)
+    assert rel_err(out.view(B, 2 * H, 2 * W, Cc), nhwc(ref)) < 2e-3
+
+
+def test_gemm_rejects_bad_args():
+    ops, L = _ops()
+    A = torch.zeros(8, 100, device="cuda", dtype=torch.float16)  # K not multiple of 64
+    W = torch.zeros(8, 100, device="cuda", dtype=torch.float16)
+    out = torch.zeros(8, 8, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, W, out)

@@ -1,0 +1,95 @@
+"""ctypes binding of libtextboost_hip.so (see include/textboost_hip.h). Fails loudly if the library is missing:
+there is no CPU / eager fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first so libamdhip64.so.7 resolves to the runtime torch uses)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtextboost_hip.so")
+
+TB_F16, TB_F32 = 0, 1
+ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2
+A_LINEAR, A_CONV3X3 = 0, 1
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("A2", C.c_void_p), ("lda2", C.c_int64),
+        ("K1", C.c_int64),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("W2", C.c_void_p), ("ldw2", C.c_int64),
+        ("a_mode", C.c_int32),
+        ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
+        ("Wout", C.c_int32), ("stride", C.c_int32), ("sign", C.c_int32), ("upsample", C.c_int32), ("transposed", C.c_int32),
+        ("alpha", C.c_float),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int64),
+        ("R", C.c_void_p), ("ldr", C.c_int64), ("r_dtype", C.c_int32),
+        ("act", C.c_int32),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int32),
+        ("C2", C.c_void_p), ("ldc2", C.c_int64),
+        ("split_k", C.c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("Sq", C.c_int32), ("Skv", C.c_int32), ("hd", C.c_int32), ("causal", C.c_int32),
+        ("scale", C.c_float),
+        ("Q", C.c_void_p), ("ldq", C.c_int64),
+        ("K", C.c_void_p), ("ldk", C.c_int64),
+        ("V", C.c_void_p), ("ldv", C.c_int64),
+        ("O", C.c_void_p), ("ldo", C.c_int64),
+        ("LSE", C.c_void_p),
+        ("dO", C.c_void_p), ("lddo", C.c_int64),
+        ("Delta", C.c_void_p),
+        ("dQ", C.c_void_p), ("lddq", C.c_int64),
+        ("dK", C.c_void_p), ("lddk", C.c_int64),
+        ("dV", C.c_void_p), ("lddv", C.c_int64),
+    ]
+
+
+_lib = None
+
+_VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
+    "tb_groupnorm_ws_floats": ([_I, _I, _I, _I], _I64),
+    "tb_groupnorm_fwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
+    "tb_groupnorm_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_layernorm_fwd": ([_VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _I64, _I, _F, _VP], C.c_int),
+    "tb_layernorm_bwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
+    "tb_attention_fwd": ([C.POINTER(AttnDesc), _VP], C.c_int),
+    "tb_attention_bwd": ([C.POINTER(AttnDesc), _VP], C.c_int),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m textboost_amd.build` (hipcc --offload-arch=gfx950). "
+                "textboost_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(_lib, name)  # AttributeError here = library older than the header
+            fn.argtypes, fn.restype = args, res
+    return _lib
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")

@@ -1,0 +1,460 @@
+// Flash attention forward + backward (dQ, dK, dV) for gfx950, fp16 in / fp32 accumulate, 32x32x16 MFMA.
+//
+// Serves the three attention shapes of the TextBoost step:
+//   * UNet self-attention   (diffusers Attention + AttnProcessor2_0 -> F.scaled_dot_product_attention),
+//     seq 4096/1024/256/64, head dim 40/80/160, non-causal          train_textboost.py:1063-1067
+//   * UNet cross-attention  (K/V = 77 text tokens)                   same call site
+//   * CLIP text self-attention (causal, 77 tokens, head dim 64)      train_textboost.py:1054-1059, :1099-1100
+// and their autograd (accelerator.backward, :1108).
+//
+// Layout trick (cdna guide "swapped QK^T"): scores are computed TRANSPOSED, S^T = K Q^T, so each lane owns one
+// query row (col = lane & 31) and the softmax statistics m, l, lse, delta are lane-local.  P^T is then already
+// in B-operand layout for O^T = V^T P^T; the k-index permutation the accumulator layout implies is absorbed by
+// reading the A operand (V^T, staged transposed in LDS) with the same permutation, so no cross-lane traffic is
+// needed between the two matmuls.  The backward kernels use the same idea (lane owns a query in the dQ kernel,
+// a key in the dK/dV kernel).
+#include "common.h"
+#include "../../include/textboost_hip.h"
+
+namespace {
+
+constexpr int KVT = 64;      // keys (or queries, in the dK/dV kernel) per LDS tile
+constexpr int TLD = KVT + 4; // row stride (halfs) of transposed tiles: 136 B -> conflict-free ds_read_b64 across d
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1e30f;
+
+template <int WD>
+struct RM {  // row-major [64][WD] tile, rows padded by 16 B
+  static constexpr int LD = WD + 8;
+  static constexpr int SIZE = KVT * LD;
+};
+template <int WD>
+struct TR {  // transposed [WD][64] tile
+  static constexpr int SIZE = WD * TLD;
+};
+
+// Stage rows [row0, row0+64) x cols [0, WD) of a (rows x hd) matrix (row stride ld) into LDS; zero outside.
+template <int WD, bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_tile(f16* rm, f16* tr, const f16* g, int64_t ld, int row0, int nrows, int hd) {
+  constexpr int CPR = WD / 8;
+  for (int idx = threadIdx.x; idx < KVT * CPR; idx += 256) {
+    const int r = idx / CPR, ch = idx - r * CPR;
+    const int row = row0 + r;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < nrows && ch * 8 < hd) v = *(const f16x8*)(g + (int64_t)row * ld + ch * 8);
+    if (ROWMAJOR) *(f16x8*)(rm + r * RM<WD>::LD + ch * 8) = v;
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tr[(ch * 8 + i) * TLD + r] = v[i];
+    }
+  }
+}
+
+template <int WD>
+__device__ __forceinline__ f16x8 frag_rm(const f16* rm, int row, int chunk) {
+  return *(const f16x8*)(rm + row * RM<WD>::LD + chunk * 8);
+}
+// A-operand fragment from a transposed tile: row d, contraction indices {k0+4hi..+3, k0+8+4hi..+3}
+__device__ __forceinline__ f16x8 frag_tr(const f16* tr, int d, int k0, int hi) {
+  const f16x4 a = *(const f16x4*)(tr + d * TLD + k0 + 4 * hi);
+  const f16x4 b = *(const f16x4*)(tr + d * TLD + k0 + 8 + 4 * hi);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = a[e];
+    o[4 + e] = b[e];
+  }
+  return o;
+}
+__device__ __forceinline__ f16x8 pack8(const f32x16& v, int r0) {
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)v[r0 + e];
+  return o;
+}
+// B-operand (k = head-dim) register fragments of one row of a (rows x hd) matrix: chunk j covers cols 16j+8hi..+8
+template <int KS>
+__device__ __forceinline__ void load_row_frags(f16x8* f, const f16* g, int64_t ld, int row, int nrows, int hd, int hi) {
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int col = 16 * j + 8 * hi;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < nrows && col < hd) v = *(const f16x8*)(g + (int64_t)row * ld + col);
+    f[j] = v;
+  }
+}
+
+#define ZERO16(x)                \
+  _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) (x)[r_] = 0.f;
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int DT, int KS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const tb_attn_desc p) {
+  constexpr int WD = DT * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16* Ks = reinterpret_cast<f16*>(smem_raw);
+  f16* Vt = Ks + RM<WD>::SIZE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk = blockIdx.x * 128;
+  const int q = qblk + wave * 32 + l31;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * p.hd;
+  f16x8 qf[KS];
+  load_row_frags<KS>(qf, Qg, p.ldq, q, p.Sq, p.hd, hi);
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) ZERO16(o[d]);
+  float m = NEG_BIG, l = 0.f;
+  const float c = p.scale * LOG2E;
+  int kv_end = p.Skv;
+  if (p.causal) kv_end = min(p.Skv, qblk + 128);  // keys beyond the block's last query are never visible
+  for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
+    __syncthreads();
+    stage_tile<WD, true, false>(Ks, nullptr, Kg, p.ldk, kv0, p.Skv, p.hd);
+    stage_tile<WD, false, true>(nullptr, Vt, Vg, p.ldv, kv0, p.Skv, p.hd);
+    __syncthreads();
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      ZERO16(s[kt]);
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s[kt], 0, 0, 0);
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + kt * 32 + mfma32_row(r, hi);
+        const bool ok = key < p.Skv && (!p.causal || key <= q);
+        s[kt][r] = ok ? s[kt][r] * c : -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    m = m_new;
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(s[kt][r] - m_new);
+        s[kt][r] = pv;
+        l += pv;
+      }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f16x8 pf = pack8(s[kt], 8 * jj);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Vt, d * 32 + l31, kt * 32 + 16 * jj, hi), pf, o[d], 0, 0, 0);
+      }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (q < p.Sq) {
+    const float inv = 1.f / l;
+    f16* Og = (f16*)p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;  // 4 consecutive head-dim columns
+        if (col < p.hd) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[d][4 * r4 + e] * inv);
+          *(f16x4*)(Og + col) = v;
+        }
+      }
+    if (p.LSE && hi == 0) p.LSE[((int64_t)b * p.H + h) * p.Sq + q] = m * (1.f / LOG2E) + logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const tb_attn_desc p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B*Sq*H
+  const int64_t total = (int64_t)p.B * p.Sq * p.H;
+  if (idx >= total) return;
+  const int h = (int)(idx % p.H);
+  const int64_t row = idx / p.H;  // b*Sq + q
+  const f16* o = (const f16*)p.O + row * p.ldo + h * p.hd;
+  const f16* d = (const f16*)p.dO + row * p.lddo + h * p.hd;
+  float a = 0.f;
+  for (int c = 0; c < p.hd; c += 8) {
+    const f16x8 ov = *(const f16x8*)(o + c), dv = *(const f16x8*)(d + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += (float)ov[e] * (float)dv[e];
+  }
+  const int b = (int)(row / p.Sq), q = (int)(row % p.Sq);
+  p.Delta[((int64_t)b * p.H + h) * p.Sq + q] = a;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int DT, int KS>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const tb_attn_desc p) {
+  constexpr int WD = DT * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16* Ks = reinterpret_cast<f16*>(smem_raw);
+  f16* Vs = Ks + RM<WD>::SIZE;
+  f16* Kt = Vs + RM<WD>::SIZE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk = blockIdx.x * 128;
+  const int q = qblk + wave * 32 + l31;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * p.hd;
+  const f16* dOg = (const f16*)p.dO + (int64_t)b * p.Sq * p.lddo + h * p.hd;
+  f16x8 qf[KS], dof[KS];
+  load_row_frags<KS>(qf, Qg, p.ldq, q, p.Sq, p.hd, hi);
+  load_row_frags<KS>(dof, dOg, p.lddo, q, p.Sq, p.hd, hi);
+  const bool qok = q < p.Sq;
+  const int64_t sidx = ((int64_t)b * p.H + h) * p.Sq + (qok ? q : 0);
+  const float lse2 = p.LSE[sidx] * LOG2E;
+  const float delta = p.Delta[sidx];
+  const float c = p.scale * LOG2E;
+  f32x16 dq[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) ZERO16(dq[d]);
+  int kv_end = p.Skv;
+  if (p.causal) kv_end = min(p.Skv, qblk + 128);
+  for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
+    __syncthreads();
+    stage_tile<WD, true, true>(Ks, Kt, Kg, p.ldk, kv0, p.Skv, p.hd);
+    stage_tile<WD, true, false>(Vs, nullptr, Vg, p.ldv, kv0, p.Skv, p.hd);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s, dp;
+      ZERO16(s);
+      ZERO16(dp);
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Vs, kt * 32 + l31, 2 * j + hi), dof[j], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + kt * 32 + mfma32_row(r, hi);
+        const bool ok = qok && key < p.Skv && (!p.causal || key <= q);
+        const float pv = ok ? exp2f(s[r] * c - lse2) : 0.f;
+        s[r] = pv * (dp[r] - delta) * p.scale;  // dS^T
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f16x8 dsf = pack8(s, 8 * jj);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Kt, d * 32 + l31, kt * 32 + 16 * jj, hi), dsf, dq[d], 0, 0, 0);
+      }
+    }
+  }
+  if (qok) {
+    f16* dQg = (f16*)p.dQ + ((int64_t)b * p.Sq + q) * p.lddq + h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < p.hd) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)dq[d][4 * r4 + e];
+          *(f16x4*)(dQg + col) = v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int DT, int KS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const tb_attn_desc p) {
+  constexpr int WD = DT * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16* Qs = reinterpret_cast<f16*>(smem_raw);
+  f16* dOs = Qs + RM<WD>::SIZE;
+  f16* Qt = dOs + RM<WD>::SIZE;
+  f16* dOt = Qt + TR<WD>::SIZE;
+  float* lse_s = reinterpret_cast<float*>(dOt + TR<WD>::SIZE);
+  float* del_s = lse_s + KVT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kblk = blockIdx.x * 128;
+  const int key = kblk + wave * 32 + l31;
+  const bool kok = key < p.Skv;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * p.hd;
+  const f16* dOg = (const f16*)p.dO + (int64_t)b * p.Sq * p.lddo + h * p.hd;
+  const float* LSEg = p.LSE + ((int64_t)b * p.H + h) * p.Sq;
+  const float* DELg = p.Delta + ((int64_t)b * p.H + h) * p.Sq;
+  f16x8 kf[KS], vf[KS];
+  load_row_frags<KS>(kf, Kg, p.ldk, key, p.Skv, p.hd, hi);
+  load_row_frags<KS>(vf, Vg, p.ldv, key, p.Skv, p.hd, hi);
+  const float c = p.scale * LOG2E;
+  f32x16 dk[DT], dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    ZERO16(dk[d]);
+    ZERO16(dv[d]);
+  }
+  int q_begin = 0;
+  if (p.causal) q_begin = (kblk / KVT) * KVT;  // queries before the block's first key see none of its keys
+  for (int q0 = q_begin; q0 < p.Sq; q0 += KVT) {
+    __syncthreads();
+    stage_tile<WD, true, true>(Qs, Qt, Qg, p.ldq, q0, p.Sq, p.hd);
+    stage_tile<WD, true, true>(dOs, dOt, dOg, p.lddo, q0, p.Sq, p.hd);
+    if (threadIdx.x < KVT) {
+      const int qq = q0 + threadIdx.x;
+      lse_s[threadIdx.x] = qq < p.Sq ? LSEg[qq] * LOG2E : 0.f;
+      del_s[threadIdx.x] = qq < p.Sq ? DELg[qq] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 s, dp;
+      ZERO16(s);
+      ZERO16(dp);
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Qs, qt * 32 + l31, 2 * j + hi), kf[j], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(dOs, qt * 32 + l31, 2 * j + hi), vf[j], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = qt * 32 + mfma32_row(r, hi);
+        const int qq = q0 + ql;
+        const bool ok = kok && qq < p.Sq && (!p.causal || key <= qq);
+        const float pv = ok ? exp2f(s[r] * c - lse_s[ql]) : 0.f;
+        s[r] = pv;                                          // P
+        dp[r] = pv * (dp[r] - del_s[ql]) * p.scale;         // dS
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f16x8 pf = pack8(s, 8 * jj);
+        const f16x8 dsf = pack8(dp, 8 * jj);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(dOt, d * 32 + l31, qt * 32 + 16 * jj, hi), pf, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Qt, d * 32 + l31, qt * 32 + 16 * jj, hi), dsf, dk[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kok) {
+    f16* dKg = (f16*)p.dK + ((int64_t)b * p.Skv + key) * p.lddk + h * p.hd;
+    f16* dVg = (f16*)p.dV + ((int64_t)b * p.Skv + key) * p.lddv + h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < p.hd) {
+          f16x4 a, bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = (f16)dk[d][4 * r4 + e];
+            bb[e] = (f16)dv[d][4 * r4 + e];
+          }
+          *(f16x4*)(dKg + col) = a;
+          *(f16x4*)(dVg + col) = bb;
+        }
+      }
+  }
+}
+
+template <int DT, int KS>
+int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
+  constexpr int WD = DT * 32;
+  size_t lds = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16);
+  dim3 grid((d.Sq + 127) / 128, d.H, d.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<DT, KS>), grid, dim3(256), lds, s, d);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+template <int DT, int KS>
+int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
+  constexpr int WD = DT * 32;
+  {
+    int64_t total = (int64_t)d.B * d.Sq * d.H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+  }
+  {
+    size_t lds = (2 * RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16);
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+      if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return TB_ELAUNCH;
+      attr_done = true;
+    }
+    dim3 grid((d.Sq + 127) / 128, d.H, d.B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d);
+  }
+  {
+    size_t lds = (2 * RM<WD>::SIZE + 2 * TR<WD>::SIZE) * sizeof(f16) + 2 * KVT * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+      if (hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return TB_ELAUNCH;
+      attr_done = true;
+    }
+    dim3 grid((d.Skv + 127) / 128, d.H, d.B);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, KS>), grid, dim3(256), lds, s, d);
+  }
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+int check_desc(const tb_attn_desc& d, bool bwd) {
+  if (d.B <= 0 || d.H <= 0 || d.Sq <= 0 || d.Skv <= 0 || d.hd <= 0 || d.hd % 8 || d.hd > 160) return TB_EINVAL;
+  if (!d.Q || !d.K || !d.V || !d.O) return TB_EINVAL;
+  if (d.ldq % 8 || d.ldk % 8 || d.ldv % 8 || d.ldo % 4) return TB_EINVAL;
+  if (bwd) {
+    if (!d.dO || !d.dQ || !d.dK || !d.dV || !d.LSE || !d.Delta) return TB_EINVAL;
+    if (d.lddo % 8 || d.lddq % 4 || d.lddk % 4 || d.lddv % 4 || d.ldo % 8) return TB_EINVAL;
+  }
+  return TB_OK;
+}
+
+#define DISPATCH_HD(FN, d, s)                              \
+  do {                                                     \
+    const int ks_ = ((d).hd + 15) / 16;                    \
+    switch (ks_) {                                         \
+      case 1: case 2: return FN<1, 2>(d, s);               \
+      case 3: return FN<2, 3>(d, s);                       \
+      case 4: return FN<2, 4>(d, s);                       \
+      case 5: return FN<3, 5>(d, s);                       \
+      case 6: return FN<3, 6>(d, s);                       \
+      case 7: case 8: return FN<4, 8>(d, s);               \
+      case 9: case 10: return FN<5, 10>(d, s);             \
+      default: return TB_EINVAL;                           \
+    }                                                      \
+  } while (0)
+
+}  // namespace
+
+extern "C" int tb_attention_fwd(const tb_attn_desc* dp, tb_stream_t stream) {
+  if (!dp) return TB_EINVAL;
+  const tb_attn_desc d = *dp;
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  DISPATCH_HD(launch_fwd, d, (hipStream_t)stream);
+}
+
+extern "C" int tb_attention_bwd(const tb_attn_desc* dp, tb_stream_t stream) {
+  if (!dp) return TB_EINVAL;
+  const tb_attn_desc d = *dp;
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  DISPATCH_HD(launch_bwd, d, (hipStream_t)stream);
+}

@@ -1,0 +1,485 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and input-gradient, for NHWC / row-major fp16 activations on gfx950.
+// All four are HBM-bound streaming kernels: 16-byte vector loads (8 halfs per lane), fp32 statistics,
+// deterministic two-stage reductions (no float atomics), explicit row strides so tensors may be column slices
+// of wider (concat) buffers.
+//
+// Replaces torch.nn.GroupNorm / F.silu / torch.nn.LayerNorm (and their autograd) that diffusers' ResnetBlock2D,
+// Transformer2DModel, BasicTransformerBlock and transformers' CLIPEncoderLayer dispatch from
+// train_textboost.py:1063-1067 (forward) and :1108 (backward).
+#include "common.h"
+#include "../../include/textboost_hip.h"
+
+namespace {
+
+constexpr int GN_MAXC = 4096;
+
+struct GnMap {  // thread -> (column-vector, row-lane) mapping shared by the four GroupNorm kernels
+  int cols, cw, nrl, col0, rl;
+  bool active;
+  __device__ GnMap(int C) {
+    cols = C >> 3;
+    cw = cols < 256 ? cols : 256;
+    nrl = 256 / cw;
+    int t = threadIdx.x;
+    active = t < cw * nrl;
+    col0 = t % cw;
+    rl = t / cw;
+  }
+};
+
+__host__ __device__ inline int gn_chunks(int B, int HW, int C) {
+  int cols = C >> 3;
+  int cw = cols < 256 ? cols : 256;
+  int nrl = 256 / cw;
+  int n = (HW + nrl * 4 - 1) / (nrl * 4);
+  int cap = 2048 / (B > 0 ? B : 1);
+  if (cap < 1) cap = 1;
+  if (n > cap) n = cap;
+  if (n < 1) n = 1;
+  return n;
+}
+
+// Reduce per-thread per-channel partial sums (two quantities) to per-group sums and write them to
+// part[(b*nchunks + chunk)*G*2 + g*2 + {0,1}].
+__device__ __forceinline__ void gn_block_group_reduce(const GnMap& mp, float (*s)[8], float (*q)[8], int C, int G,
+                                                      float* lds /* 2*nrl*C floats */, float* part_out) {
+  const int gs = C / G;
+  float* ls = lds;
+  float* lq = lds + mp.nrl * C;
+  if (mp.active) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cc = mp.col0 + k * mp.cw;
+      if (cc >= mp.cols) break;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ls[mp.rl * C + cc * 8 + e] = s[k][e];
+        lq[mp.rl * C + cc * 8 + e] = q[k][e];
+      }
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 2 * G) {
+    const int g = t >> 1;
+    const float* src = (t & 1) ? lq : ls;
+    float a = 0.f;
+    for (int r = 0; r < mp.nrl; ++r)
+      for (int ch = g * gs; ch < (g + 1) * gs; ++ch) a += src[r * C + ch];
+    part_out[g * 2 + (t & 1)] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X, int64_t ldx, float* __restrict__ part, int HW,
+                                                       int C, int G, int nchunks) {
+  __shared__ float lds[2 * GN_MAXC];
+  const GnMap mp(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  const int r_begin = chunk * rpc, r_end = min(HW, r_begin + rpc);
+  float s[2][8], q[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[k][e] = q[k][e] = 0.f;
+  if (mp.active) {
+    const f16* base = X + (int64_t)b * HW * ldx;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cc = mp.col0 + k * mp.cw;
+      if (cc >= mp.cols) break;
+      for (int r = r_begin + mp.rl; r < r_end; r += mp.nrl) {
+        f16x8 v = *(const f16x8*)(base + (int64_t)r * ldx + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)v[e];
+          s[k][e] += f;
+          q[k][e] += f * f;
+        }
+      }
+    }
+  }
+  gn_block_group_reduce(mp, s, q, C, G, lds, part + ((int64_t)b * nchunks + chunk) * G * 2);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ part, float* __restrict__ stats, int HW, int C,
+                                                       int G, int nchunks, float eps, int silu) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const GnMap mp(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int gs = C / G;
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      const float* p = part + ((int64_t)b * nchunks + c) * G * 2 + g * 2;
+      s += p[0];
+      q += p[1];
+    }
+    const float n = (float)gs * (float)HW;
+    const float mean = s / n;
+    const float var = fmaxf(q / n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    mean_s[g] = mean;
+    rstd_s[g] = rstd;
+    if (chunk == 0) {
+      stats[((int64_t)b * G + g) * 2 + 0] = mean;
+      stats[((int64_t)b * G + g) * 2 + 1] = rstd;
+    }
+  }
+  __syncthreads();
+  if (!mp.active) return;
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  const int r_begin = chunk * rpc, r_end = min(HW, r_begin + rpc);
+  const f16* xb = X + (int64_t)b * HW * ldx;
+  f16* yb = Y + (int64_t)b * HW * ldy;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int cc = mp.col0 + k * mp.cw;
+    if (cc >= mp.cols) break;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int ch = cc * 8 + e;
+      int g = ch / gs;
+      sc[e] = rstd_s[g] * gamma[ch];
+      sh[e] = beta[ch] - mean_s[g] * sc[e];
+    }
+    for (int r = r_begin + mp.rl; r < r_end; r += mp.nrl) {
+      f16x8 v = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = (float)v[e] * sc[e] + sh[e];
+        o[e] = (f16)(silu ? silu_f(z) : z);
+      }
+      *(f16x8*)(yb + (int64_t)r * ldy + cc * 8) = o;
+    }
+  }
+}
+
+// backward pass 1: per (b, group) sums of dyh = dz*gamma and dyh*xhat, where dz = dOut * silu'(z)
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ X,
+                                                           int64_t ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stats,
+                                                           float* __restrict__ part, int HW, int C, int G, int nchunks, int silu) {
+  __shared__ float lds[2 * GN_MAXC];
+  const GnMap mp(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int gs = C / G;
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  const int r_begin = chunk * rpc, r_end = min(HW, r_begin + rpc);
+  float s[2][8], q[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[k][e] = q[k][e] = 0.f;
+  if (mp.active) {
+    const f16* xb = X + (int64_t)b * HW * ldx;
+    const f16* dyb = dY + (int64_t)b * HW * lddy;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cc = mp.col0 + k * mp.cw;
+      if (cc >= mp.cols) break;
+      float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int ch = cc * 8 + e;
+        int g = ch / gs;
+        mu[e] = stats[((int64_t)b * G + g) * 2];
+        rs[e] = stats[((int64_t)b * G + g) * 2 + 1];
+        ga[e] = gamma[ch];
+        be[e] = beta[ch];
+      }
+      for (int r = r_begin + mp.rl; r < r_end; r += mp.nrl) {
+        f16x8 xv = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
+        f16x8 dv = *(const f16x8*)(dyb + (int64_t)r * lddy + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = ((float)xv[e] - mu[e]) * rs[e];
+          float d = (float)dv[e];
+          if (silu) d *= silu_grad_f(xh * ga[e] + be[e]);
+          d *= ga[e];
+          s[k][e] += d;
+          q[k][e] += d * xh;
+        }
+      }
+    }
+  }
+  gn_block_group_reduce(mp, s, q, C, G, lds, part + ((int64_t)b * nchunks + chunk) * G * 2);
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ X,
+                                                           int64_t ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stats,
+                                                           const float* __restrict__ part, const f16* __restrict__ add,
+                                                           int64_t ldadd, f16* __restrict__ dX, int64_t lddx, int HW, int C, int G,
+                                                           int nchunks, int silu) {
+  __shared__ float s1_s[64], s2_s[64];
+  const GnMap mp(C);
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int gs = C / G;
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      const float* p = part + ((int64_t)b * nchunks + c) * G * 2 + g * 2;
+      s += p[0];
+      q += p[1];
+    }
+    const float n = (float)gs * (float)HW;
+    s1_s[g] = s / n;
+    s2_s[g] = q / n;
+  }
+  __syncthreads();
+  if (!mp.active) return;
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  const int r_begin = chunk * rpc, r_end = min(HW, r_begin + rpc);
+  const f16* xb = X + (int64_t)b * HW * ldx;
+  const f16* dyb = dY + (int64_t)b * HW * lddy;
+  const f16* ab = add ? add + (int64_t)b * HW * ldadd : nullptr;
+  f16* dxb = dX + (int64_t)b * HW * lddx;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int cc = mp.col0 + k * mp.cw;
+    if (cc >= mp.cols) break;
+    float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int ch = cc * 8 + e;
+      int g = ch / gs;
+      mu[e] = stats[((int64_t)b * G + g) * 2];
+      rs[e] = stats[((int64_t)b * G + g) * 2 + 1];
+      ga[e] = gamma[ch];
+      be[e] = beta[ch];
+      m1[e] = s1_s[g];
+      m2[e] = s2_s[g];
+    }
+    for (int r = r_begin + mp.rl; r < r_end; r += mp.nrl) {
+      f16x8 xv = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
+      f16x8 dv = *(const f16x8*)(dyb + (int64_t)r * lddy + cc * 8);
+      f16x8 av;
+      if (ab) av = *(const f16x8*)(ab + (int64_t)r * ldadd + cc * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = ((float)xv[e] - mu[e]) * rs[e];
+        float d = (float)dv[e];
+        if (silu) d *= silu_grad_f(xh * ga[e] + be[e]);
+        d *= ga[e];
+        float dx = rs[e] * (d - m1[e] - xh * m2[e]);
+        if (ab) dx += (float)av[e];
+        o[e] = (f16)dx;
+      }
+      *(f16x8*)(dxb + (int64_t)r * lddx + cc * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm
+constexpr int LN_MAXV = 3;  // vectors of 8 per lane -> C <= 1536
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float* out);
+template <>
+__device__ __forceinline__ void load8<f16>(const f16* p, float* out) {
+  f16x8 v = *(const f16x8*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[e] = (float)v[e];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float* out) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    out[e] = a[e];
+    out[4 + e] = b[e];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store8<f16>(f16* p, const float* v) {
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+  *(f16x8*)p = o;
+}
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float* v) {
+  f32x4 a, b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = v[e];
+    b[e] = v[4 + e];
+  }
+  *(f32x4*)p = a;
+  *(f32x4*)(p + 4) = b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ stats, int64_t M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = C >> 3;
+  float v[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vi = lane + 64 * k;
+    if (vi < nv) {
+      load8<T>(X + row * ldx + vi * 8, v[k]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[k][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vi = lane + 64 * k;
+    if (vi < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = v[k][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0 && stats) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vi = lane + 64 * k;
+    if (vi < nv) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * gamma[vi * 8 + e] + beta[vi * 8 + e];
+      store8<f16>(Y + row * ldy + vi * 8, o);
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ add],  g = dy * gamma.   T = dtype of x / add / dx.
+template <typename T, typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dY, int64_t lddy, const T* __restrict__ X, int64_t ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                     const T* __restrict__ add, int64_t ldadd, T* __restrict__ dX, int64_t lddx,
+                                                     int64_t M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = C >> 3;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float g[LN_MAXV][8], xh[LN_MAXV][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vi = lane + 64 * k;
+    if (vi < nv) {
+      float xv[8], dv[8];
+      load8<T>(X + row * ldx + vi * 8, xv);
+      load8<TDY>(dY + row * lddy + vi * 8, dv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[k][e] = (xv[e] - mean) * rstd;
+        g[k][e] = dv[e] * gamma[vi * 8 + e];
+        s1 += g[k][e];
+        s2 += g[k][e] * xh[k][e];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vi = lane + 64 * k;
+    if (vi < nv) {
+      float o[8];
+      if (add) load8<T>(add + row * ldadd + vi * 8, o);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += rstd * (g[k][e] - s1 - xh[k][e] * s2);
+      store8<T>(dX + row * lddx + vi * 8, o);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t tb_groupnorm_ws_floats(int B, int HW, int C, int G) { return (int64_t)B * gn_chunks(B, HW, C) * G * 2; }
+
+extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
+                                float* stats, float* ws, int B, int HW, int C, int G, float eps, int silu, tb_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !stats || !ws) return TB_EINVAL;
+  if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || ldy % 8 || B <= 0 || HW <= 0) return TB_EINVAL;
+  const int nch = gn_chunks(B, HW, C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, ws, HW, C, G, nch);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, ws, stats, HW, C,
+                     G, nch, eps, silu);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                                const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx, float* ws, int B, int HW,
+                                int C, int G, int silu, tb_stream_t stream) {
+  if (!dy || !x || !gamma || !beta || !stats || !dx || !ws) return TB_EINVAL;
+  if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8)) return TB_EINVAL;
+  const int nch = gn_chunks(B, HW, C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
+                     ws, HW, C, G, nch, silu);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
+                     ws, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, nch, silu);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, const float* gamma, const float* beta,
+                                float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
+  if (!x || !y || !gamma || !beta || M <= 0) return TB_EINVAL;
+  if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || ldy % 8) return TB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (x_dtype == TB_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<f16>, grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,
+                                const float* gamma, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx,
+                                int64_t M, int C, tb_stream_t stream) {
+  if (!dy || !x || !gamma || !stats || !dx || M <= 0) return TB_EINVAL;
+  if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8)) return TB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (x_dtype == TB_F32 && dy_dtype == TB_F16)
+    hipLaunchKernelGGL((ln_bwd_kernel<float, f16>), grid, dim3(256), 0, s, (const f16*)dy, lddy, (const float*)x, ldx, gamma, stats,
+                       (const float*)add, ldadd, (float*)dx, lddx, M, C);
+  else if (x_dtype == TB_F32 && dy_dtype == TB_F32)
+    hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)dy, lddy, (const float*)x, ldx, gamma,
+                       stats, (const float*)add, ldadd, (float*)dx, lddx, M, C);
+  else if (x_dtype == TB_F16 && dy_dtype == TB_F16)
+    hipLaunchKernelGGL((ln_bwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, stats,
+                       (const f16*)add, ldadd, (f16*)dx, lddx, M, C);
+  else
+    return TB_EINVAL;
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
