@@ -25,7 +25,7 @@ typedef void* tb_stream_t; /* hipStream_t */
 
 /* ---- dtype / activation codes ------------------------------------------------------------- */
 enum { TB_F16 = 0, TB_F32 = 1 };
-enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2 };
+enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2, TB_ACT_SILU = 3, TB_ACT_QUICK_GELU_GRAD = 4 };
 enum { TB_A_LINEAR = 0, TB_A_CONV3X3 = 1 };
 
 /* ---- MFMA GEMM family: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), fp16 in, fp32 accumulate ------
@@ -52,11 +52,13 @@ typedef struct tb_gemm_desc {
   float alpha;
   const float* bias;             /* fp32 [N] or NULL */
   const float* rowbias;          /* fp32 [M/rows_per_group, N] or NULL (ResnetBlock2D time_emb_proj term) */
-  int64_t rows_per_group;
+  int64_t rows_per_group; int64_t ldrb; /* row stride of rowbias (>= N) */
   const void* R; int64_t ldr; int32_t r_dtype; /* residual, fp16 or fp32, or NULL */
   int32_t act;                   /* GEGLU: W rows interleaved in 32-row blocks [h|g]; C is [M, N/2] */
   void* C; int64_t ldc; int32_t c_dtype;
-  void* C2; int64_t ldc2;        /* GEGLU only: raw (pre-gate) fp16 [M,N] in packed column order, or NULL */
+  void* C2; int64_t ldc2;        /* fp16 [M,N] aux: GEGLU: raw pre-gate output (packed order), written;
+                                  * QUICK_GELU: pre-activation, written (if non-NULL);
+                                  * QUICK_GELU_GRAD: pre-activation, READ: v *= quick_gelu'(C2[m,n]) */
   int32_t split_k;               /* reserved, must be 0 or 1 */
 } tb_gemm_desc;
 
@@ -105,6 +107,70 @@ typedef struct tb_attn_desc {
 } tb_attn_desc;
 int tb_attention_fwd(const tb_attn_desc* d, tb_stream_t stream);
 int tb_attention_bwd(const tb_attn_desc* d, tb_stream_t stream);
+
+/* ---- scheduler / boundary / loss / misc streaming kernels ------------------------------------------ */
+/* noise_scheduler.add_noise (:1052) [+ get_velocity (:1073) when velocity != NULL]; fp32 NCHW in, fp16 noisy out */
+int tb_add_noise(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod, void* noisy,
+                 float* velocity, int B, int64_t per_sample, tb_stream_t stream);
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0): out fp16 [B, dim] = [cos | sin] */
+int tb_timestep_embed(const int64_t* timesteps, void* out, int B, int dim, tb_stream_t stream);
+/* 3x3 conv whose NCHW side has 4 channels -> NHWC fp16 [B*H*W, Cout]: UNet conv_in forward (sign=+1) and conv_out
+ * input-gradient (sign=-1).  w_packed fp32 [(tap*4 + c4)*Cout + co]. */
+int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
+                     int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream);
+/* UNet conv_out forward: NHWC fp16 [B*H*W, C] -> NCHW fp16 [B,4,H,W]; w_packed fp32 [4][9][C] */
+int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, const float* bias, void* out, int B, int H, int W, int C,
+                tb_stream_t stream);
+/* F.mse_loss(pred.float(), target.float()).mean() (:1085-1090); dpred = loss_scale[0] * dloss/dpred (fp32) */
+int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
+                tb_stream_t stream);
+/* knowledge-preservation loss, cos variant (:1099-1106): loss_out = mean_rows(1 - cos(h, h0));
+ * dh = weight * loss_scale[0] * dloss/dh.  partial = M floats scratch. */
+int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,
+               float* partial, float* loss_out, const float* loss_scale, float weight, int64_t M, int D, tb_stream_t stream);
+/* backward of diffusers GEGLU on the packed [h32|g32] layout tb_gemm(TB_ACT_GEGLU) saved in C2 */
+int tb_geglu_bwd(const void* dout, int64_t lddo, const void* raw, int64_t ldr, void* dproj, int64_t lddp, int64_t M,
+                 int inner, tb_stream_t stream);
+/* backward of F.interpolate(scale 2, nearest): dx[b,y,x,:] = sum of the 2x2 block of du (NHWC fp16) */
+int tb_pool2x2_sum(const void* du, int64_t ldu, void* dx, int64_t ldx, int B, int H, int W, int C, tb_stream_t stream);
+int tb_add_f16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t M, int C, tb_stream_t stream);
+int tb_convert(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int64_t M, int C, float scale,
+               tb_stream_t stream);
+
+/* ---- text-encoder small kernels ------------------------------------------------------------------- */
+/* CLIPTextEmbeddings: out[m] = tok[ids[m]] + pos[m % T]; (fp32 table -> fp32 out) or (fp16 -> fp16, KPL teacher) */
+int tb_embed_fwd(const int64_t* ids, const void* tok, const void* pos, int table_dtype, void* out, int out_dtype, int64_t M,
+                 int T, int D, tb_stream_t stream);
+/* g_added[a] += sum over positions with ids == first_added + a of dh (rows below first_added get no gradient, :1109-1117) */
+int tb_embed_bwd(const float* dh, const int64_t* ids, float* g_added, int64_t M, int D, int64_t first_added, int n_added,
+                 tb_stream_t stream);
+/* TextBoostModel.forward pins, textboost/text_encoder.py:71-86, and their (zero) gradient */
+int tb_textboost_pin_fwd(void* h, int h_dtype, const int64_t* ids, const float* null_embedding, int B, int T, int D,
+                         int use_fixed, int64_t eos_id, tb_stream_t stream);
+int tb_textboost_pin_bwd(float* dh, const int64_t* ids, int B, int T, int D, int use_fixed, int64_t eos_id, tb_stream_t stream);
+/* peft lora.Linear pieces (train_textboost.py:700-722): P adapters (q,k,v) stacked: A fp32 [P*r, K], Bcat fp32 [P*D, r] */
+int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t, int64_t ldt, int64_t M, int K, int R, tb_stream_t stream);
+int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd /*fp16 [P*D,64]*/, void* w2_dgrad /*fp16 [K,64]*/, int D, int K,
+                 int r, int P, float scaling, tb_stream_t stream);
+int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
+                void* dt, int64_t lddt, float* dA, float* dB, int64_t M, int D, int K, int r, int P, float scaling,
+                tb_stream_t stream);
+
+/* ---- optimizer tail: all scalars stay on the device in `state` (fp32[TB_ST_COUNT]) ------------------- */
+enum { TB_ST_LOSS_SCALE = 0, TB_ST_GROWTH_TRACKER = 1, TB_ST_STEP = 2, TB_ST_FOUND_INF = 3, TB_ST_COEF_LORA = 4,
+       TB_ST_COEF_EMB = 5, TB_ST_BC1 = 6, TB_ST_BC2 = 7, TB_ST_GRAD_NORM = 8, TB_ST_SUMSQ_LORA = 9, TB_ST_SUMSQ_EMB = 10,
+       TB_ST_LOSS_MSE = 11, TB_ST_LOSS_KPL = 12, TB_ST_COUNT = 16 };
+int tb_sumsq(const float* x, int64_t n, float* out, tb_stream_t stream);
+/* GradScaler unscale/inf-check/update + clip_grad_norm_ coefficient + Adam bias corrections (:1108, :1128-1134) */
+int tb_scaler_update(float* state, float max_norm, float beta1, float beta2, float growth_factor, float backoff_factor,
+                     float growth_interval, int use_scaler, tb_stream_t stream);
+/* torch.optim.AdamW step on a flat fp32 buffer; g is multiplied by state[coef_slot]; skipped when state says inf */
+int tb_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+             const float* state, int coef_slot, tb_stream_t stream);
+int tb_weight_decay(float* p, int64_t n, float factor, const float* state, tb_stream_t stream);
+/* added-row norm clamp (:1138-1149) and row norms for mean_norm (:1017) */
+int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, float* norms, tb_stream_t stream);
+int tb_row_norms(const float* w, int64_t rows, int D, float* norms, tb_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtextboost_hip.so")
 
 TB_F16, TB_F32 = 0, 1
-ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
+(ST_LOSS_SCALE, ST_GROWTH_TRACKER, ST_STEP, ST_FOUND_INF, ST_COEF_LORA, ST_COEF_EMB, ST_BC1, ST_BC2, ST_GRAD_NORM,
+ ST_SUMSQ_LORA, ST_SUMSQ_EMB, ST_LOSS_MSE, ST_LOSS_KPL) = range(13)
+ST_COUNT = 16
 A_LINEAR, A_CONV3X3 = 0, 1
 
 
@@ -27,7 +30,7 @@ class GemmDesc(C.Structure):
         ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
         ("Wout", C.c_int32), ("stride", C.c_int32), ("sign", C.c_int32), ("upsample", C.c_int32), ("transposed", C.c_int32),
         ("alpha", C.c_float),
-        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int64),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int64), ("ldrb", C.c_int64),
         ("R", C.c_void_p), ("ldr", C.c_int64), ("r_dtype", C.c_int32),
         ("act", C.c_int32),
         ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int32),
@@ -65,6 +68,29 @@ _SIGS = {
     "tb_layernorm_bwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_attention_fwd": ([C.POINTER(AttnDesc), _VP], C.c_int),
     "tb_attention_bwd": ([C.POINTER(AttnDesc), _VP], C.c_int),
+    "tb_add_noise": ([_VP, _VP, _VP, _VP, _VP, _VP, _I, _I64, _VP], C.c_int),
+    "tb_timestep_embed": ([_VP, _VP, _I, _I, _VP], C.c_int),
+    "tb_conv4_to_nhwc": ([_VP, _I, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_conv_to4": ([_VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_mse_loss": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP], C.c_int),
+    "tb_kpl_cos": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),
+    "tb_geglu_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
+    "tb_pool2x2_sum": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_add_f16": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
+    "tb_convert": ([_VP, _I64, _I, _VP, _I64, _I, _I64, _I, _F, _VP], C.c_int),
+    "tb_embed_fwd": ([_VP, _VP, _VP, _I, _VP, _I, _I64, _I, _I, _VP], C.c_int),
+    "tb_embed_bwd": ([_VP, _VP, _VP, _I64, _I, _I64, _I, _VP], C.c_int),
+    "tb_textboost_pin_fwd": ([_VP, _I, _VP, _VP, _I, _I, _I, _I, _I64, _VP], C.c_int),
+    "tb_textboost_pin_bwd": ([_VP, _VP, _I, _I, _I, _I, _I64, _VP], C.c_int),
+    "tb_lora_down": ([_VP, _I64, _VP, _VP, _I64, _I64, _I, _I, _VP], C.c_int),
+    "tb_lora_pack": ([_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_lora_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _VP, _VP, _I64, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_sumsq": ([_VP, _I64, _VP, _VP], C.c_int),
+    "tb_scaler_update": ([_VP, _F, _F, _F, _F, _F, _F, _I, _VP], C.c_int),
+    "tb_adamw": ([_VP, _VP, _VP, _VP, _I64, _F, _F, _F, _F, _F, _VP, _I, _VP], C.c_int),
+    "tb_weight_decay": ([_VP, _I64, _F, _VP, _VP], C.c_int),
+    "tb_renorm_rows": ([_VP, _I, _I, _F, _VP, _VP], C.c_int),
+    "tb_row_norms": ([_VP, _I64, _I, _VP, _VP], C.c_int),
 }
 
 

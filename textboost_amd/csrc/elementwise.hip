@@ -1,0 +1,357 @@
+// Small streaming kernels of the TextBoost step on gfx950: scheduler noise, 4-channel convs at the UNet boundary,
+// losses, GEGLU backward, nearest-upsample backward, residual adds, timestep embedding.
+// Reference call sites are cited per kernel (all in /root/reference/train_textboost.py unless noted).
+#include "common.h"
+#include "../../include/textboost_hip.h"
+
+namespace {
+
+// ---- :1052 noise_scheduler.add_noise (+ :1073 get_velocity): fp32 NCHW in, fp16 NCHW noisy out
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                 const float* __restrict__ acp, f16* __restrict__ noisy, float* __restrict__ velocity,
+                                 int64_t per_sample, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / per_sample);
+  const float a = acp[t[b]];
+  const float sa = sqrtf(a), sb = sqrtf(1.f - a);
+  const float x = x0[i], n = noise[i];
+  noisy[i] = (f16)(sa * x + sb * n);
+  if (velocity) velocity[i] = sa * n - sb * x;
+}
+
+// ---- Timesteps(320, flip_sin_to_cos=True, shift 0) of the UNet time embedding: out fp16 [B, dim] = [cos | sin]
+__global__ void timestep_embed_kernel(const int64_t* __restrict__ t, f16* __restrict__ out, int B, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i - b * dim, half = dim / 2;
+  const int k = j < half ? j : j - half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float arg = (float)t[b] * f;
+  out[i] = (f16)(j < half ? cosf(arg) : sinf(arg));
+}
+
+// ---- 3x3 conv with 4 channels on the NCHW side (UNet conv_in forward; conv_out input-gradient), fp32 accumulate.
+// out[m, co] (NHWC fp16, row stride ldo) = bias[co] + sum_{tap, ci<4} in[b, ci, y+sign*(ky-1), x+sign*(kx-1)] * Wp[(tap*4+ci)*Cout + co]
+template <typename TIN>
+__global__ __launch_bounds__(256) void conv4_to_nhwc_kernel(const TIN* __restrict__ in, const float* __restrict__ Wp,
+                                                            const float* __restrict__ bias, f16* __restrict__ out, int64_t ldo,
+                                                            int B, int H, int W, int Cout, int sign, float in_scale) {
+  const int groups = Cout >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t M = (int64_t)B * H * W;
+  if (idx >= M * groups) return;
+  const int64_t m = idx / groups;
+  const int cg = (int)(idx - m * groups);
+  const int b = (int)(m / (H * W));
+  const int rem = (int)(m - (int64_t)b * H * W);
+  const int y = rem / W, x = rem - y * W;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[cg * 8 + e] : 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
+    if (sy < 0 || sx < 0 || sy >= H || sx >= W) continue;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const float v = (float)in[(((int64_t)b * 4 + ci) * H + sy) * W + sx] * in_scale;
+      const float* w = Wp + (int64_t)(tap * 4 + ci) * Cout + cg * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v * w[e];
+    }
+  }
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)acc[e];
+  *(f16x8*)(out + m * ldo + cg * 8) = o;
+}
+
+// ---- UNet conv_out forward: NHWC fp16 [M, C] -> NCHW fp16 [B, 4, H, W]; one wave per output pixel.
+// Wp fp32 [4][9][C]
+__global__ __launch_bounds__(256) void conv_to4_kernel(const f16* __restrict__ in, int64_t ldi, const float* __restrict__ Wp,
+                                                       const float* __restrict__ bias, f16* __restrict__ out, int B, int H, int W,
+                                                       int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t M = (int64_t)B * H * W;
+  if (m >= M) return;
+  const int b = (int)(m / (H * W));
+  const int rem = (int)(m - (int64_t)b * H * W);
+  const int y = rem / W, x = rem - y * W;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int sy = y + ky - 1, sx = x + kx - 1;
+    if (sy < 0 || sx < 0 || sy >= H || sx >= W) continue;
+    const f16* src = in + (((int64_t)b * H + sy) * W + sx) * ldi;
+    for (int c = lane; c < C; c += 64) {
+      const float v = (float)src[c];
+#pragma unroll
+      for (int co = 0; co < 4; ++co) acc[co] += v * Wp[((int64_t)co * 9 + tap) * C + c];
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    const float s = wave_sum(acc[co]);
+    if (lane == 0) out[(((int64_t)b * 4 + co) * H + y) * W + x] = (f16)(s + (bias ? bias[co] : 0.f));
+  }
+}
+
+// ---- :1085-1090 loss = mean((pred.float() - target.float())^2); also d(loss*loss_scale)/d pred.
+// Single block (N = B*4*h*w is small); loss_out[0] = mse (unscaled). dpred fp32 NCHW.
+__global__ __launch_bounds__(1024) void mse_loss_kernel(const f16* __restrict__ pred, const float* __restrict__ target,
+                                                        float* __restrict__ dpred, float* __restrict__ loss_out,
+                                                        const float* __restrict__ loss_scale, int64_t N) {
+  __shared__ float red[16];
+  const float ls = loss_scale ? loss_scale[0] : 1.f;
+  const float gcoef = 2.f / (float)N * ls;
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < N; i += 1024) {
+    const float d = (float)pred[i] - target[i];
+    a += d * d;
+    if (dpred) dpred[i] = gcoef * d;
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    loss_out[0] = s / (float)N;
+  }
+}
+
+// ---- :1099-1106 knowledge-preservation loss, cos variant: mean_rows(1 - cos(h, h0)); grad wrt h (fp32).
+// One wave per row; partial[row] = 1 - cos;  dh = -(weight*loss_scale/M) * (h0/(|h||h0|) - cos * h/|h|^2)
+template <typename T0>
+__global__ __launch_bounds__(256) void kpl_cos_kernel(const float* __restrict__ h, int64_t ldh, const T0* __restrict__ h0,
+                                                      int64_t ldh0, float* __restrict__ dh, int64_t lddh, float* __restrict__ partial,
+                                                      const float* __restrict__ loss_scale, float weight, int64_t M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float dot = 0.f, n1 = 0.f, n2 = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float a = h[row * ldh + c], b = (float)h0[row * ldh0 + c];
+    dot += a * b;
+    n1 += a * a;
+    n2 += b * b;
+  }
+  dot = wave_sum(dot);
+  n1 = wave_sum(n1);
+  n2 = wave_sum(n2);
+  const float eps = 1e-8f;
+  const float na = fmaxf(sqrtf(n1), eps), nb = fmaxf(sqrtf(n2), eps);
+  const float cosv = dot / (na * nb);
+  if (lane == 0) partial[row] = 1.f - cosv;
+  if (dh) {
+    const float coef = -(weight * (loss_scale ? loss_scale[0] : 1.f)) / (float)M;
+    for (int c = lane; c < D; c += 64) {
+      const float a = h[row * ldh + c], b = (float)h0[row * ldh0 + c];
+      dh[row * lddh + c] = coef * (b / (na * nb) - cosv * a / (na * na));
+    }
+  }
+}
+
+// deterministic sum of n floats by one block; out[0] = scale * sum
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float scale) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) a += x[i];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) out[0] = a * scale;
+}
+
+// ---- GEGLU backward on the packed [h32|g32] column order the forward GEMM epilogue saved:
+// dproj[:, blk*64 + j] = dout[:, blk*32+j] * gelu(g);  dproj[:, blk*64+32+j] = dout * h * gelu'(g)
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ dout, int64_t lddo, const f16* __restrict__ raw,
+                                                        int64_t ldr, f16* __restrict__ dproj, int64_t lddp, int64_t M, int inner) {
+  const int vecs = inner >> 3;  // 8 gate outputs per thread
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * vecs) return;
+  const int64_t m = idx / vecs;
+  const int v = (int)(idx - m * vecs);
+  const int col = v * 8;              // output column (0..inner)
+  const int blk = col >> 5, j = col & 31;
+  const f16x8 d = *(const f16x8*)(dout + m * lddo + col);
+  const f16x8 hh = *(const f16x8*)(raw + m * ldr + blk * 64 + j);
+  const f16x8 gg = *(const f16x8*)(raw + m * ldr + blk * 64 + 32 + j);
+  f16x8 dh, dg;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float g = (float)gg[e], dd = (float)d[e];
+    dh[e] = (f16)(dd * gelu_erf_f(g));
+    dg[e] = (f16)(dd * (float)hh[e] * gelu_erf_grad_f(g));
+  }
+  *(f16x8*)(dproj + m * lddp + blk * 64 + j) = dh;
+  *(f16x8*)(dproj + m * lddp + blk * 64 + 32 + j) = dg;
+}
+
+// ---- backward of F.interpolate(nearest, x2): dX[b,y,x,:] = sum of the 2x2 block of dU (NHWC fp16)
+__global__ __launch_bounds__(256) void pool2x2_sum_kernel(const f16* __restrict__ dU, int64_t ldu, f16* __restrict__ dX, int64_t ldx,
+                                                          int B, int H, int W, int C) {
+  const int vecs = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t M = (int64_t)B * H * W;
+  if (idx >= M * vecs) return;
+  const int64_t m = idx / vecs;
+  const int v = (int)(idx - m * vecs);
+  const int b = (int)(m / (H * W));
+  const int rem = (int)(m - (int64_t)b * H * W);
+  const int y = rem / W, x = rem - y * W;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int64_t um = ((int64_t)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx;
+      const f16x8 u = *(const f16x8*)(dU + um * ldu + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)u[e];
+    }
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
+  *(f16x8*)(dX + m * ldx + v * 8) = o;
+}
+
+// ---- out = a + b (fp16 rows with strides); gradient merges at residual / skip fan-outs
+__global__ __launch_bounds__(256) void add_f16_kernel(const f16* __restrict__ a, int64_t lda, const f16* __restrict__ b, int64_t ldb,
+                                                      f16* __restrict__ out, int64_t ldo, int64_t M, int C) {
+  const int vecs = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * vecs) return;
+  const int64_t m = idx / vecs;
+  const int v = (int)(idx - m * vecs);
+  const f16x8 x = *(const f16x8*)(a + m * lda + v * 8);
+  const f16x8 y = *(const f16x8*)(b + m * ldb + v * 8);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)((float)x[e] + (float)y[e]);
+  *(f16x8*)(out + m * ldo + v * 8) = o;
+}
+
+// ---- dtype conversion with strides (fp32 <-> fp16), optional scale: used for ehs.to(fp16) (:1066) and its gradient
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ in, int64_t ldi, TO* __restrict__ out, int64_t ldo,
+                                                      int64_t M, int C, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * C) return;
+  const int64_t m = idx / C;
+  const int c = (int)(idx - m * C);
+  out[m * ldo + c] = (TO)((float)in[m * ldi + c] * scale);
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
+
+extern "C" int tb_add_noise(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod, void* noisy,
+                            float* velocity, int B, int64_t per_sample, tb_stream_t stream) {
+  if (!x0 || !noise || !timesteps || !alphas_cumprod || !noisy || B <= 0 || per_sample <= 0) return TB_EINVAL;
+  const int64_t total = (int64_t)B * per_sample;
+  hipLaunchKernelGGL(add_noise_kernel, GRID1D(total), dim3(256), 0, (hipStream_t)stream, x0, noise, timesteps, alphas_cumprod,
+                     (f16*)noisy, velocity, per_sample, total);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_timestep_embed(const int64_t* timesteps, void* out, int B, int dim, tb_stream_t stream) {
+  if (!timesteps || !out || B <= 0 || dim <= 0 || dim % 2) return TB_EINVAL;
+  hipLaunchKernelGGL(timestep_embed_kernel, GRID1D((int64_t)B * dim), dim3(256), 0, (hipStream_t)stream, timesteps, (f16*)out, B, dim);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
+                                int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream) {
+  if (!in || !w_packed || !out || Cout % 8 || ldo % 8 || (sign != 1 && sign != -1)) return TB_EINVAL;
+  const int64_t n = (int64_t)B * H * W * (Cout / 8);
+  if (in_dtype == TB_F32)
+    hipLaunchKernelGGL(conv4_to_nhwc_kernel<float>, GRID1D(n), dim3(256), 0, (hipStream_t)stream, (const float*)in, w_packed, bias,
+                       (f16*)out, ldo, B, H, W, Cout, sign, in_scale);
+  else
+    hipLaunchKernelGGL(conv4_to_nhwc_kernel<f16>, GRID1D(n), dim3(256), 0, (hipStream_t)stream, (const f16*)in, w_packed, bias,
+                       (f16*)out, ldo, B, H, W, Cout, sign, in_scale);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, const float* bias, void* out, int B, int H, int W, int C,
+                           tb_stream_t stream) {
+  if (!in || !w_packed || !out || B <= 0) return TB_EINVAL;
+  const int64_t M = (int64_t)B * H * W;
+  hipLaunchKernelGGL(conv_to4_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)in, ldi, w_packed,
+                     bias, (f16*)out, B, H, W, C);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
+                           tb_stream_t stream) {
+  if (!pred || !target || !loss_out || N <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const f16*)pred, target, dpred, loss_out,
+                     loss_scale, N);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,
+                          float* partial, float* loss_out, const float* loss_scale, float weight, int64_t M, int D, tb_stream_t stream) {
+  if (!h || !h0 || !partial || !loss_out || M <= 0 || D <= 0) return TB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (h0_dtype == TB_F32)
+    hipLaunchKernelGGL(kpl_cos_kernel<float>, grid, dim3(256), 0, s, h, ldh, (const float*)h0, ldh0, dh, lddh, partial, loss_scale,
+                       weight, M, D);
+  else
+    hipLaunchKernelGGL(kpl_cos_kernel<f16>, grid, dim3(256), 0, s, h, ldh, (const f16*)h0, ldh0, dh, lddh, partial, loss_scale, weight,
+                       M, D);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, partial, loss_out, M, 1.f / (float)M);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_geglu_bwd(const void* dout, int64_t lddo, const void* raw, int64_t ldr, void* dproj, int64_t lddp, int64_t M,
+                            int inner, tb_stream_t stream) {
+  if (!dout || !raw || !dproj || inner % 32 || lddo % 8 || ldr % 8 || lddp % 8) return TB_EINVAL;
+  hipLaunchKernelGGL(geglu_bwd_kernel, GRID1D(M * (inner / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, lddo,
+                     (const f16*)raw, ldr, (f16*)dproj, lddp, M, inner);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_pool2x2_sum(const void* du, int64_t ldu, void* dx, int64_t ldx, int B, int H, int W, int C, tb_stream_t stream) {
+  if (!du || !dx || C % 8 || ldu % 8 || ldx % 8) return TB_EINVAL;
+  hipLaunchKernelGGL(pool2x2_sum_kernel, GRID1D((int64_t)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)du, ldu,
+                     (f16*)dx, ldx, B, H, W, C);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_add_f16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t M, int C,
+                          tb_stream_t stream) {
+  if (!a || !b || !out || C % 8 || lda % 8 || ldb % 8 || ldo % 8) return TB_EINVAL;
+  hipLaunchKernelGGL(add_f16_kernel, GRID1D(M * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)a, lda, (const f16*)b, ldb,
+                     (f16*)out, ldo, M, C);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_convert(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int64_t M, int C, float scale,
+                          tb_stream_t stream) {
+  if (!in || !out || M <= 0 || C <= 0) return TB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = GRID1D(M * C);
+  if (in_dtype == TB_F32 && out_dtype == TB_F16)
+    hipLaunchKernelGGL((convert_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)in, ldi, (f16*)out, ldo, M, C, scale);
+  else if (in_dtype == TB_F16 && out_dtype == TB_F32)
+    hipLaunchKernelGGL((convert_kernel<f16, float>), grid, dim3(256), 0, s, (const f16*)in, ldi, (float*)out, ldo, M, C, scale);
+  else if (in_dtype == TB_F32 && out_dtype == TB_F32)
+    hipLaunchKernelGGL((convert_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, M, C, scale);
+  else
+    hipLaunchKernelGGL((convert_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)in, ldi, (f16*)out, ldo, M, C, scale);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}

@@ -220,9 +220,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tb_gemm_desc p) {
         int64_t m = m0 + wm * WTM + i * 32 + mfma32_row(r, hi);
         if (m >= p.M) continue;
         float v = alpha * acc[i][j][r] + bn;
-        if (p.rowbias) v += p.rowbias[(m / p.rows_per_group) * p.N + n];
+        if (p.rowbias) v += p.rowbias[(m / p.rows_per_group) * p.ldrb + n];
         if (p.R) v += (p.r_dtype == TB_F32) ? ((const float*)p.R)[m * p.ldr + n] : (float)((const f16*)p.R)[m * p.ldr + n];
-        if (p.act == TB_ACT_QUICK_GELU) v = quick_gelu_f(v);
+        if (p.act == TB_ACT_QUICK_GELU) {
+          if (p.C2) ((f16*)p.C2)[m * p.ldc2 + n] = (f16)v;
+          v = quick_gelu_f((float)(f16)v);  // fp16 linear output feeds the activation, as under autocast
+        } else if (p.act == TB_ACT_SILU) {
+          v = silu_f(v);
+        } else if (p.act == TB_ACT_QUICK_GELU_GRAD) {
+          v *= quick_gelu_grad_f((float)((const f16*)p.C2)[m * p.ldc2 + n]);
+        }
         if (p.c_dtype == TB_F32) ((float*)p.C)[m * p.ldc + n] = v;
         else ((f16*)p.C)[m * p.ldc + n] = (f16)v;
       }
@@ -251,6 +258,9 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if ((d.A2 == nullptr) != (d.W2 == nullptr)) return TB_EINVAL;
   if (d.lda % 8 || d.ldw % 8 || (d.A2 && (d.lda2 % 8 || d.ldw2 % 8))) return TB_EINVAL;  // 16-byte vector loads
   if (d.rowbias && d.rows_per_group <= 0) return TB_EINVAL;
+  if (d.rowbias && d.ldrb < d.N) d.ldrb = d.N;
+  if (d.act == TB_ACT_QUICK_GELU_GRAD && !d.C2) return TB_EINVAL;
+  if (d.act < 0 || d.act > TB_ACT_QUICK_GELU_GRAD) return TB_EINVAL;
   if (d.split_k > 1) return TB_EINVAL;
   if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;

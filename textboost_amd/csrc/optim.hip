@@ -1,0 +1,168 @@
+// On-device optimizer tail of the TextBoost step (gfx950), no host round trip:
+//   GradScaler unscale + inf check + dynamic scale update   (accelerate fp16; train_textboost.py:1108, :1134)
+//   clip_grad_norm_(text_model.encoder.parameters(), 1.0)     (:1128-1133; only the LoRA tensors have grads there)
+//   AdamW group 0 (token embedding, lr emb_lr) / group 1 (LoRA, lr)  (:828-854, :1134)
+//   embedding re-normalisation of the added rows               (:1138-1149)
+// State lives in one small fp32 device array `st` (see TB_ST_* in the header).
+#include "common.h"
+#include "../../include/textboost_hip.h"
+
+namespace {
+
+// deterministic sum of squares by a single 1024-thread block (n <= a few 1e5)
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = x[i];
+    a += v * v;
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    out[0] = s;
+  }
+}
+
+// one thread: derive every per-step scalar from the two gradient sums of squares
+__global__ void scaler_update_kernel(float* __restrict__ st, float max_norm, float beta1, float beta2, float growth_factor,
+                                     float backoff_factor, float growth_interval, int use_scaler) {
+  const float scale = st[TB_ST_LOSS_SCALE];
+  const float ss_lora = st[TB_ST_SUMSQ_LORA], ss_emb = st[TB_ST_SUMSQ_EMB];
+  const bool found_inf = !(isfinite(ss_lora) && isfinite(ss_emb));
+  const float inv = 1.f / scale;
+  const float total = sqrtf(ss_lora) * inv;                      // norm of the unscaled LoRA grads
+  const float clip = fminf(max_norm / (total + 1e-6f), 1.f);    // torch clip_grad_norm_
+  st[TB_ST_FOUND_INF] = found_inf ? 1.f : 0.f;
+  st[TB_ST_GRAD_NORM] = total;
+  st[TB_ST_COEF_LORA] = inv * clip;
+  st[TB_ST_COEF_EMB] = inv;
+  if (!found_inf) {
+    const float step = st[TB_ST_STEP] + 1.f;
+    st[TB_ST_STEP] = step;
+    st[TB_ST_BC1] = 1.f - powf(beta1, step);
+    st[TB_ST_BC2] = 1.f - powf(beta2, step);
+  }
+  if (use_scaler) {  // torch.cuda.amp.GradScaler.update()
+    if (found_inf) {
+      st[TB_ST_LOSS_SCALE] = scale * backoff_factor;
+      st[TB_ST_GROWTH_TRACKER] = 0.f;
+    } else {
+      const float tr = st[TB_ST_GROWTH_TRACKER] + 1.f;
+      if (tr >= growth_interval) {
+        st[TB_ST_LOSS_SCALE] = scale * growth_factor;
+        st[TB_ST_GROWTH_TRACKER] = 0.f;
+      } else {
+        st[TB_ST_GROWTH_TRACKER] = tr;
+      }
+    }
+  }
+}
+
+// torch.optim.AdamW (decoupled decay first, then Adam update with bias corrections), grads pre-multiplied by coef
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                                    float wd, const float* __restrict__ st, int coef_slot) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (st[TB_ST_FOUND_INF] != 0.f) return;
+  const float gi = g[i] * st[coef_slot];
+  const float bc1 = st[TB_ST_BC1], bc2 = st[TB_ST_BC2];
+  float pi = p[i] * (1.f - lr * wd);
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi;
+}
+
+// rows that never receive gradient: AdamW still applies p *= (1 - lr*wd) every (non-skipped) step
+__global__ __launch_bounds__(256) void decay_kernel(float* __restrict__ p, int64_t n4, float factor, const float* __restrict__ st) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  if (st[TB_ST_FOUND_INF] != 0.f) return;
+  f32x4 x = ((f32x4*)p)[i];
+  x *= factor;
+  ((f32x4*)p)[i] = x;
+}
+
+// w[a] <- w[a] * min(mean_norm, |w[a]|) / |w[a]| ; norms[a] = |w[a]| before clamping  (:1143-1149)
+__global__ __launch_bounds__(256) void renorm_rows_kernel(float* __restrict__ w, int D, float mean_norm, float* __restrict__ norms) {
+  __shared__ float red[4];
+  float* row = w + (int64_t)blockIdx.x * D;
+  float a = 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) a += row[c] * row[c];
+  const float nrm = sqrtf(block_sum_256(a, red));
+  const float f = fminf(mean_norm, nrm) / nrm;
+  for (int c = threadIdx.x; c < D; c += 256) row[c] *= f;
+  if (threadIdx.x == 0 && norms) norms[blockIdx.x] = nrm;
+}
+
+// mean over rows of the L2 row norm of a [rows, D] fp32 table (:1017 mean_norm); two-stage deterministic
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ w, int D, float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  float a = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float x = w[row * D + c];
+    a += x * x;
+  }
+  a = wave_sum(a);
+  if (lane == 0) norms[row] = sqrtf(a);
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
+
+extern "C" int tb_sumsq(const float* x, int64_t n, float* out, tb_stream_t stream) {
+  if (!x || !out || n <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_scaler_update(float* state, float max_norm, float beta1, float beta2, float growth_factor, float backoff_factor,
+                                float growth_interval, int use_scaler, tb_stream_t stream) {
+  if (!state) return TB_EINVAL;
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, max_norm, beta1, beta2, growth_factor,
+                     backoff_factor, growth_interval, use_scaler);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                        const float* state, int coef_slot, tb_stream_t stream) {
+  if (!p || !g || !m || !v || !state || n <= 0) return TB_EINVAL;
+  if (coef_slot != TB_ST_COEF_LORA && coef_slot != TB_ST_COEF_EMB) return TB_EINVAL;
+  hipLaunchKernelGGL(adamw_kernel, GRID1D(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, wd, state,
+                     coef_slot);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_weight_decay(float* p, int64_t n, float factor, const float* state, tb_stream_t stream) {
+  if (!p || !state || n <= 0 || n % 4) return TB_EINVAL;
+  hipLaunchKernelGGL(decay_kernel, GRID1D(n / 4), dim3(256), 0, (hipStream_t)stream, p, n / 4, factor, state);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, float* norms, tb_stream_t stream) {
+  if (!rows || n_rows <= 0 || D <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(renorm_rows_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, rows, D, mean_norm, norms);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_row_norms(const float* w, int64_t rows, int D, float* norms, tb_stream_t stream) {
+  if (!w || !norms || rows <= 0 || rows % 4) return TB_EINVAL;
+  hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)(rows / 4)), dim3(256), 0, (hipStream_t)stream, w, D, norms);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
