@@ -76,11 +76,11 @@ int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
                      const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx, float* ws,
                      int B, int HW, int C, int G, int silu, tb_stream_t stream);
 
-/* ---- LayerNorm over rows [M, C]; x fp16 (UNet) or fp32 (CLIP residual stream), y fp16 -----------
+/* ---- LayerNorm over rows [M, C]; x fp16 (UNet) or fp32 (CLIP residual stream), y fp16|fp32 ----
  * Replaces torch.nn.LayerNorm in diffusers BasicTransformerBlock and transformers CLIPEncoderLayer /
  * final_layer_norm.  stats = [M, 2] (mean, rstd).  bwd: dx = LN'(dy) (+ add), dx/add in x's dtype. */
-int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, const float* gamma, const float* beta,
-                     float* stats, int64_t M, int C, float eps, tb_stream_t stream);
+int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                     const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream);
 int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,
                      const float* gamma, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx,
                      int64_t M, int C, tb_stream_t stream);

@@ -1,0 +1,207 @@
+"""GPU parity of the HIP executors (UNet fwd + dgrad bwd, text encoder fwd/bwd, full optimizer step) against the
+CPU oracle (oracle/) on small configs the oracle finishes in seconds. Tolerances are fp16-mixed-precision vs fp32."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def round_fp16_(module):
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(p.half().float())
+    return module
+
+
+def make_unet(B=2, hw=16, cross_dim=64, seed=0):
+    from oracle.unet_sd import UNet2DCondition, UNetConfig
+    from textboost_amd.unet import HipUNet, UNetGeometry
+    torch.manual_seed(seed)
+    cfg = UNetConfig.tiny(cross_dim)
+    ref = round_fp16_(UNet2DCondition(cfg))
+    with torch.no_grad():   # default-init norms are identity: perturb so affine params matter
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+        round_fp16_(ref)
+    geo = UNetGeometry(block_out_channels=cfg.block_out_channels, num_heads=cfg.num_heads, cross_attention_dim=cross_dim,
+                       cross_attn_levels=cfg.cross_attn_levels)
+    hip = HipUNet(geo, ref.state_dict(), B, hw, hw, text_len=77, device=dev)
+    return ref, hip, cfg
+
+
+def test_unet_forward_and_dgrad_backward_match_oracle():
+    B, hw, D = 2, 16, 64
+    ref, hip, cfg = make_unet(B, hw, D)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 4, hw, hw, generator=g).half().float()
+    t = torch.tensor([17, 801])
+    ehs = torch.randn(B, 77, D, generator=g).half().float().requires_grad_(True)
+    pred_ref = ref(x, t, ehs)
+    dpred = torch.randn(B, 4, hw, hw, generator=g)
+    pred_ref.backward(dpred)
+    pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, D).to(dev).contiguous())
+    e = rel_err(pred, pred_ref)
+    assert e < 1.5e-2, f"unet forward rel err {e}"
+    d_ehs = hip.backward(dpred.to(dev))
+    e = rel_err(d_ehs.view(B, 77, D), ehs.grad)
+    assert e < 3e-2, f"unet d_ehs rel err {e}"
+
+
+def make_encoders(B=2, D=64, r=4, n_added=3, seed=0):
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle import train_step as ts
+    from textboost_amd.text_encoder import CLIPGeometry, HipTextEncoder
+    torch.manual_seed(seed)
+    ccfg = CLIPTextCfg.tiny(D)
+    base = TextBoostEncoder(ccfg, r=0)
+    with torch.no_grad():
+        for n, p in base.named_parameters():
+            if "ln" in n or n.endswith("bias"):
+                p.add_(torch.randn_like(p) * 0.1)
+        base.token_embedding.weight.mul_(0.5)
+        null = base.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    base.set_null_embedding(null)
+    teacher = ts.make_teacher(base)
+    student = TextBoostEncoder(ccfg, r=r)
+    student.load_state_dict(base.state_dict(), strict=False)
+    student.set_null_embedding(null)
+    with torch.no_grad():
+        for n, p in student.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.05)     # non-zero B so every LoRA gradient path is exercised
+    added = add_tokens(student, [100, 200, 300][:n_added])
+    geo = CLIPGeometry(hidden_size=D, intermediate_size=ccfg.intermediate_size, num_layers=ccfg.num_layers, num_heads=ccfg.num_heads)
+    sd = {hf: dict(base.named_parameters())[ours].detach() for ours, hf in base.hf_key_map().items()}
+    hip = HipTextEncoder(geo, sd, B, mode="autocast", lora_rank=r, n_slots=2, device=dev, seed=0)
+    hip.set_null_embedding(null)
+    hip.add_tokens([100, 200, 300][:n_added])
+    for i, layer in enumerate(student.layers):
+        hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
+        hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
+    hip_teacher = HipTextEncoder(geo, sd, B, mode="half", lora_rank=0, device=dev)
+    hip_teacher.set_null_embedding(null)
+    return student, teacher, hip, hip_teacher, added, null
+
+
+def lora_grads_from_oracle(student):
+    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in student.layers])
+    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in student.layers])
+    return gA, gB
+
+
+def test_text_encoder_forward_backward_match_oracle():
+    from oracle import train_step as ts
+    B, D = 3, 64
+    student, teacher, hip, hip_teacher, added, null = make_encoders(B, D)
+    g = torch.Generator().manual_seed(2)
+    ids = ts.synthetic_ids(B, added, g)
+    ids[1, 1:] = 49407   # a null prompt row -> pinned, zero gradient
+    out_ref = student(ids)
+    R = torch.randn(B, 77, D, generator=g)
+    (out_ref * R).sum().backward()
+    hip.pack_lora()
+    out = hip.forward(ids.to(dev), slot=0)
+    assert rel_err(out.view(B, 77, D), out_ref) < 5e-3
+    assert torch.equal(out.view(B, 77, D)[1].cpu(), null)
+    hip.zero_grad()
+    hip.backward(R.view(B * 77, D).to(dev).contiguous(), slot=0)
+    gA, gB = lora_grads_from_oracle(student)
+    assert rel_err(hip.grad_A, gA) < 2e-2, rel_err(hip.grad_A, gA)
+    assert rel_err(hip.grad_B, gB) < 2e-2, rel_err(hip.grad_B, gB)
+    assert rel_err(hip.grad_added, student.token_embedding.weight.grad[added]) < 2e-2
+    # the fp16 teacher
+    pids = ts.synthetic_ids(B, added, g, prior=True)   # the teacher never sees added tokens (49408-row table, :650)
+    with torch.no_grad():
+        t_ref = teacher(pids)
+    t_out = hip_teacher.forward(pids.to(dev), slot=0)
+    assert rel_err(t_out.view(B, 77, D), t_ref) < 1e-2
+
+
+def build_step(B=2, hw=16, D=64, use_scaler=True):
+    from oracle import train_step as ts
+    from textboost_amd.trainer import StepHyper, TextBoostStep
+    ref_unet, hip_unet, _ = make_unet(B, hw, D, seed=3)
+    student, teacher, hip_te, hip_teacher, added, null = make_encoders(B, D, seed=4)
+    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig())
+    hp = StepHyper(use_grad_scaler=use_scaler, init_scale=65536.0 if use_scaler else 1.0)
+    step = TextBoostStep(hip_unet, hip_te, hip_teacher, hp, (B, 4, hw, hw), device=dev)
+    step.external_noise = True
+    return st_ref, step, added
+
+
+def test_full_step_matches_oracle_elementwise():
+    from oracle import train_step as ts
+    B, hw, D = 2, 16, 64
+    st_ref, step, added = build_step(B, hw, D)
+    assert abs(step.mean_norm - st_ref.mean_norm) < 1e-4 * st_ref.mean_norm
+    g = torch.Generator().manual_seed(5)
+    te_ref = st_ref.te
+    for it in range(2):
+        ids = ts.synthetic_ids(B, added, g)
+        pids = ts.synthetic_ids(B, added, g, prior=True)
+        x0 = torch.randn(B, 4, hw, hw, generator=g)
+        noise = torch.randn(B, 4, hw, hw, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        w_before = te_ref.token_embedding.weight.detach().clone()
+        out = st_ref.step(x0, noise, t, ids, pids)
+        step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t)
+        step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+        step.step_eager()
+        sc = step.scalars()
+        assert sc["found_inf"] == 0.0
+        assert abs(sc["loss_mse"] - out["mse"]) < 2e-2 * abs(out["mse"]) + 1e-4, (sc, out["mse"])
+        assert abs(sc["loss_kpl"] - out["kpl"]) < 5e-2 * abs(out["kpl"]) + 1e-5, (sc, out["kpl"])
+        # gradients (unscaled): flat_grad holds loss_scale * grad
+        inv = 1.0 / 65536.0 if it == 0 else 1.0 / sc["loss_scale"]
+        nA = step.te.lora_A.numel()
+        gA = torch.stack([torch.cat(out["g_lora"][6 * l + 0: 6 * l + 6: 2]) for l in range(len(te_ref.layers))])
+        gB = torch.stack([torch.cat(out["g_lora"][6 * l + 1: 6 * l + 6: 2]) for l in range(len(te_ref.layers))])
+        # oracle g_lora are post-clip; compare directions through the clip coefficient
+        clip = min(1.0, 1.0 / (out["lora_grad_norm"] + 1e-6))
+        assert abs(sc["grad_norm"] - out["lora_grad_norm"]) < 5e-2 * out["lora_grad_norm"]
+        e = rel_err(step.te.grad_A * inv * clip, gA)
+        assert e < 5e-2, f"step {it} grad_A rel err {e}"
+        e = rel_err(step.te.grad_B * inv * clip, gB)
+        assert e < 5e-2, f"step {it} grad_B rel err {e}"
+        e = rel_err(step.te.grad_added * inv, out["g_emb_added"])
+        assert e < 5e-2, f"step {it} grad_added rel err {e}"
+        # parameters after the update, elementwise
+        w = step.te.token_table.cpu()
+        wr = te_ref.token_embedding.weight.detach()
+        torch.testing.assert_close(w[:49408], wr[:49408], rtol=1e-6, atol=1e-7)       # decay-only rows
+        assert (w[added] - wr[added]).abs().max().item() < 2.5e-3                     # <= ~2 * emb_lr (Adam step-1 sign flips)
+        assert rel_err(w[added], wr[added]) < 2e-3
+        A_ref = torch.stack([torch.cat([l.q.lora_A, l.k.lora_A, l.v.lora_A]) for l in te_ref.layers]).detach()
+        assert (step.te.lora_A.cpu() - A_ref).abs().max().item() < 1.5e-4             # <= ~2 * lr
+    assert step.scalars()["opt_steps"] == 2.0
+
+
+def test_graph_replay_equals_eager():
+    from oracle import train_step as ts
+    B, hw, D = 2, 16, 64
+    outs = []
+    for mode in ("eager", "graph"):
+        st_ref, step, added = build_step(B, hw, D)
+        g = torch.Generator().manual_seed(6)
+        step.input_ids.copy_(ts.synthetic_ids(B, added, g)); step.prior_ids.copy_(ts.synthetic_ids(B, added, g, prior=True))
+        step.x0.copy_(torch.randn(B, 4, hw, hw, generator=g)); step.noise.copy_(torch.randn(B, 4, hw, hw, generator=g))
+        step.timesteps.copy_(torch.randint(0, 1000, (B,), generator=g))
+        if mode == "graph":
+            step.capture(warmup=2)
+            step.replay(); step.replay()
+        else:
+            for _ in range(4):
+                step.step_eager()
+        torch.cuda.synchronize()
+        outs.append((step.te.lora_A.clone(), step.te.lora_B.clone(), step.te.token_table[49408:].clone(), step.state.clone()))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)

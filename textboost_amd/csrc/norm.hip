@@ -319,8 +319,8 @@ __device__ __forceinline__ void store8<float>(float* p, const float* v) {
   *(f32x4*)(p + 4) = b;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, int64_t ldx, TO* __restrict__ Y, int64_t ldy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ stats, int64_t M, int C, float eps) {
   const int lane = threadIdx.x & 63;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * gamma[vi * 8 + e] + beta[vi * 8 + e];
-      store8<f16>(Y + row * ldy + vi * 8, o);
+      store8<TO>(Y + row * ldy + vi * 8, o);
     }
   }
 }
@@ -448,16 +448,20 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   return TB_OK;
 }
 
-extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, const float* gamma, const float* beta,
-                                float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
+extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                                const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
   if (!x || !y || !gamma || !beta || M <= 0) return TB_EINVAL;
   if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || ldy % 8) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 3) / 4));
-  if (x_dtype == TB_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+  if (x_dtype == TB_F32 && y_dtype == TB_F16)
+    hipLaunchKernelGGL((ln_fwd_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+  else if (x_dtype == TB_F32 && y_dtype == TB_F32)
+    hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, stats, M, C, eps);
+  else if (x_dtype == TB_F16 && y_dtype == TB_F16)
+    hipLaunchKernelGGL((ln_fwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
   else
-    hipLaunchKernelGGL(ln_fwd_kernel<f16>, grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+    return TB_EINVAL;
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

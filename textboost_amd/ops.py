@@ -72,7 +72,7 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G=32, silu=False,
 
 def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5):
     M, Cc = y.shape
-    L.check(L.lib().tb_layernorm_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), L.ptr(gamma), L.ptr(beta),
+    L.check(L.lib().tb_layernorm_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), _dt(y), L.ptr(gamma), L.ptr(beta),
                                      L.ptr(stats), M, Cc, eps, L.stream()), "tb_layernorm_fwd")
     return y
 

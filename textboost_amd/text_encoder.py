@@ -1,0 +1,245 @@
+"""HIP executor of the TextBoost text encoder: CLIP text transformer + rank-r LoRA on q/k/v + TextBoost pins.
+
+Mirrors /root/reference/textboost/text_encoder.py:17-87 (`TextBoostModel`), the LoRA injection of
+train_textboost.py:700-722 (peft `LoraConfig(r, lora_alpha=r, init_lora_weights="gaussian",
+target_modules=["q_proj","k_proj","v_proj"])`) and the token-table growth of textboost/utils.py:117-166.
+
+Two numeric modes, matching how the reference runs the two encoders in fp16 mixed precision:
+  * "autocast" -- the trainable encoder under accelerate autocast: fp32 master params, fp32 residual stream and
+    LayerNorm/softmax statistics, fp16 Linear/attention operands (`train_textboost.py:919-926`);
+  * "half"     -- the KPL teacher `original_text_encoder.to(fp16)` (:650, :939): plain fp16 module, forward only.
+
+All arithmetic is in libtextboost_hip.so; this file owns parameters, buffers and the layer schedule.
+Trainable state lives in three flat fp32 buffers so the optimizer / all-reduce see one tensor each:
+  lora_A [L, 3r, D], lora_B [L, 3D, r]  and the token table [V + k, D] (rows >= first_added train).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+EOS_ID = 49407  # textboost/text_encoder.py:71
+
+
+@dataclass
+class CLIPGeometry:
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_layers: int = 12
+    num_heads: int = 12
+    max_pos: int = 77
+    act: str = "quick_gelu"
+    eps: float = 1e-5
+
+
+HF_LAYER = {"ln1": "layer_norm1", "ln2": "layer_norm2", "q": "self_attn.q_proj", "k": "self_attn.k_proj", "v": "self_attn.v_proj",
+            "out": "self_attn.out_proj", "fc1": "mlp.fc1", "fc2": "mlp.fc2"}
+
+
+class HipTextEncoder:
+    def __init__(self, geo: CLIPGeometry, state_dict: Dict[str, torch.Tensor], batch: int, mode: str = "autocast", lora_rank: int = 0,
+                 lora_alpha: Optional[float] = None, n_slots: int = 1, device="cuda", seed: Optional[int] = None):
+        """state_dict uses transformers CLIPTextModel keys (`text_model.embeddings.token_embedding.weight`, ...)."""
+        assert mode in ("autocast", "half")
+        assert geo.act == "quick_gelu", "only the SD1.x quick_gelu MLP is wired in this round"
+        self.geo, self.B, self.T, self.mode, self.dev = geo, batch, geo.max_pos, mode, device
+        self.r = lora_rank
+        self.scaling = (lora_alpha if lora_alpha is not None else lora_rank) / lora_rank if lora_rank else 0.0
+        self.res_dtype = torch.float32 if mode == "autocast" else torch.float16
+        self.n_slots = n_slots
+        self._bufs: Dict[str, torch.Tensor] = {}
+        D, Lr = geo.hidden_size, geo.num_layers
+        sd = state_dict
+        pre = "text_model."
+        f16 = lambda t: t.detach().to(torch.float16).to(device).contiguous()
+        f32r = lambda t: t.detach().to(torch.float16).to(torch.float32).to(device).contiguous()  # fp16-rounded, fp32 storage
+        tbl_dt = torch.float32 if mode == "autocast" else torch.float16
+        self.token_table = sd[pre + "embeddings.token_embedding.weight"].detach().to(tbl_dt).to(device).contiguous()
+        self.pos_table = sd[pre + "embeddings.position_embedding.weight"].detach().to(tbl_dt).to(device).contiguous()
+        # LayerNorm affine: fp32 params under autocast (LN runs in fp32); fp16-rounded for the half module
+        lnp = (lambda t: t.detach().float().to(device).contiguous()) if mode == "autocast" else f32r
+        self.Wl: List[Dict[str, torch.Tensor]] = []
+        for i in range(Lr):
+            lp = f"{pre}encoder.layers.{i}."
+            W = {}
+            wq = torch.cat([sd[lp + HF_LAYER[x] + ".weight"] for x in "qkv"], dim=0)
+            W["qkv.w"], W["qkv.wd"] = f16(wq), f16(wq).t().contiguous()
+            W["qkv.b"] = f32r(torch.cat([sd[lp + HF_LAYER[x] + ".bias"] for x in "qkv"], dim=0))
+            for n in ("out", "fc1", "fc2"):
+                w = sd[lp + HF_LAYER[n] + ".weight"]
+                W[n + ".w"], W[n + ".wd"] = f16(w), f16(w).t().contiguous()
+                W[n + ".b"] = f32r(sd[lp + HF_LAYER[n] + ".bias"])
+            for n in ("ln1", "ln2"):
+                W[n + ".g"], W[n + ".b"] = lnp(sd[lp + HF_LAYER[n] + ".weight"]), lnp(sd[lp + HF_LAYER[n] + ".bias"])
+            self.Wl.append(W)
+        self.lnf_g, self.lnf_b = lnp(sd[pre + "final_layer_norm.weight"]), lnp(sd[pre + "final_layer_norm.bias"])
+        self.null_embedding = torch.zeros(self.T, D, device=device, dtype=torch.float32)
+        self.use_fixed_special_embedding = False
+        self.first_added = self.token_table.shape[0]
+        self.n_added = 0
+        if self.r:
+            g = torch.Generator(device="cpu")
+            if seed is not None:
+                g.manual_seed(seed)
+            # peft init_lora_weights="gaussian": A ~ N(0, (1/r)^2), B = 0
+            self.lora_A = (torch.randn(Lr, 3 * self.r, D, generator=g) / self.r).to(device)
+            self.lora_B = torch.zeros(Lr, 3 * D, self.r, device=device)
+            self.grad_A = torch.zeros_like(self.lora_A)
+            self.grad_B = torch.zeros_like(self.lora_B)
+            self.w2_fwd = torch.zeros(Lr, 3 * D, 64, device=device, dtype=torch.float16)
+            self.w2_dgrad = torch.zeros(Lr, D, 64, device=device, dtype=torch.float16)
+
+    # ------------------------------------------------------------------ reference-facing surface
+    def set_null_embedding(self, null):  # text_encoder.py:28-32
+        self.null_embedding = null.detach().to(torch.float32).to(self.dev).contiguous()
+        self.use_fixed_special_embedding = True
+
+    def get_input_embeddings_weight(self):
+        return self.token_table
+
+    def add_tokens(self, initializer_ids):
+        """textboost/utils.py:117-166 row bookkeeping: grow the table, copy initializer rows; returns new ids."""
+        V, D = self.token_table.shape
+        k = len(initializer_ids)
+        new = torch.empty(V + k, D, device=self.dev, dtype=self.token_table.dtype)
+        new[:V] = self.token_table
+        for j, init in enumerate(initializer_ids):
+            new[V + j] = self.token_table[init]
+        self.token_table = new
+        if self.n_added == 0:
+            self.first_added = V
+        self.n_added += k
+        self.grad_added = torch.zeros(self.n_added, D, device=self.dev)
+        return list(range(V, V + k))
+
+    def __call__(self, input_ids, attention_mask=None, return_dict=False, slot=0):
+        assert attention_mask is None, "text_encoder_use_attention_mask is off in the reference defaults (utils.py:14-17)"
+        return (self.forward(input_ids, slot=slot), None)
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name, rows, cols, dtype):
+        t = self._bufs.get(name)
+        if t is None or t.shape != (rows, cols) or t.dtype != dtype:
+            t = torch.zeros(rows, cols, device=self.dev, dtype=dtype)
+            self._bufs[name] = t
+        return t
+
+    def pack_lora(self):
+        """refresh the fp16 K-extension operands from the fp32 LoRA masters (once per optimizer step)."""
+        if not self.r:
+            return
+        D = self.geo.hidden_size
+        for i in range(self.geo.num_layers):
+            ops.lora_pack(self.lora_A[i], self.lora_B[i], self.w2_fwd[i], self.w2_dgrad[i], D, D, self.r, 3, self.scaling)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, slot=0, pins=True):
+        geo, B, T = self.geo, input_ids.shape[0], self.T
+        D, I, H = geo.hidden_size, geo.intermediate_size, geo.num_heads
+        hd = D // H
+        M = B * T
+        rdt, f16, f32 = self.res_dtype, torch.float16, torch.float32
+        ids = input_ids.reshape(-1).contiguous()
+        s = f"s{slot}."
+        self._bufs[s + "ids"] = ids
+        h = self.buf(s + "h0", M, D, rdt)
+        ops.embed_fwd(ids, self.token_table, self.pos_table, h, T)
+        for i, W in enumerate(self.Wl):
+            p = f"{s}l{i}."
+            x1 = self.buf(p + "x1", M, D, f16)
+            ls1 = self.buf(p + "ls1", M, 2, f32)
+            ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
+            qkv = self.buf(p + "qkv", M, 3 * D, f16)
+            if self.r:
+                t = self.buf(p + "t", M, 64, f16)
+                ops.lora_down(x1, self.lora_A[i], t)
+                ops.gemm(x1, W["qkv.w"], qkv, A2=t, W2=self.w2_fwd[i], bias=W["qkv.b"])
+            else:
+                ops.gemm(x1, W["qkv.w"], qkv, bias=W["qkv.b"])
+            o = self.buf(p + "o", M, D, f16)
+            lse = self.buf(p + "lse", B * H, T, f32)
+            ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, B, H, T, T, hd, causal=True)
+            h2 = self.buf(p + "h2", M, D, rdt)
+            ops.gemm(o, W["out.w"], h2, bias=W["out.b"], R=h)
+            x2 = self.buf(s + "x2", M, D, f16)
+            ls2 = self.buf(p + "ls2", M, 2, f32)
+            ops.layernorm_fwd(h2, x2, W["ln2.g"], W["ln2.b"], ls2, geo.eps)
+            a = self.buf(s + "a", M, I, f16)
+            pre = self.buf(p + "pre", M, I, f16)
+            ops.gemm(x2, W["fc1.w"], a, bias=W["fc1.b"], act=L.ACT_QUICK_GELU, C2=pre)
+            h3 = self.buf(p + "h3", M, D, rdt)
+            ops.gemm(a, W["fc2.w"], h3, bias=W["fc2.b"], R=h2)
+            h = h3
+        out = self.buf(s + "out", M, D, rdt)
+        lsf = self.buf(s + "lsf", M, 2, f32)
+        ops.layernorm_fwd(h, out, self.lnf_g, self.lnf_b, lsf, geo.eps)
+        if pins:
+            ops.pin_fwd(out, ids, self.null_embedding, B, T, self.use_fixed_special_embedding, EOS_ID)
+        return out
+
+    # ------------------------------------------------------------------ backward (autocast mode only)
+    def zero_grad(self):
+        if self.r:
+            self.grad_A.zero_()
+            self.grad_B.zero_()
+        if self.n_added:
+            self.grad_added.zero_()
+
+    def backward(self, d_out, slot=0, pins=True):
+        """d_out: fp32 [B*T, D] gradient of the (scaled) loss w.r.t. forward(slot)'s output. Accumulates into
+        grad_A / grad_B / grad_added."""
+        assert self.mode == "autocast"
+        geo, T = self.geo, self.T
+        D, I, H = geo.hidden_size, geo.intermediate_size, geo.num_heads
+        hd = D // H
+        s = f"s{slot}."
+        ids = self._bufs[s + "ids"]
+        M = ids.numel()
+        B = M // T
+        f16, f32 = torch.float16, torch.float32
+        if pins:
+            ops.pin_bwd(d_out, ids, B, T, self.use_fixed_special_embedding, EOS_ID)
+        h_last = self._bufs[f"{s}l{geo.num_layers - 1}.h3"]
+        dh = self.buf("g.dh_a", M, D, f32)
+        ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh)
+        dh_other = self.buf("g.dh_b", M, D, f32)
+        for i in reversed(range(geo.num_layers)):
+            W = self.Wl[i]
+            p = f"{s}l{i}."
+            h_in = self._bufs[f"{s}l{i - 1}.h3"] if i > 0 else self._bufs[s + "h0"]
+            h2, pre, qkv, o, lse = (self._bufs[p + n] for n in ("h2", "pre", "qkv", "o", "lse"))
+            x1 = self._bufs[p + "x1"]
+            dh16 = self.buf("g.dh16", M, D, f16)
+            ops.convert(dh, dh16)
+            dpre = self.buf("g.dpre", M, I, f16)
+            ops.gemm(dh16, W["fc2.wd"], dpre, act=L.ACT_QUICK_GELU_GRAD, C2=pre)
+            dx2 = self.buf("g.dx", M, D, f16)
+            ops.gemm(dpre, W["fc1.wd"], dx2)
+            dh2 = dh_other
+            ops.layernorm_bwd(dx2, h2, W["ln2.g"], self._bufs[p + "ls2"], dh2, add=dh)
+            ops.convert(dh2, dh16)
+            do = self.buf("g.do", M, D, f16)
+            ops.gemm(dh16, W["out.wd"], do)
+            dqkv = self.buf("g.dqkv", M, 3 * D, f16)
+            delta = self.buf("g.delta", B * H, T, f32)
+            ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, do, delta, dqkv[:, :D], dqkv[:, D:2 * D],
+                              dqkv[:, 2 * D:], B, H, T, T, hd, causal=True)
+            dx1 = self.buf("g.dx", M, D, f16)
+            if self.r:
+                dt = self.buf("g.dt", M, 64, f16)
+                ops.lora_bwd(dqkv, x1, self._bufs[p + "t"], self.lora_B[i], dt, self.grad_A[i], self.grad_B[i], D, D, self.r, 3,
+                             self.scaling)
+                ops.gemm(dqkv, W["qkv.wd"], dx1, A2=dt, W2=self.w2_dgrad[i])
+            else:
+                ops.gemm(dqkv, W["qkv.wd"], dx1)
+            ops.layernorm_bwd(dx1, h_in, W["ln1.g"], self._bufs[p + "ls1"], dh, add=dh2)
+            # dh (buffer a) now holds the gradient w.r.t. this layer's input; dh2 (buffer b) is free again
+        if self.n_added:
+            ops.embed_bwd(dh, ids, self.grad_added, self.first_added)
+        return dh

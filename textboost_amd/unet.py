@@ -1,0 +1,549 @@
+"""HIP executor of the frozen SD1.x/SD2.x UNet2DConditionModel: forward and dgrad-only backward.
+
+Mirrors the call the reference makes at train_textboost.py:1063-1067 --
+`unet(noisy_model_input, timesteps, encoder_hidden_states).sample` -- and the part of
+`accelerator.backward(loss)` (:1108) that flows through the frozen UNet into `encoder_hidden_states`
+(the UNet has no trainable parameter by default, :696-698, so no weight gradients are formed and the backward
+stops at the first cross-attention).
+
+Everything numeric runs in the C-ABI kernels of libtextboost_hip.so (textboost_amd.ops); this file only owns
+buffers, the layer schedule and the weight re-packing:
+  * activations are NHWC fp16, viewed as [B*H*W, C] with explicit row strides, so the 12 skip tensors are written
+    by their producers straight into the channel slice of the up-path concat buffer they will be read from
+    (zero-copy torch.cat), and nearest-x2 upsampling is folded into the consuming conv's gather;
+  * the 32 cross-attention K/V projections of `encoder_hidden_states` are hoisted into ONE GEMM (and one dgrad GEMM);
+  * the 22 time_emb_proj Linears are one GEMM whose fp32 output is consumed as a per-sample row bias by conv1;
+  * weights are frozen, so every dgrad operand (W^T, tap-transposed conv weights) is materialised once at load.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+@dataclass
+class UNetGeometry:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    cross_attn_levels: Tuple[bool, ...] = (True, True, True, False)
+    num_heads: Tuple[int, ...] | int = 8
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    use_linear_projection: bool = False
+
+    def heads(self, level):
+        return self.num_heads if isinstance(self.num_heads, int) else self.num_heads[level]
+
+
+def _f16(t):
+    return t.detach().to(torch.float16)
+
+
+def _f32_via_f16(t, dev):
+    """unet.to(fp16) (:937) rounds every parameter to fp16; biases / norm affines are consumed as fp32 here."""
+    return t.detach().to(torch.float16).to(torch.float32).to(dev).contiguous()
+
+
+def pack_conv3x3(w, dev):
+    """[Co,Ci,3,3] -> fwd [Co, 9*Ci] (k = (ky*3+kx)*Ci + ci) and dgrad [Ci, 9*Co] (k = (ky*3+kx)*Co + co), fp16."""
+    w = _f16(w).to(dev)
+    fwd = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    dg = w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous()
+    return fwd, dg
+
+
+def pack_linear(w, dev):
+    w = _f16(w).to(dev)
+    if w.dim() == 4:  # 1x1 conv
+        w = w.reshape(w.shape[0], w.shape[1])
+    return w.contiguous(), w.t().contiguous()
+
+
+def pack_geglu_rows(w):
+    """[2*inner, ...] (h rows then g rows) -> 32-row interleaved blocks [h0..31 | g0..31 | h32..63 | ...]."""
+    inner = w.shape[0] // 2
+    hs = w[:inner].reshape(inner // 32, 32, *w.shape[1:])
+    gs = w[inner:].reshape(inner // 32, 32, *w.shape[1:])
+    return torch.stack([hs, gs], dim=1).reshape(w.shape)
+
+
+class HipUNet:
+    """`forward(sample[B,4,h,w] fp16 NCHW, timesteps[B] i64, ehs[B*77, D] fp16) -> pred[B,4,h,w] fp16`,
+    `backward(dpred[B,4,h,w] fp32) -> d_ehs[B*77, D] fp32` (gradient of the scaled loss)."""
+
+    def __init__(self, geo: UNetGeometry, state_dict: Dict[str, torch.Tensor], batch: int, height: int, width: int,
+                 text_len: int = 77, device="cuda"):
+        self.geo, self.B, self.H, self.W, self.T, self.dev = geo, batch, height, width, text_len, device
+        self.dtype = torch.float16
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self.tape: List = []
+        self._pack(state_dict)
+        # tb_groupnorm_ws_floats = B * chunks * G * 2 with B * chunks <= 2048 (+B when chunks clamps to 1)
+        self.gn_ws = torch.empty((2048 + batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name, rows, cols, dtype=torch.float16):
+        key = name
+        t = self._bufs.get(key)
+        if t is None or t.shape != (rows, cols) or t.dtype != dtype:
+            t = torch.empty(rows, cols, device=self.dev, dtype=dtype)
+            self._bufs[key] = t
+        return t
+
+    def scratch(self, tag, rows, cols, dtype=torch.float16):
+        return self.buf(f"scr.{tag}.{rows}x{cols}.{dtype}", rows, cols, dtype)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, sd):
+        dev, geo = self.dev, self.geo
+        P = {}
+        self.P = P
+
+        def conv(name):
+            P[name + ".w"], P[name + ".wd"] = pack_conv3x3(sd[name + ".weight"], dev)
+            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+
+        def lin(name, bias=True):
+            P[name + ".w"], P[name + ".wd"] = pack_linear(sd[name + ".weight"], dev)
+            if bias:
+                P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+
+        def norm(name):
+            P[name + ".g"] = _f32_via_f16(sd[name + ".weight"], dev)
+            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+
+        ch = geo.block_out_channels
+        self.resnets: List[str] = []
+        self.xattn: List[Tuple[str, int]] = []   # (prefix of attn2, C)
+        self._walk = []
+        # conv_in / conv_out as boundary kernels (4-channel NCHW side)
+        w = _f32_via_f16(sd["conv_in.weight"], dev)                     # [C0,4,3,3]
+        P["conv_in.wp"] = w.permute(2, 3, 1, 0).reshape(36, ch[0]).contiguous()
+        P["conv_in.b"] = _f32_via_f16(sd["conv_in.bias"], dev)
+        w = _f32_via_f16(sd["conv_out.weight"], dev)                    # [4,C0,3,3]
+        P["conv_out.wp"] = w.permute(0, 2, 3, 1).reshape(4, 9, ch[0]).contiguous()
+        P["conv_out.wdp"] = w.permute(2, 3, 0, 1).reshape(36, ch[0]).contiguous()
+        P["conv_out.b"] = _f32_via_f16(sd["conv_out.bias"], dev)
+        norm("conv_norm_out")
+        lin("time_embedding.linear_1")
+        lin("time_embedding.linear_2")
+
+        def resnet(prefix, cin, cout):
+            norm(prefix + ".norm1"); conv(prefix + ".conv1"); norm(prefix + ".norm2"); conv(prefix + ".conv2")
+            if cin != cout:
+                lin(prefix + ".conv_shortcut")
+            self.resnets.append(prefix)
+
+        def transformer(prefix, C):
+            norm(prefix + ".norm")
+            lin(prefix + ".proj_in"); lin(prefix + ".proj_out")
+            tb = prefix + ".transformer_blocks.0"
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{tb}.{n}")
+            wq = torch.cat([sd[f"{tb}.attn1.to_{x}.weight"] for x in "qkv"], dim=0)
+            P[f"{tb}.attn1.qkv.w"], P[f"{tb}.attn1.qkv.wd"] = pack_linear(wq, dev)
+            lin(f"{tb}.attn1.to_out.0")
+            lin(f"{tb}.attn2.to_q", bias=False)
+            lin(f"{tb}.attn2.to_out.0")
+            self.xattn.append((f"{tb}.attn2", C))
+            wff = pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.weight"])
+            P[f"{tb}.ff1.w"], P[f"{tb}.ff1.wd"] = pack_linear(wff, dev)
+            P[f"{tb}.ff1.b"] = _f32_via_f16(pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.bias"]), dev)
+            lin(f"{tb}.ff.net.2")
+
+        L_ = geo.layers_per_block
+        prev = ch[0]
+        skip_chs = [ch[0]]
+        for i, c in enumerate(ch):
+            for j in range(L_):
+                resnet(f"down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+                if geo.cross_attn_levels[i]:
+                    transformer(f"down_blocks.{i}.attentions.{j}", c)
+                skip_chs.append(c)
+            if i < len(ch) - 1:
+                conv(f"down_blocks.{i}.downsamplers.0.conv")
+                skip_chs.append(c)
+            prev = c
+        resnet("mid_block.resnets.0", ch[-1], ch[-1])
+        transformer("mid_block.attentions.0", ch[-1])
+        resnet("mid_block.resnets.1", ch[-1], ch[-1])
+        self.skip_chs = list(skip_chs)
+        rev = list(reversed(ch))
+        prev = ch[-1]
+        sk = list(skip_chs)
+        for i, c in enumerate(rev):
+            level = len(ch) - 1 - i
+            for j in range(L_ + 1):
+                s = sk.pop()
+                resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else c) + s, c)
+                if geo.cross_attn_levels[level]:
+                    transformer(f"up_blocks.{i}.attentions.{j}", c)
+            if i < len(ch) - 1:
+                conv(f"up_blocks.{i}.upsamplers.0.conv")
+            prev = c
+        # hoisted projections
+        tw = torch.cat([sd[p + ".time_emb_proj.weight"] for p in self.resnets], dim=0)
+        P["temb_all.w"] = _f16(tw).to(dev).contiguous()
+        P["temb_all.b"] = _f32_via_f16(torch.cat([sd[p + ".time_emb_proj.bias"] for p in self.resnets], dim=0), dev)
+        self.temb_off, o = {}, 0
+        for p in self.resnets:
+            self.temb_off[p] = o
+            o += sd[p + ".time_emb_proj.weight"].shape[0]
+        self.temb_total = o
+        kv = torch.cat([torch.cat([sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0) for p, _ in self.xattn], dim=0)
+        P["kv_all.w"], P["kv_all.wd"] = pack_linear(kv, dev)
+        self.kv_off, o = {}, 0
+        for p, C in self.xattn:
+            self.kv_off[p] = o
+            o += 2 * C
+        self.kv_total = o
+        self.first_xattn = self.xattn[0][0]
+
+    # ------------------------------------------------------------------ primitive wrappers
+    def _conv(self, x, name, out, B, Hin, Win, Hout, Wout, dgrad=False, stride=1, upsample=0, transposed=0, **epi):
+        w = self.P[name + (".wd" if dgrad else ".w")]
+        cin = x.shape[1]
+        geo = dict(B=B, Hin=Hin, Win=Win, Cin=cin, Hout=Hout, Wout=Wout, stride=stride, sign=-1 if (dgrad and not transposed) else 1,
+                   upsample=upsample, transposed=transposed)
+        return ops.gemm(x, w, out, conv=geo, **epi)
+
+    def _gn_fwd(self, x, name, y, stats, HW, silu, eps=None):
+        C = x.shape[1]
+        ops.groupnorm_fwd(x, y, self.P[name + ".g"], self.P[name + ".b"], stats, self.gn_ws, self.B, HW, C, self.geo.norm_num_groups,
+                          self.geo.norm_eps if eps is None else eps, silu)
+
+    def _gn_bwd(self, dy, x, name, stats, dx, HW, silu, add=None):
+        C = x.shape[1]
+        ops.groupnorm_bwd(dy, x, self.P[name + ".g"], self.P[name + ".b"], stats, dx, self.gn_ws, self.B, HW, C,
+                          self.geo.norm_num_groups, silu, add)
+
+    # ------------------------------------------------------------------ blocks
+    def _resnet(self, prefix, x, out, lvl_hw):
+        """x [M,Cin] view -> out [M,Cout] view; pushes its backward on the tape."""
+        H, W = lvl_hw
+        HW, M, B = H * W, x.shape[0], self.B
+        cin, cout = x.shape[1], out.shape[1]
+        P = self.P
+        st1 = self.buf(prefix + ".st1", B * self.geo.norm_num_groups, 2, torch.float32)
+        st2 = self.buf(prefix + ".st2", B * self.geo.norm_num_groups, 2, torch.float32)
+        a1 = self.scratch("a", M, cin)
+        self._gn_fwd(x, prefix + ".norm1", a1, st1, HW, True)
+        h1 = self.buf(prefix + ".h1", M, cout)
+        rb = self.rowbias[:, self.temb_off[prefix]: self.temb_off[prefix] + cout]
+        self._conv(a1, prefix + ".conv1", h1, B, H, W, H, W, bias=P[prefix + ".conv1.b"], rowbias=rb, rows_per_group=HW)
+        a2 = self.scratch("a", M, cout)
+        self._gn_fwd(h1, prefix + ".norm2", a2, st2, HW, True)
+        has_sc = cin != cout
+        if has_sc:
+            ops.gemm(x, P[prefix + ".conv_shortcut.w"], out, bias=P[prefix + ".conv_shortcut.b"])
+            self._conv(a2, prefix + ".conv2", out, B, H, W, H, W, bias=P[prefix + ".conv2.b"], R=out)
+        else:
+            self._conv(a2, prefix + ".conv2", out, B, H, W, H, W, bias=P[prefix + ".conv2.b"], R=x)
+
+        def bwd(dout, dx):
+            da2 = self.scratch("g1", M, cout)
+            self._conv(dout, prefix + ".conv2", da2, B, H, W, H, W, dgrad=True)
+            dh1 = self.scratch("g2", M, cout)
+            self._gn_bwd(da2, h1, prefix + ".norm2", st2, dh1, HW, True)
+            da1 = self.scratch("g1", M, cin)
+            self._conv(dh1, prefix + ".conv1", da1, B, H, W, H, W, dgrad=True)
+            if has_sc:
+                dsc = self.scratch("g3", M, cin)
+                ops.gemm(dout, P[prefix + ".conv_shortcut.wd"], dsc)
+                self._gn_bwd(da1, x, prefix + ".norm1", st1, dx, HW, True, add=dsc)
+            else:
+                self._gn_bwd(da1, x, prefix + ".norm1", st1, dx, HW, True, add=dout)
+        return bwd
+
+    def _transformer(self, prefix, x, out, lvl_hw, level):
+        H, W = lvl_hw
+        HW, M, B, C = H * W, x.shape[0], self.B, x.shape[1]
+        heads = self.geo.heads(level)
+        hd = C // heads
+        P, T = self.P, self.T
+        tb = prefix + ".transformer_blocks.0"
+        G = self.geo.norm_num_groups
+        st0 = self.buf(prefix + ".st0", B * G, 2, torch.float32)
+        n0 = self.scratch("a", M, C)
+        self._gn_fwd(x, prefix + ".norm", n0, st0, HW, False, eps=1e-6)
+        t0 = self.buf(prefix + ".t0", M, C)
+        ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
+        # --- self attention
+        ls1 = self.buf(prefix + ".ls1", M, 2, torch.float32)
+        l1 = self.scratch("a", M, C)
+        ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
+        qkv = self.buf(prefix + ".qkv", M, 3 * C)
+        ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
+        o1 = self.buf(prefix + ".o1", M, C)
+        lse1 = self.buf(prefix + ".lse1", B * heads, HW, torch.float32)
+        ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, B, heads, HW, HW, hd)
+        t1 = self.buf(prefix + ".t1", M, C)
+        ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
+        # --- cross attention (K/V hoisted)
+        ls2 = self.buf(prefix + ".ls2", M, 2, torch.float32)
+        l2 = self.scratch("a", M, C)
+        ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
+        q2 = self.buf(prefix + ".q2", M, C)
+        ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
+        ko = self.kv_off[tb + ".attn2"]
+        k2, v2 = self.kv_all[:, ko:ko + C], self.kv_all[:, ko + C:ko + 2 * C]
+        o2 = self.buf(prefix + ".o2", M, C)
+        lse2 = self.buf(prefix + ".lse2", B * heads, HW, torch.float32)
+        ops.attention_fwd(q2, k2, v2, o2, lse2, B, heads, HW, T, hd)
+        t2 = self.buf(prefix + ".t2", M, C)
+        ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
+        # --- GEGLU feed-forward
+        ls3 = self.buf(prefix + ".ls3", M, 2, torch.float32)
+        l3 = self.scratch("a", M, C)
+        ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
+        raw = self.buf(prefix + ".raw", M, 8 * C)
+        gated = self.scratch("b", M, 4 * C)
+        ops.gemm(l3, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.b"], act=L.ACT_GEGLU, C2=raw)
+        t3 = self.scratch("a", M, C)
+        ops.gemm(gated, P[tb + ".ff.net.2.w"], t3, bias=P[tb + ".ff.net.2.b"], R=t2)
+        ops.gemm(t3, P[prefix + ".proj_out.w"], out, bias=P[prefix + ".proj_out.b"], R=x)
+        stop_after_cross = (tb + ".attn2") == self.first_xattn
+
+        def bwd(dout, dx):
+            dt3 = self.scratch("g1", M, C)
+            ops.gemm(dout, P[prefix + ".proj_out.wd"], dt3)
+            dgated = self.scratch("gb", M, 4 * C)
+            ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dgated)
+            dproj = self.scratch("gc", M, 8 * C)
+            ops.geglu_bwd(dgated, raw, dproj)
+            dl3 = self.scratch("g2", M, C)
+            ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
+            dt2 = self.scratch("g3", M, C)
+            ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
+            do2 = self.scratch("g1", M, C)
+            ops.gemm(dt2, P[tb + ".attn2.to_out.0.wd"], do2)
+            dq2 = self.scratch("g2", M, C)
+            delta = self.scratch("delta", B * heads, HW, torch.float32)
+            dk2, dv2 = self.dkv_all[:, ko:ko + C], self.dkv_all[:, ko + C:ko + 2 * C]
+            ops.attention_bwd(q2, k2, v2, o2, lse2, do2, delta, dq2, dk2, dv2, B, heads, HW, T, hd)
+            if stop_after_cross:
+                return
+            dl2 = self.scratch("g1", M, C)
+            ops.gemm(dq2, P[tb + ".attn2.to_q.wd"], dl2)
+            dt1 = self.scratch("g4", M, C)
+            ops.layernorm_bwd(dl2, t1, P[tb + ".norm2.g"], ls2, dt1, add=dt2)
+            do1 = self.scratch("g1", M, C)
+            ops.gemm(dt1, P[tb + ".attn1.to_out.0.wd"], do1)
+            dqkv = self.scratch("gq", M, 3 * C)
+            ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, do1, delta, dqkv[:, :C], dqkv[:, C:2 * C],
+                              dqkv[:, 2 * C:], B, heads, HW, HW, hd)
+            dl1 = self.scratch("g2", M, C)
+            ops.gemm(dqkv, P[tb + ".attn1.qkv.wd"], dl1)
+            dt0 = self.scratch("g3", M, C)
+            ops.layernorm_bwd(dl1, t0, P[tb + ".norm1.g"], ls1, dt0, add=dt1)
+            dn0 = self.scratch("g1", M, C)
+            ops.gemm(dt0, P[prefix + ".proj_in.wd"], dn0)
+            self._gn_bwd(dn0, x, prefix + ".norm", st0, dx, HW, False, add=dout)
+        return bwd, stop_after_cross
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, sample, timesteps, ehs16):
+        geo, B, P = self.geo, self.B, self.P
+        ch = geo.block_out_channels
+        nl = len(ch)
+        hw = [(self.H >> l, self.W >> l) for l in range(nl)]
+        Ms = [B * h * w for h, w in hw]
+        L_ = geo.layers_per_block
+        self.tape = []
+        # ---- time embedding -> per-resnet row bias (one GEMM for all 22 time_emb_proj)
+        te = self.buf("temb.sincos", B, ch[0])
+        ops.timestep_embed(timesteps, te)
+        te1 = self.buf("temb.l1", B, ch[0] * 4)
+        ops.gemm(te, P["time_embedding.linear_1.w"], te1, bias=P["time_embedding.linear_1.b"], act=L.ACT_SILU)
+        te2 = self.buf("temb.l2", B, ch[0] * 4)
+        ops.gemm(te1, P["time_embedding.linear_2.w"], te2, bias=P["time_embedding.linear_2.b"], act=L.ACT_SILU)  # silu(temb)
+        self.rowbias = self.buf("temb.rowbias", B, self.temb_total, torch.float32)
+        ops.gemm(te2, P["temb_all.w"], self.rowbias, bias=P["temb_all.b"])
+        # ---- hoisted cross-attention K/V projections of the text states
+        self.kv_all = self.buf("kv_all", B * self.T, self.kv_total)
+        self.dkv_all = self.buf("dkv_all", B * self.T, self.kv_total)
+        ops.gemm(ehs16, P["kv_all.w"], self.kv_all)
+        # ---- concat buffers of the up path (hidden part first, skip part second)
+        skip_level = [0]
+        for i in range(nl):
+            skip_level += [i] * L_
+            if i < nl - 1:
+                skip_level.append(i + 1)
+        nskips = len(self.skip_chs)
+        cat_views = [None] * nskips          # skip k -> (cat buffer, h_cols)
+        cats = {}
+        sk = list(range(nskips))
+        prev = ch[-1]
+        for i, c in enumerate(reversed(ch)):
+            for j in range(L_ + 1):
+                k = sk.pop()
+                hc = prev if j == 0 else c
+                lvl = skip_level[k]
+                cb = self.buf(f"cat.{i}.{j}", Ms[lvl], hc + self.skip_chs[k])
+                cats[(i, j)] = (cb, hc)
+                cat_views[k] = cb[:, hc:]
+            prev = c
+        # ---- down path
+        x = cat_views[0]
+        ops.conv4_to_nhwc(sample, P["conv_in.wp"], P["conv_in.b"], x, B, self.H, self.W, ch[0], sign=1)
+        k = 1
+        down_records = []   # (kind, bwd_fn / info, input_view, output_view, skip index of the output or None)
+        for i, c in enumerate(ch):
+            for j in range(L_):
+                has_attn = geo.cross_attn_levels[i]
+                dst = cat_views[k]
+                if has_attn:
+                    mid = self.buf(f"down.{i}.{j}.res", Ms[i], c)
+                    rb = self._resnet(f"down_blocks.{i}.resnets.{j}", x, mid, hw[i])
+                    tbwd, stop = self._transformer(f"down_blocks.{i}.attentions.{j}", mid, dst, hw[i], i)
+                    down_records.append(("res", rb, x, mid, None))
+                    down_records.append(("attn", (tbwd, stop), mid, dst, k))
+                else:
+                    rb = self._resnet(f"down_blocks.{i}.resnets.{j}", x, dst, hw[i])
+                    down_records.append(("res", rb, x, dst, k))
+                x = dst
+                k += 1
+            if i < nl - 1:
+                dst = cat_views[k]
+                name = f"down_blocks.{i}.downsamplers.0.conv"
+                self._conv(x, name, dst, B, hw[i][0], hw[i][1], hw[i + 1][0], hw[i + 1][1], stride=2, bias=P[name + ".b"])
+                down_records.append(("down", (name, i), x, dst, k))
+                x = dst
+                k += 1
+        # ---- mid
+        lvl = nl - 1
+        m1 = self.buf("mid.r0", Ms[lvl], ch[-1])
+        mb0 = self._resnet("mid_block.resnets.0", x, m1, hw[lvl])
+        m2 = self.buf("mid.a0", Ms[lvl], ch[-1])
+        mb1, _ = self._transformer("mid_block.attentions.0", m1, m2, hw[lvl], lvl)
+        cb, hc = cats[(0, 0)]
+        m3 = cb[:, :hc]
+        mb2 = self._resnet("mid_block.resnets.1", m2, m3, hw[lvl])
+        mid_records = [(mb0, x, m1), (mb1, m1, m2), (mb2, m2, m3)]
+        # ---- up path
+        up_records = []
+        for i, c in enumerate(reversed(ch)):
+            lvl = nl - 1 - i
+            has_attn = geo.cross_attn_levels[lvl]
+            for j in range(L_ + 1):
+                cb, hc = cats[(i, j)]
+                last = j == L_
+                if not last:
+                    nb, nhc = cats[(i, j + 1)]
+                    dst = nb[:, :nhc]
+                elif i < nl - 1:
+                    dst = self.buf(f"up.{i}.out", Ms[lvl], c)
+                else:
+                    dst = self.buf("up.final", Ms[lvl], c)
+                if has_attn:
+                    mid = self.buf(f"up.{i}.{j}.res", Ms[lvl], c)
+                    rb = self._resnet(f"up_blocks.{i}.resnets.{j}", cb, mid, hw[lvl])
+                    tbwd, _ = self._transformer(f"up_blocks.{i}.attentions.{j}", mid, dst, hw[lvl], lvl)
+                    up_records.append(("res", rb, cb, mid, (i, j)))
+                    up_records.append(("attn", tbwd, mid, dst, None))
+                else:
+                    rb = self._resnet(f"up_blocks.{i}.resnets.{j}", cb, dst, hw[lvl])
+                    up_records.append(("res", rb, cb, dst, (i, j)))
+                x = dst
+            if i < nl - 1:
+                nb, nhc = cats[(i + 1, 0)]
+                dst = nb[:, :nhc]
+                name = f"up_blocks.{i}.upsamplers.0.conv"
+                self._conv(x, name, dst, B, hw[lvl][0], hw[lvl][1], hw[lvl - 1][0], hw[lvl - 1][1], upsample=1, bias=P[name + ".b"])
+                up_records.append(("up", (name, lvl), x, dst, None))
+                x = dst
+        # ---- head
+        M0 = Ms[0]
+        sto = self.buf("out.st", B * geo.norm_num_groups, 2, torch.float32)
+        a = self.scratch("a", M0, ch[0])
+        self._gn_fwd(x, "conv_norm_out", a, sto, hw[0][0] * hw[0][1], True)
+        pred = self.buf("pred", B * 4, self.H * self.W).view(B, 4, self.H, self.W)
+        ops.conv_to4(a, P["conv_out.wp"], P["conv_out.b"], pred, B, self.H, self.W, ch[0])
+        self._saved = dict(final=x, sto=sto, cats=cats, cat_views=cat_views, down=down_records, mid=mid_records, up=up_records,
+                           hw=hw, Ms=Ms, ehs16=ehs16)
+        return pred
+
+    # ------------------------------------------------------------------ backward (dgrad only, down to d_ehs)
+    def backward(self, dpred, d_ehs_out=None):
+        S, geo, B, P = self._saved, self.geo, self.B, self.P
+        ch = geo.block_out_channels
+        nl = len(ch)
+        hw, Ms = S["hw"], S["Ms"]
+        L_ = geo.layers_per_block
+        # head
+        da = self.scratch("g1", Ms[0], ch[0])
+        ops.conv4_to_nhwc(dpred, P["conv_out.wdp"], None, da, B, self.H, self.W, ch[0], sign=-1)
+        g = self.buf("grad.final", Ms[0], ch[0])
+        self._gn_bwd(da, S["final"], "conv_norm_out", S["sto"], g, hw[0][0] * hw[0][1], True)
+        # up path in reverse; d(cat) buffers are kept for the skip gradients
+        dcat = {}
+        for kind, fn, xin, xout, tag in reversed(S["up"]):
+            M, cin = xin.shape
+            if kind == "up":
+                name, lvl = fn
+                du = self.scratch("gu", Ms[lvl - 1], xin.shape[1])
+                self._conv(g, name, du, B, hw[lvl - 1][0], hw[lvl - 1][1], hw[lvl - 1][0], hw[lvl - 1][1], dgrad=True)
+                gx = self.buf(f"grad.up.{name}", M, cin)
+                ops.pool2x2_sum(du, gx, B, hw[lvl][0], hw[lvl][1], cin)
+                g = gx
+            elif kind == "attn":
+                gx = self.buf(f"grad.attn.{M}x{cin}.u", M, cin)
+                fn(g, gx)
+                g = gx
+            else:
+                i, j = tag
+                gx = self.buf(f"grad.cat.{i}.{j}", M, cin)
+                fn(g, gx)
+                dcat[(i, j)] = gx
+                hc = S["cats"][(i, j)][1]
+                g = gx[:, :hc]
+        # mid
+        for mi, (fn, xin, xout) in reversed(list(enumerate(S["mid"]))):
+            gx = self.buf(f"grad.mid.{mi}", xin.shape[0], xin.shape[1])
+            fn(g, gx)
+            g = gx
+        # skip gradient views, indexed by skip number
+        sk = list(range(len(self.skip_chs)))
+        skip_grad = {}
+        for i in range(nl):
+            for j in range(L_ + 1):
+                k = sk.pop()
+                hc = S["cats"][(i, j)][1]
+                skip_grad[k] = dcat[(i, j)][:, hc:]
+        # down path in reverse: gradient of each skip tensor = grad from its down-path consumer + skip slice
+        # g currently = gradient w.r.t. the last skip tensor coming from the mid block
+        for kind, fn, xin, xout, s_idx in reversed(S["down"]):
+            if s_idx is not None:
+                merged = self.buf(f"grad.skipmerge.{s_idx}", xout.shape[0], xout.shape[1])
+                ops.add_f16(g, skip_grad[s_idx], merged)
+                g = merged
+            if kind == "attn":
+                tbwd, stop = fn
+                if stop:
+                    tbwd(g, None)   # first cross-attention: only dK/dV are produced; nothing upstream needs a gradient
+                    break
+                gx = self.buf(f"grad.attn.{xin.shape[0]}x{xin.shape[1]}.d", xin.shape[0], xin.shape[1])
+                tbwd(g, gx)
+                g = gx
+            elif kind == "res":
+                gx = self.buf(f"grad.res.{xin.shape[0]}x{xin.shape[1]}.d", xin.shape[0], xin.shape[1])
+                fn(g, gx)
+                g = gx
+            else:
+                name, lvl = fn
+                gx = self.buf(f"grad.down.{lvl}", xin.shape[0], xin.shape[1])
+                self._conv(g, name, gx, B, hw[lvl + 1][0], hw[lvl + 1][1], hw[lvl][0], hw[lvl][1], dgrad=True, transposed=1)
+                g = gx
+        # hoisted K/V dgrad -> d encoder_hidden_states (fp32)
+        if d_ehs_out is None:
+            d_ehs_out = self.buf("d_ehs", B * self.T, geo.cross_attention_dim, torch.float32)
+        ops.gemm(self.dkv_all, P["kv_all.wd"], d_ehs_out)
+        return d_ehs_out
