@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- TextBoost train steps/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full optimizer step of train_textboost.py:1040-1149 on synthetic 4x64x64 latents: text-encoder
+LoRA fwd, frozen SD1.5 UNet fwd + dgrad bwd, MSE + KPL (teacher fwd + student fwd), text-encoder bwd, all-reduce of
+the trainable gradients (N>1), GradScaler/clip/AdamW/renorm -- captured in a HIP graph, inputs resident in HBM.
+Rank 0 prints ONE JSON line (fields per the driver contract, plus `roofline` and `cpu_baseline`)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE = 1.76e12  # UNet fwd 803.3 + dgrad bwd ~888 + CLIP 66.7 GFLOP
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, MI355X_MICROARCH.md
+
+
+def roofline_leg(step):
+    """One extra EAGER step with a HIP-event pair around every kernel-family launch (same stream), after the timed
+    region; the dominant family (largest summed duration) is reported against the dense fp16 MFMA peak."""
+    from textboost_amd import ops
+    torch.cuda.synchronize()
+    ops.start_recording()
+    step.step_eager()
+    torch.cuda.synchronize()
+    rec = ops.stop_recording()
+    agg = {}
+    for name, flops, byts, e0, e1 in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += flops
+        a[3] += byts
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    name, (n, t, fl, _) = dom
+    table = {k: {"launches": v[0], "total_ms": round(v[1] * 1e3, 3), "avg_us": round(v[1] / v[0] * 1e6, 2),
+                 "tflops": round(v[2] / v[1] / 1e12, 1) if v[2] else None,
+                 "gbps": round(v[3] / v[1] / 1e9, 1) if v[3] else None} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    achieved = fl / t / 1e12
+    roof = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2),
+            "alg_flop_per_launch": fl / n, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+    return roof, table
+
+
+def cpu_baseline_leg(max_seconds=60.0):
+    """oracle/ (the eager-PyTorch fp32 restatement of the reference step) timed on this box's host cores:
+    bounded sample = optimizer steps at B=1 (1/8 of the metric's batch) of the same SD1.5 shapes; value is scaled to B=8."""
+    import torch.nn as nn
+    from oracle import train_step as ts
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle.unet_sd import UNet2DCondition, UNetConfig
+    from textboost_amd.workload import synthetic_ids
+    torch.manual_seed(0)
+
+    def fast_init(m):
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2:
+                    fan = p[0].numel()
+                    p.uniform_(-fan ** -0.5, fan ** -0.5)
+                elif "norm" in n or "ln" in n:
+                    p.fill_(1.0 if n.endswith("weight") else 0.0)
+                else:
+                    p.zero_()
+        return m
+    with torch.device("meta"):
+        unet = UNet2DCondition(UNetConfig.sd15())
+    unet = fast_init(unet.to_empty(device="cpu"))
+    base = TextBoostEncoder(CLIPTextCfg.sd15(), r=0)
+    with torch.no_grad():
+        null = base.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    base.set_null_embedding(null)
+    teacher = ts.make_teacher(base)
+    te = TextBoostEncoder(CLIPTextCfg.sd15(), r=4)
+    te.load_state_dict(base.state_dict(), strict=False)
+    te.set_null_embedding(null)
+    added = add_tokens(te, list(range(1000, 1018)))
+    st = ts.TrainState(te, teacher, unet, added, ts.StepConfig())
+    g = torch.Generator().manual_seed(1)
+    times = []
+    t_begin = time.perf_counter()
+    for i in range(3):
+        ids = synthetic_ids(1, added, g)
+        pids = synthetic_ids(1, added, g, prior=True)
+        x0, noise = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g)
+        t = torch.randint(0, 1000, (1,), generator=g)
+        t0 = time.perf_counter()
+        st.step(x0, noise, t, ids, pids)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > max_seconds / 2:
+            break
+    best = min(times)
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(1.0 / (8.0 * best), 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} optimizer step(s) at B=1 (1/8 of the metric's batch), SD1.5 UNet + CLIP-L r=4 + KPL, 64x64 latents, "
+                      f"fp32 eager oracle; best {best:.2f} s/step scaled to B=8", "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE.json metric: 8)")
+    ap.add_argument("--latent", type=int, default=64, help="latent side (512^2 images -> 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from textboost_amd.build import LIB  # noqa: F401
+    from textboost_amd import _lib
+    _lib.lib()  # fail loudly if the HIP extension is missing
+    from textboost_amd.workload import build_step
+
+    torch.manual_seed(42)  # the reference seeds every rank identically (train_textboost.py:601); data is offset by rank
+    step, added = build_step(batch=args.batch, latent=args.latent, data_seed=1000 + rank, world_size=world,
+                             device=torch.device("cuda", local))
+    if args.no_graph:
+        for _ in range(2):
+            step.step_eager()
+    else:
+        step.capture(warmup=2)
+    for _ in range(args.warmup):
+        step.replay()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.replay()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    sc = step.scalars()
+    roof, table = (None, None)
+    if rank == 0 and not args.no_roofline:
+        roof, table = roofline_leg(step)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_leg()
+        except Exception as e:  # the baseline is a reported reference, never fatal to the GPU number
+            cpu = {"error": repr(e)}
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        sps = args.steps * 1.0 / dt
+        out = {
+            "metric": "train steps/sec (batch=8, 512^2, SD1.5, LoRA r=4)", "value": round(sps, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: SD1.5 UNet (859.5M, frozen, fwd + dgrad bwd) + CLIP-L text encoder LoRA r=4 on "
+                                   "q/k/v (fwd x2 + bwd x2) + fp16 KPL teacher fwd, per-GPU batch %d, %dx%d latents (512^2), 18 added token vectors, "
+                                   "MSE + 0.1*KPL(cos), GradScaler + clip + AdamW + renorm on device; random-init weights; step as one HIP graph"
+                                   % (args.batch, args.latent, args.latent),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "images_per_s": round(sps * args.batch * world, 2)},
+            "alg_tflops_per_gpu": round(sps * args.batch * FLOP_PER_IMAGE / 1e12, 2),
+            "frac_of_mfma_peak_whole_step": round(sps * args.batch * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "loss": sc["loss"], "loss_scale": sc["loss_scale"], "found_inf_last": sc["found_inf"], "opt_steps": sc["opt_steps"],
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if table is not None:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
+                json.dump(table, f, indent=1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,9 @@ typedef struct tb_gemm_desc {
 
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
 
+/* text of the HIP error behind the most recent -5 (launch failure) return; diagnostics only */
+const char* tb_last_hip_error(void);
+
 /* ---- GroupNorm(+SiLU) over NHWC fp16 [B, HW, C] (row stride ld), G groups, fp32 statistics -------
  * Replaces torch.nn.GroupNorm + F.silu inside diffusers ResnetBlock2D / Transformer2DModel /
  * conv_norm_out (train_textboost.py:1063-1067) and their autograd (:1108); gamma/beta are frozen so only
@@ -104,6 +107,9 @@ typedef struct tb_attn_desc {
   void* dQ; int64_t lddq;
   void* dK; int64_t lddk;
   void* dV; int64_t lddv;
+  float* ws; int64_t ws_floats;  /* optional scratch (n * 2*B*Skv*H*hd floats, n >= 2): lets the dK/dV kernel split the query
+                                  * range over up to n blocks per key block (per-slice fp32 partials summed in a fixed order)
+                                  * when Skv is too short to fill the chip (cross-attention) */
 } tb_attn_desc;
 int tb_attention_fwd(const tb_attn_desc* d, tb_stream_t stream);
 int tb_attention_bwd(const tb_attn_desc* d, tb_stream_t stream);
@@ -152,9 +158,10 @@ int tb_textboost_pin_bwd(float* dh, const int64_t* ids, int B, int T, int D, int
 int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t, int64_t ldt, int64_t M, int K, int R, tb_stream_t stream);
 int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd /*fp16 [P*D,64]*/, void* w2_dgrad /*fp16 [K,64]*/, int D, int K,
                  int r, int P, float scaling, tb_stream_t stream);
+int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P);
 int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
-                void* dt, int64_t lddt, float* dA, float* dB, int64_t M, int D, int K, int r, int P, float scaling,
-                tb_stream_t stream);
+                void* dt, int64_t lddt, float* dA /* += */, float* dB /* += */, float* ws, int64_t M, int D, int K, int r, int P,
+                float scaling, tb_stream_t stream);
 
 /* ---- optimizer tail: all scalars stay on the device in `state` (fp32[TB_ST_COUNT]) ------------------- */
 enum { TB_ST_LOSS_SCALE = 0, TB_ST_GROWTH_TRACKER = 1, TB_ST_STEP = 2, TB_ST_FOUND_INF = 3, TB_ST_COEF_LORA = 4,

@@ -84,6 +84,7 @@ def ref_attention(q, k, v, H, causal):
     (1, 8, 320, 320, 80, False),    # L1 (ragged vs 128 / 64 tiles)
     (2, 4, 64, 64, 160, False),     # L2/L3
     (2, 8, 200, 77, 40, False),     # cross attention, 77 text tokens
+    (2, 8, 1024, 77, 40, False),    # cross attention, long query range -> several q slices per key block
     (3, 12, 77, 77, 64, True),      # CLIP causal
     (2, 2, 100, 100, 32, False),    # tiny-config head dims
     (1, 2, 130, 70, 128, False),
@@ -113,7 +114,8 @@ def test_attention_fwd_bwd(B, H, Sq, Skv, hd, causal):
     dq = torch.empty(B * Sq, C, device="cuda", dtype=torch.float16)
     dkv = torch.empty(B * Skv, 2 * C, device="cuda", dtype=torch.float16)
     dk, dv = dkv[:, :C], dkv[:, C:]
-    ops.attention_bwd(q, k, v, o, lse, do, delta, dq, dk, dv, B, H, Sq, Skv, hd, causal=causal)
+    ws = torch.empty(8 * 2 * B * Skv * C, device="cuda") if Skv <= 128 else None   # exercises the split-q path
+    ops.attention_bwd(q, k, v, o, lse, do, delta, dq, dk, dv, B, H, Sq, Skv, hd, causal=causal, ws=ws)
     oref.backward(do.float().view(B, Sq, C))
     assert rel_err(dq.view(B, Sq, C), qr.grad) < 4e-3
     assert rel_err(dk.reshape(B, Skv, C), kr.grad) < 4e-3

@@ -53,6 +53,7 @@ class AttnDesc(C.Structure):
         ("dQ", C.c_void_p), ("lddq", C.c_int64),
         ("dK", C.c_void_p), ("lddk", C.c_int64),
         ("dV", C.c_void_p), ("lddv", C.c_int64),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 
@@ -61,6 +62,7 @@ _lib = None
 _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
+    "tb_last_hip_error": ([], C.c_char_p),
     "tb_groupnorm_ws_floats": ([_I, _I, _I, _I], _I64),
     "tb_groupnorm_fwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
     "tb_groupnorm_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I, _I, _I, _I, _I, _VP], C.c_int),
@@ -84,7 +86,8 @@ _SIGS = {
     "tb_textboost_pin_bwd": ([_VP, _VP, _I, _I, _I, _I, _I64, _VP], C.c_int),
     "tb_lora_down": ([_VP, _I64, _VP, _VP, _I64, _I64, _I, _I, _VP], C.c_int),
     "tb_lora_pack": ([_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP], C.c_int),
-    "tb_lora_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _VP, _VP, _I64, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_lora_bwd_ws_floats": ([_I64, _I, _I, _I, _I], _I64),
+    "tb_lora_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _F, _VP], C.c_int),
     "tb_sumsq": ([_VP, _I64, _VP, _VP], C.c_int),
     "tb_scaler_update": ([_VP, _F, _F, _F, _F, _F, _F, _I, _VP], C.c_int),
     "tb_adamw": ([_VP, _VP, _VP, _VP, _I64, _F, _F, _F, _F, _F, _VP, _I, _VP], C.c_int),
@@ -118,4 +121,7 @@ def stream():
 
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError(f"{what} failed with code {rc}")
+        detail = ""
+        if rc == -5:
+            detail = " (HIP: " + (lib().tb_last_hip_error() or b"?").decode() + ")"
+        raise RuntimeError(f"{what} failed with code {rc}{detail}")

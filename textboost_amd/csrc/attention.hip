@@ -89,7 +89,7 @@ __device__ __forceinline__ void load_row_frags(f16x8* f, const f16* g, int64_t l
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int DT, int KS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const tb_attn_desc p) {
+__global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const tb_attn_desc p) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DT, int KS>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const tb_attn_desc p) {
+__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
@@ -277,8 +277,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const tb_attn_desc p) 
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+// qsplit > 1: blockIdx.x = key_block * qsplit + q_slice; each block covers a slice of the queries and writes its partial
+// dK/dV in fp32 to ws32[slice][{K,V}][B*Skv][H*hd]; a finalize kernel sums the slices in a fixed order (deterministic)
+// and rounds to fp16.  Used when there are too few key blocks to fill the chip (cross-attention: 77 keys).
 template <int DT, int KS>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const tb_attn_desc p) {
+__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(const tb_attn_desc p, int qsplit, int q_chunk, float* ws32) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Qs = reinterpret_cast<f16*>(smem_raw);
@@ -289,7 +292,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const tb_attn_desc p)
   float* del_s = lse_s + KVT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int kblk = blockIdx.x * 128;
+  const int kblk = (blockIdx.x / qsplit) * 128;
+  const int qslice = blockIdx.x % qsplit;
   const int key = kblk + wave * 32 + l31;
   const bool kok = key < p.Skv;
   const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
@@ -308,9 +312,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const tb_attn_desc p)
     ZERO16(dk[d]);
     ZERO16(dv[d]);
   }
-  int q_begin = 0;
-  if (p.causal) q_begin = (kblk / KVT) * KVT;  // queries before the block's first key see none of its keys
-  for (int q0 = q_begin; q0 < p.Sq; q0 += KVT) {
+  int q_begin = qslice * q_chunk;
+  const int q_end = min(p.Sq, q_begin + q_chunk);
+  if (p.causal) q_begin = max(q_begin, (kblk / KVT) * KVT);  // queries before the block's first key see none of its keys
+  for (int q0 = q_begin; q0 < q_end; q0 += KVT) {
     __syncthreads();
     stage_tile<WD, true, true>(Qs, Qt, Qg, p.ldq, q0, p.Sq, p.hd);
     stage_tile<WD, true, true>(dOs, dOt, dOg, p.lddo, q0, p.Sq, p.hd);
@@ -351,7 +356,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const tb_attn_desc p)
       }
     }
   }
-  if (kok) {
+  if (kok && qsplit > 1) {
+    const int64_t C = (int64_t)p.H * p.hd;
+    const int64_t plane = (int64_t)p.B * p.Skv * C;
+    float* dK32 = ws32 + (int64_t)qslice * 2 * plane + ((int64_t)b * p.Skv + key) * C + h * p.hd;
+    float* dV32 = dK32 + plane;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < p.hd) {
+          f32x4 a, bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = dk[d][4 * r4 + e];
+            bb[e] = dv[d][4 * r4 + e];
+          }
+          *(f32x4*)(dK32 + col) = a;
+          *(f32x4*)(dV32 + col) = bb;
+        }
+      }
+  } else if (kok) {
     f16* dKg = (f16*)p.dK + ((int64_t)b * p.Skv + key) * p.lddk + h * p.hd;
     f16* dVg = (f16*)p.dV + ((int64_t)b * p.Skv + key) * p.lddv + h * p.hd;
 #pragma unroll
@@ -371,6 +397,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const tb_attn_desc p)
         }
       }
   }
+}
+
+__global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __restrict__ ws32, f16* __restrict__ dK, int64_t lddk,
+                                                                f16* __restrict__ dV, int64_t lddv, int64_t rows, int C, int qsplit) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t plane = rows * C;
+  if (idx >= plane) return;
+  const int64_t m = idx / C;
+  const int c = (int)(idx - m * C);
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < qsplit; ++s) {
+    a += ws32[(int64_t)s * 2 * plane + idx];
+    b += ws32[(int64_t)s * 2 * plane + plane + idx];
+  }
+  dK[m * lddk + c] = (f16)a;
+  dV[m * lddv + c] = (f16)b;
 }
 
 template <int DT, int KS>
@@ -408,8 +450,26 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
         return TB_ELAUNCH;
       attr_done = true;
     }
-    dim3 grid((d.Skv + 127) / 128, d.H, d.B);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, KS>), grid, dim3(256), lds, s, d);
+    const int nkb = (d.Skv + 127) / 128;
+    int qsplit = 1;
+    const int64_t nblk = (int64_t)nkb * d.H * d.B;
+    const int64_t C = (int64_t)d.H * d.hd;
+    const int64_t plane2 = 2 * (int64_t)d.B * d.Skv * C;
+    if (d.ws && d.ws_floats >= 2 * plane2 && !d.causal && nblk < 512) {
+      qsplit = (int)((1024 + nblk - 1) / nblk);
+      const int max_split = (d.Sq + KVT - 1) / KVT;
+      if (qsplit > max_split) qsplit = max_split;
+      if ((int64_t)qsplit * plane2 > d.ws_floats) qsplit = (int)(d.ws_floats / plane2);
+    }
+    int q_chunk = ((d.Sq + qsplit - 1) / qsplit + KVT - 1) / KVT * KVT;
+    if (qsplit > 1) qsplit = (d.Sq + q_chunk - 1) / q_chunk;
+    dim3 grid(nkb * qsplit, d.H, d.B);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, KS>), grid, dim3(256), lds, s, d, qsplit, q_chunk, d.ws);
+    if (qsplit > 1) {
+      const int64_t rows = (int64_t)d.B * d.Skv;
+      hipLaunchKernelGGL(attn_dkv_finalize_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, s, d.ws, (f16*)d.dK, d.lddk,
+                         (f16*)d.dV, d.lddv, rows, (int)C, qsplit);
+    }
   }
   TB_CHECK_LAUNCH();
   return TB_OK;
@@ -444,6 +504,7 @@ int check_desc(const tb_attn_desc& d, bool bwd) {
 }  // namespace
 
 extern "C" int tb_attention_fwd(const tb_attn_desc* dp, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dp) return TB_EINVAL;
   const tb_attn_desc d = *dp;
   int rc = check_desc(d, false);
@@ -452,6 +513,7 @@ extern "C" int tb_attention_fwd(const tb_attn_desc* dp, tb_stream_t stream) {
 }
 
 extern "C" int tb_attention_bwd(const tb_attn_desc* dp, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dp) return TB_EINVAL;
   const tb_attn_desc d = *dp;
   int rc = check_desc(d, true);

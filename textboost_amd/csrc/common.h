@@ -14,10 +14,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define TB_EINVAL (-22)
 #define TB_ELAUNCH (-5)
 
+// last HIP error seen by a failed launch check (diagnostics only; see tb_last_hip_error in optim.hip)
+extern "C" int tb_last_hip_error_code_;
 #define TB_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \
-    if (e__ != hipSuccess) return TB_ELAUNCH;               \
+    if (e__ != hipSuccess) {                                \
+      tb_last_hip_error_code_ = (int)e__;                   \
+      return TB_ELAUNCH;                                    \
+    }                                                       \
   } while (0)
 
 // row index of accumulator register r (0..15) of a 32x32 MFMA tile for a lane with hi = lane >> 5

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ in,
 
 extern "C" int tb_add_noise(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod, void* noisy,
                             float* velocity, int B, int64_t per_sample, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x0 || !noise || !timesteps || !alphas_cumprod || !noisy || B <= 0 || per_sample <= 0) return TB_EINVAL;
   const int64_t total = (int64_t)B * per_sample;
   hipLaunchKernelGGL(add_noise_kernel, GRID1D(total), dim3(256), 0, (hipStream_t)stream, x0, noise, timesteps, alphas_cumprod,
@@ -258,6 +259,7 @@ extern "C" int tb_add_noise(const float* x0, const float* noise, const int64_t* 
 }
 
 extern "C" int tb_timestep_embed(const int64_t* timesteps, void* out, int B, int dim, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!timesteps || !out || B <= 0 || dim <= 0 || dim % 2) return TB_EINVAL;
   hipLaunchKernelGGL(timestep_embed_kernel, GRID1D((int64_t)B * dim), dim3(256), 0, (hipStream_t)stream, timesteps, (f16*)out, B, dim);
   TB_CHECK_LAUNCH();
@@ -266,6 +268,7 @@ extern "C" int tb_timestep_embed(const int64_t* timesteps, void* out, int B, int
 
 extern "C" int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
                                 int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!in || !w_packed || !out || Cout % 8 || ldo % 8 || (sign != 1 && sign != -1)) return TB_EINVAL;
   const int64_t n = (int64_t)B * H * W * (Cout / 8);
   if (in_dtype == TB_F32)
@@ -280,6 +283,7 @@ extern "C" int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_pac
 
 extern "C" int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, const float* bias, void* out, int B, int H, int W, int C,
                            tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!in || !w_packed || !out || B <= 0) return TB_EINVAL;
   const int64_t M = (int64_t)B * H * W;
   hipLaunchKernelGGL(conv_to4_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)in, ldi, w_packed,
@@ -290,6 +294,7 @@ extern "C" int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, c
 
 extern "C" int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
                            tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!pred || !target || !loss_out || N <= 0) return TB_EINVAL;
   hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const f16*)pred, target, dpred, loss_out,
                      loss_scale, N);
@@ -299,6 +304,7 @@ extern "C" int tb_mse_loss(const void* pred, const float* target, float* dpred, 
 
 extern "C" int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,
                           float* partial, float* loss_out, const float* loss_scale, float weight, int64_t M, int D, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!h || !h0 || !partial || !loss_out || M <= 0 || D <= 0) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 3) / 4));
@@ -315,6 +321,7 @@ extern "C" int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t l
 
 extern "C" int tb_geglu_bwd(const void* dout, int64_t lddo, const void* raw, int64_t ldr, void* dproj, int64_t lddp, int64_t M,
                             int inner, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dout || !raw || !dproj || inner % 32 || lddo % 8 || ldr % 8 || lddp % 8) return TB_EINVAL;
   hipLaunchKernelGGL(geglu_bwd_kernel, GRID1D(M * (inner / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, lddo,
                      (const f16*)raw, ldr, (f16*)dproj, lddp, M, inner);
@@ -323,6 +330,7 @@ extern "C" int tb_geglu_bwd(const void* dout, int64_t lddo, const void* raw, int
 }
 
 extern "C" int tb_pool2x2_sum(const void* du, int64_t ldu, void* dx, int64_t ldx, int B, int H, int W, int C, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!du || !dx || C % 8 || ldu % 8 || ldx % 8) return TB_EINVAL;
   hipLaunchKernelGGL(pool2x2_sum_kernel, GRID1D((int64_t)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)du, ldu,
                      (f16*)dx, ldx, B, H, W, C);
@@ -332,6 +340,7 @@ extern "C" int tb_pool2x2_sum(const void* du, int64_t ldu, void* dx, int64_t ldx
 
 extern "C" int tb_add_f16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t M, int C,
                           tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!a || !b || !out || C % 8 || lda % 8 || ldb % 8 || ldo % 8) return TB_EINVAL;
   hipLaunchKernelGGL(add_f16_kernel, GRID1D(M * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)a, lda, (const f16*)b, ldb,
                      (f16*)out, ldo, M, C);
@@ -341,6 +350,7 @@ extern "C" int tb_add_f16(const void* a, int64_t lda, const void* b, int64_t ldb
 
 extern "C" int tb_convert(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int64_t M, int C, float scale,
                           tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!in || !out || M <= 0 || C <= 0) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid = GRID1D(M * C);

@@ -422,6 +422,7 @@ extern "C" int64_t tb_groupnorm_ws_floats(int B, int HW, int C, int G) { return 
 
 extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                                 float* stats, float* ws, int B, int HW, int C, int G, float eps, int silu, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x || !y || !gamma || !beta || !stats || !ws) return TB_EINVAL;
   if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || ldy % 8 || B <= 0 || HW <= 0) return TB_EINVAL;
   const int nch = gn_chunks(B, HW, C);
@@ -436,6 +437,7 @@ extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy
 extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,
                                 const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx, float* ws, int B, int HW,
                                 int C, int G, int silu, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dy || !x || !gamma || !beta || !stats || !dx || !ws) return TB_EINVAL;
   if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8)) return TB_EINVAL;
   const int nch = gn_chunks(B, HW, C);
@@ -450,6 +452,7 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
 
 extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
                                 const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x || !y || !gamma || !beta || M <= 0) return TB_EINVAL;
   if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || ldy % 8) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -469,6 +472,7 @@ extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y
 extern "C" int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,
                                 const float* gamma, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx,
                                 int64_t M, int C, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dy || !x || !gamma || !stats || !dx || M <= 0) return TB_EINVAL;
   if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8)) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;

@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
 
 #define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
 
+extern "C" int tb_last_hip_error_code_ = 0;
+extern "C" const char* tb_last_hip_error(void) { return hipGetErrorString((hipError_t)tb_last_hip_error_code_); }
+
 extern "C" int tb_sumsq(const float* x, int64_t n, float* out, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x || !out || n <= 0) return TB_EINVAL;
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
   TB_CHECK_LAUNCH();
@@ -129,6 +133,7 @@ extern "C" int tb_sumsq(const float* x, int64_t n, float* out, tb_stream_t strea
 
 extern "C" int tb_scaler_update(float* state, float max_norm, float beta1, float beta2, float growth_factor, float backoff_factor,
                                 float growth_interval, int use_scaler, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!state) return TB_EINVAL;
   hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, max_norm, beta1, beta2, growth_factor,
                      backoff_factor, growth_interval, use_scaler);
@@ -138,6 +143,7 @@ extern "C" int tb_scaler_update(float* state, float max_norm, float beta1, float
 
 extern "C" int tb_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                         const float* state, int coef_slot, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!p || !g || !m || !v || !state || n <= 0) return TB_EINVAL;
   if (coef_slot != TB_ST_COEF_LORA && coef_slot != TB_ST_COEF_EMB) return TB_EINVAL;
   hipLaunchKernelGGL(adamw_kernel, GRID1D(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, wd, state,
@@ -147,6 +153,7 @@ extern "C" int tb_adamw(float* p, const float* g, float* m, float* v, int64_t n,
 }
 
 extern "C" int tb_weight_decay(float* p, int64_t n, float factor, const float* state, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!p || !state || n <= 0 || n % 4) return TB_EINVAL;
   hipLaunchKernelGGL(decay_kernel, GRID1D(n / 4), dim3(256), 0, (hipStream_t)stream, p, n / 4, factor, state);
   TB_CHECK_LAUNCH();
@@ -154,6 +161,7 @@ extern "C" int tb_weight_decay(float* p, int64_t n, float factor, const float* s
 }
 
 extern "C" int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, float* norms, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!rows || n_rows <= 0 || D <= 0) return TB_EINVAL;
   hipLaunchKernelGGL(renorm_rows_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, rows, D, mean_norm, norms);
   TB_CHECK_LAUNCH();
@@ -161,6 +169,7 @@ extern "C" int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, f
 }
 
 extern "C" int tb_row_norms(const float* w, int64_t rows, int D, float* norms, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!w || !norms || rows <= 0 || rows % 4) return TB_EINVAL;
   hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)(rows / 4)), dim3(256), 0, (hipStream_t)stream, w, D, norms);
   TB_CHECK_LAUNCH();

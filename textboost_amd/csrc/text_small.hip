@@ -105,41 +105,56 @@ __global__ __launch_bounds__(256) void lora_bwd_dt_kernel(const f16* __restrict_
       if (lane == 0) dt[row * lddt + p * r + j] = (f16)a;
     }
 }
-// (b) dB[(p*D+n)*r + j] += scaling * sum_m dY[m, p*D+n] * t[m, p*r+j]              (thread per output column n)
+// (b)/(c) are reductions over the M rows; M is split into slabs of LORA_RS rows across blockIdx.y so the chip is
+// filled, per-slab partials go to a workspace and a second kernel sums them in a fixed order (deterministic).
+constexpr int LORA_RS = 16;
+// (b) partB[s][n*r + j] = sum_{m in slab s} dY[m, n] * t[m, p*r+j]                    (thread per output column n)
 __global__ __launch_bounds__(256) void lora_bwd_db_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ t,
-                                                          int64_t ldt, float* __restrict__ dB, int64_t M, int D, int r, int P,
-                                                          float scaling) {
+                                                          int64_t ldt, float* __restrict__ part, int64_t M, int D, int r, int P) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over P*D
   if (n >= (int64_t)P * D) return;
   const int p = (int)(n / D);
+  const int64_t m0 = (int64_t)blockIdx.y * LORA_RS, m1 = m0 + LORA_RS < M ? m0 + LORA_RS : M;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t m = 0; m < M; ++m) {
+  for (int64_t m = m0; m < m1; ++m) {
     const float d = (float)dY[m * lddy + n];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (j < r) a[j] += d * (float)t[m * ldt + p * r + j];
   }
+  float* o = part + (int64_t)blockIdx.y * P * D * r + n * r;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if (j < r) dB[n * r + j] += scaling * a[j];
+    if (j < r) o[j] = a[j];
 }
-// (c) dA[j*K + k] += sum_m dt[m, j] * x[m, k]                                         (thread per k, j < R <= 24)
+// (c) partA[s][j*K + k] = sum_{m in slab s} dt[m, j] * x[m, k]                          (thread per k, j < R <= 24)
 __global__ __launch_bounds__(256) void lora_bwd_da_kernel(const f16* __restrict__ dt, int64_t lddt, const f16* __restrict__ x,
-                                                          int64_t ldx, float* __restrict__ dA, int64_t M, int K, int R) {
+                                                          int64_t ldx, float* __restrict__ part, int64_t M, int K, int R) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
+  const int64_t m0 = (int64_t)blockIdx.y * LORA_RS, m1 = m0 + LORA_RS < M ? m0 + LORA_RS : M;
   float a[24];
 #pragma unroll
   for (int j = 0; j < 24; ++j) a[j] = 0.f;
-  for (int64_t m = 0; m < M; ++m) {
+  for (int64_t m = m0; m < m1; ++m) {
     const float xv = (float)x[m * ldx + k];
 #pragma unroll
     for (int j = 0; j < 24; ++j)
       if (j < R) a[j] += (float)dt[m * lddt + j] * xv;
   }
+  float* o = part + (int64_t)blockIdx.y * R * K;
 #pragma unroll
   for (int j = 0; j < 24; ++j)
-    if (j < R) dA[(int64_t)j * K + k] += a[j];
+    if (j < R) o[(int64_t)j * K + k] = a[j];
+}
+// out[i] += scale * sum_s part[s*n + i]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int nslab,
+                                                          float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < nslab; ++s) a += part[(int64_t)s * n + i];
+  out[i] += scale * a;
 }
 
 }  // namespace
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(256) void lora_bwd_da_kernel(const f16* __restrict_
 
 extern "C" int tb_embed_fwd(const int64_t* ids, const void* tok, const void* pos, int table_dtype, void* out, int out_dtype, int64_t M,
                             int T, int D, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!ids || !tok || !pos || !out || M <= 0) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (table_dtype == TB_F32 && out_dtype == TB_F32)
@@ -164,6 +180,7 @@ extern "C" int tb_embed_fwd(const int64_t* ids, const void* tok, const void* pos
 
 extern "C" int tb_embed_bwd(const float* dh, const int64_t* ids, float* g_added, int64_t M, int D, int64_t first_added, int n_added,
                             tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dh || !ids || !g_added || n_added <= 0) return TB_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_added), dim3(256), 0, (hipStream_t)stream, dh, ids, g_added, M, D, first_added);
   TB_CHECK_LAUNCH();
@@ -172,6 +189,7 @@ extern "C" int tb_embed_bwd(const float* dh, const int64_t* ids, float* g_added,
 
 extern "C" int tb_textboost_pin_fwd(void* h, int h_dtype, const int64_t* ids, const float* null_embedding, int B, int T, int D,
                                     int use_fixed, int64_t eos_id, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!h || !ids || !null_embedding) return TB_EINVAL;
   const int64_t n = (int64_t)B * T * D;
   if (h_dtype == TB_F32)
@@ -186,6 +204,7 @@ extern "C" int tb_textboost_pin_fwd(void* h, int h_dtype, const int64_t* ids, co
 
 extern "C" int tb_textboost_pin_bwd(float* dh, const int64_t* ids, int B, int T, int D, int use_fixed, int64_t eos_id,
                                     tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dh || !ids) return TB_EINVAL;
   hipLaunchKernelGGL(pin_bwd_kernel, GRID1D((int64_t)B * T * D), dim3(256), 0, (hipStream_t)stream, dh, ids, B, T, D, use_fixed, eos_id);
   TB_CHECK_LAUNCH();
@@ -194,6 +213,7 @@ extern "C" int tb_textboost_pin_bwd(float* dh, const int64_t* ids, int B, int T,
 
 extern "C" int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t, int64_t ldt, int64_t M, int K, int R,
                             tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x || !A || !t || R <= 0 || R > 64) return TB_EINVAL;
   hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, A, (f16*)t,
                      ldt, M, K, R);
@@ -203,6 +223,7 @@ extern "C" int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t,
 
 extern "C" int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd, void* w2_dgrad, int D, int K, int r, int P, float scaling,
                             tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!A || !Bcat || !w2_fwd || !w2_dgrad || P * r > 64) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(lora_pack_b_kernel, GRID1D((int64_t)P * D * 64), dim3(256), 0, s, Bcat, (f16*)w2_fwd, D, r, P, scaling);
@@ -211,16 +232,28 @@ extern "C" int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd, voi
   return TB_OK;
 }
 
+extern "C" int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P) {
+  const int64_t nslab = (M + LORA_RS - 1) / LORA_RS;
+  return nslab * ((int64_t)P * D * r + (int64_t)P * r * K);
+}
+
 extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
-                           void* dt, int64_t lddt, float* dA, float* dB, int64_t M, int D, int K, int r, int P, float scaling,
-                           tb_stream_t stream) {
-  if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || r > 8 || P * r > 24) return TB_EINVAL;
+                           void* dt, int64_t lddt, float* dA, float* dB, float* ws, int64_t M, int D, int K, int r, int P,
+                           float scaling, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || !ws || r > 8 || P * r > 24) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const int nslab = (int)((M + LORA_RS - 1) / LORA_RS);
+  float* partB = ws;
+  float* partA = ws + (int64_t)nslab * P * D * r;
   hipLaunchKernelGGL(lora_bwd_dt_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const f16*)dY, lddy, Bcat, (f16*)dt, lddt, M,
                      D, r, P, scaling);
-  hipLaunchKernelGGL(lora_bwd_db_kernel, GRID1D((int64_t)P * D), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)t, ldt, dB, M, D, r,
-                     P, scaling);
-  hipLaunchKernelGGL(lora_bwd_da_kernel, GRID1D(K), dim3(256), 0, s, (const f16*)dt, lddt, (const f16*)x, ldx, dA, M, K, P * r);
+  hipLaunchKernelGGL(lora_bwd_db_kernel, dim3((unsigned)(((int64_t)P * D + 255) / 256), nslab), dim3(256), 0, s, (const f16*)dY, lddy,
+                     (const f16*)t, ldt, partB, M, D, r, P);
+  hipLaunchKernelGGL(lora_bwd_da_kernel, dim3((unsigned)((K + 255) / 256), nslab), dim3(256), 0, s, (const f16*)dt, lddt,
+                     (const f16*)x, ldx, partA, M, K, P * r);
+  hipLaunchKernelGGL(slab_reduce_kernel, GRID1D((int64_t)P * D * r), dim3(256), 0, s, partB, dB, (int64_t)P * D * r, nslab, scaling);
+  hipLaunchKernelGGL(slab_reduce_kernel, GRID1D((int64_t)P * r * K), dim3(256), 0, s, partA, dA, (int64_t)P * r * K, nslab, 1.f);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -11,6 +11,39 @@ def _dt(t):
     return L.TB_F32 if t.dtype == torch.float32 else L.TB_F16
 
 
+# ---- optional per-launch timing (bench.py roofline leg): HIP events on torch's current stream, which is the stream every
+# kernel here is launched on.  Off by default; never active inside graph capture.
+_REC = None
+
+
+def start_recording():
+    global _REC
+    _REC = []
+
+
+def stop_recording():
+    global _REC
+    r, _REC = _REC, None
+    return r
+
+
+class _rec:
+    def __init__(self, name, flops=0.0, bytes_=0.0):
+        self.name, self.flops, self.bytes = name, flops, bytes_
+
+    def __enter__(self):
+        if _REC is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _REC is not None:
+            self.e1.record()
+            _REC.append((self.name, self.flops, self.bytes, self.e0, self.e1))
+
+
 def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_per_group=0, R=None, act=L.ACT_NONE,
          alpha=1.0, C2=None, conv=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
@@ -48,7 +81,13 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
     d.C, d.ldc, d.c_dtype = L.ptr(out), out.stride(0), _dt(out)
     if C2 is not None:
         d.C2, d.ldc2 = L.ptr(C2), C2.stride(0)
-    L.check(L.lib().tb_gemm(d, L.stream()), "tb_gemm")
+    if _REC is not None:
+        narrow = (N % 128) != 0 and (N % 128) <= 64 and act != L.ACT_GEGLU
+        name = f"gemm_kernel<128,{64 if narrow else 128},{'CONV3X3' if conv is not None else 'LINEAR'}>"
+    else:
+        name = "gemm"
+    with _rec(name, 2.0 * M * N * d.K):
+        L.check(L.lib().tb_gemm(d, L.stream()), "tb_gemm")
     return out
 
 
@@ -58,15 +97,17 @@ def groupnorm_ws(B, HW, C, G=32):
 
 def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, G=32, eps=1e-5, silu=False):
     """x,y: [B*HW, C] fp16 (may be strided slices). stats [B,G,2] fp32 out."""
-    L.check(L.lib().tb_groupnorm_fwd(L.ptr(x), x.stride(0), L.ptr(y), y.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
-                                     L.ptr(ws), B, HW, C, G, eps, int(silu), L.stream()), "tb_groupnorm_fwd")
+    with _rec("groupnorm_fwd(stats+apply)", 0.0, 3.0 * B * HW * C * 2):
+        L.check(L.lib().tb_groupnorm_fwd(L.ptr(x), x.stride(0), L.ptr(y), y.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
+                                         L.ptr(ws), B, HW, C, G, eps, int(silu), L.stream()), "tb_groupnorm_fwd")
     return y
 
 
 def groupnorm_bwd(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G=32, silu=False, add=None):
-    L.check(L.lib().tb_groupnorm_bwd(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
-                                     L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), L.ptr(ws),
-                                     B, HW, C, G, int(silu), L.stream()), "tb_groupnorm_bwd")
+    with _rec("groupnorm_bwd(stats+apply)", 0.0, (6.0 if add is not None else 5.0) * B * HW * C * 2):
+        L.check(L.lib().tb_groupnorm_bwd(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
+                                         L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), L.ptr(ws),
+                                         B, HW, C, G, int(silu), L.stream()), "tb_groupnorm_bwd")
     return dx
 
 
@@ -99,18 +140,22 @@ def _attn_desc(q, k, v, o, lse, B, H, Sq, Skv, hd, scale, causal):
 def attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd, scale=None, causal=False):
     """q,o: [B*Sq, H*hd]; k,v: [B*Skv, H*hd] fp16 (column slices allowed). lse fp32 [B,H,Sq]."""
     d = _attn_desc(q, k, v, o, lse, B, H, Sq, Skv, hd, scale if scale is not None else hd ** -0.5, causal)
-    L.check(L.lib().tb_attention_fwd(d, L.stream()), "tb_attention_fwd")
+    with _rec("attn_fwd_kernel", 4.0 * B * H * Sq * Skv * hd):
+        L.check(L.lib().tb_attention_fwd(d, L.stream()), "tb_attention_fwd")
     return o
 
 
-def attention_bwd(q, k, v, o, lse, do, delta, dq, dk, dv, B, H, Sq, Skv, hd, scale=None, causal=False):
+def attention_bwd(q, k, v, o, lse, do, delta, dq, dk, dv, B, H, Sq, Skv, hd, scale=None, causal=False, ws=None):
     d = _attn_desc(q, k, v, o, lse, B, H, Sq, Skv, hd, scale if scale is not None else hd ** -0.5, causal)
     d.dO, d.lddo = L.ptr(do), do.stride(0)
     d.Delta = L.ptr(delta)
     d.dQ, d.lddq = L.ptr(dq), dq.stride(0)
     d.dK, d.lddk = L.ptr(dk), dk.stride(0)
     d.dV, d.lddv = L.ptr(dv), dv.stride(0)
-    L.check(L.lib().tb_attention_bwd(d, L.stream()), "tb_attention_bwd")
+    if ws is not None:
+        d.ws, d.ws_floats = L.ptr(ws), ws.numel()
+    with _rec("attn_bwd(delta+dq+dkv)", 10.0 * B * H * Sq * Skv * hd):
+        L.check(L.lib().tb_attention_bwd(d, L.stream()), "tb_attention_bwd")
 
 
 # ------------------------------------------------------------------ small streaming kernels
@@ -194,10 +239,18 @@ def lora_pack(A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, scaling=1.0):
     L.check(L.lib().tb_lora_pack(L.ptr(A), L.ptr(Bcat), L.ptr(w2_fwd), L.ptr(w2_dgrad), D, K, r, P, scaling, L.stream()), "tb_lora_pack")
 
 
-def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0):
+_lora_ws = {}
+
+
+def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None):
     M = x.shape[0]
+    if ws is None:
+        key = (M, D, K, r, P, x.device)
+        ws = _lora_ws.get(key)
+        if ws is None:
+            ws = _lora_ws[key] = torch.empty(int(L.lib().tb_lora_bwd_ws_floats(M, D, K, r, P)), device=x.device)
     L.check(L.lib().tb_lora_bwd(L.ptr(dY), dY.stride(0), L.ptr(x), x.stride(0), L.ptr(t), t.stride(0), L.ptr(Bcat), L.ptr(dt),
-                                dt.stride(0), L.ptr(dA), L.ptr(dB), M, D, K, r, P, scaling, L.stream()), "tb_lora_bwd")
+                                dt.stride(0), L.ptr(dA), L.ptr(dB), L.ptr(ws), M, D, K, r, P, scaling, L.stream()), "tb_lora_bwd")
 
 
 # ------------------------------------------------------------------ optimizer tail

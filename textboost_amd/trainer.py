@@ -86,13 +86,20 @@ class TextBoostStep:
         self.x0 = torch.zeros(B, C, H, W, device=device)
         self.noise = torch.zeros(B, C, H, W, device=device)
         self.timesteps = torch.zeros(B, dtype=torch.int64, device=device)
-        self.input_ids = torch.zeros(B, te.T, dtype=torch.int64, device=device)
-        self.prior_ids = torch.zeros(B, te.T, dtype=torch.int64, device=device)
+        # the instance prompts (:1054) and the KPL prior prompts (:1099) go through the trainable encoder as ONE batch of 2B
+        # rows (rows are independent, so this is arithmetically identical to the reference's two calls)
+        self.kpl = hyper.kpl_weight > 0 and teacher is not None
+        nb = 2 * B if self.kpl else B
+        self.ids_all = torch.zeros(nb, te.T, dtype=torch.int64, device=device)
+        self.input_ids = self.ids_all[:B]
+        self.prior_ids = self.ids_all[B:] if self.kpl else torch.zeros(B, te.T, dtype=torch.int64, device=device)
+        self.d_all = torch.zeros(nb * te.T, D, device=device)
         self.noisy = torch.empty(B, C, H, W, device=device, dtype=torch.float16)
         self.velocity = torch.empty(B, C, H, W, device=device) if hyper.prediction_type == "v_prediction" else None
         self.dpred = torch.empty(B, C, H, W, device=device)
         self.ehs16 = torch.empty(B * te.T, D, device=device, dtype=torch.float16)
-        self.d_prior = torch.empty(B * te.T, D, device=device)
+        self.d_ehs = self.d_all[: B * te.T]
+        self.d_prior = self.d_all[B * te.T:]
         self.kpl_partial = torch.empty(B * te.T, device=device)
         self.added_norms = torch.empty(max(te.n_added, 1), device=device)
         self.graph = None
@@ -111,20 +118,18 @@ class TextBoostStep:
         st = self.state
         ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
         te.pack_lora()
-        ehs = te.forward(self.input_ids, slot=0)                                   # :1054-1059
-        ops.convert(ehs, self.ehs16)                                               # .to(unet.dtype) :1066
+        BT = B * te.T
+        h_all = te.forward(self.ids_all, slot=0)                                   # :1054-1059 and :1099 in one batch
+        ops.convert(h_all[:BT], self.ehs16)                                        # .to(unet.dtype) :1066
         pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)           # :1063-1067
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
         ops.mse_loss(pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
-        if hp.kpl_weight > 0 and self.teacher is not None:                         # :1096-1106
-            h = te.forward(self.prior_ids, slot=1)
+        if self.kpl:                                                               # :1096-1106
             h0 = self.teacher.forward(self.prior_ids, slot=0)
-            ops.kpl_cos(h, h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
-        d_ehs = self.unet.backward(self.dpred)                                     # :1108 (UNet part, dgrad only)
+            ops.kpl_cos(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
+        self.unet.backward(self.dpred, d_ehs_out=self.d_ehs)                       # :1108 (UNet part, dgrad only)
         self.flat_grad.zero_()
-        te.backward(d_ehs, slot=0)
-        if hp.kpl_weight > 0 and self.teacher is not None:
-            te.backward(self.d_prior, slot=1)
+        te.backward(self.d_all, slot=0)
 
     def all_reduce(self):
         """DDP gradient averaging (:919-926): ONE RCCL all-reduce of the flat trainable-gradient buffer

@@ -328,7 +328,8 @@ class HipUNet:
             dq2 = self.scratch("g2", M, C)
             delta = self.scratch("delta", B * heads, HW, torch.float32)
             dk2, dv2 = self.dkv_all[:, ko:ko + C], self.dkv_all[:, ko + C:ko + 2 * C]
-            ops.attention_bwd(q2, k2, v2, o2, lse2, do2, delta, dq2, dk2, dv2, B, heads, HW, T, hd)
+            xws = self.scratch("xattn_ws", 16 * 2 * B * T, C, torch.float32)
+            ops.attention_bwd(q2, k2, v2, o2, lse2, do2, delta, dq2, dk2, dv2, B, heads, HW, T, hd, ws=xws)
             if stop_after_cross:
                 return
             dl2 = self.scratch("g1", M, C)
