@@ -59,10 +59,13 @@ typedef struct tb_gemm_desc {
   void* C2; int64_t ldc2;        /* fp16 [M,N] aux: GEGLU: raw pre-gate output (packed order), written;
                                   * QUICK_GELU: pre-activation, written (if non-NULL);
                                   * QUICK_GELU_GRAD: pre-activation, READ: v *= quick_gelu'(C2[m,n]) */
-  int32_t split_k;               /* reserved, must be 0 or 1 */
+  void* ws; int64_t ws_bytes;    /* optional scratch: lets small-M / long-K problems split K over blocks (fp32 partials,
+                                  * fixed-order reduction => deterministic); NULL disables */
 } tb_gemm_desc;
 
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
+/* tuning knob for the k-tile / pipeline-depth variant of tb_gemm (returns the previous value); 0 is the default */
+int tb_gemm_set_variant(int v);
 
 /* text of the HIP error behind the most recent -5 (launch failure) return; diagnostics only */
 const char* tb_last_hip_error(void);

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textboost_amd import ops, _lib as L
 dev = "cuda"
 def timeit(fn, n=20, warm=3):

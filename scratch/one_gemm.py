@@ -1,0 +1,20 @@
+import sys, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from textboost_amd import ops, _lib as L
+dev = "cuda"
+which = sys.argv[1] if len(sys.argv) > 1 else "lin"
+if which == "lin":
+    M, N, K = 32768, 2560, 320
+    A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half(); out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    fn = lambda: ops.gemm(A, W, out)
+elif which == "lin2":
+    M, N, K = 8192, 5120, 640
+    A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half(); out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    fn = lambda: ops.gemm(A, W, out)
+else:
+    B, H, Ci, Co = 8, 64, 320, 320
+    x = torch.randn(B * H * H, Ci, device=dev).half(); w = torch.randn(Co, 9 * Ci, device=dev).half(); out = torch.empty(B * H * H, Co, device=dev, dtype=torch.float16)
+    geo = dict(B=B, Hin=H, Win=H, Cin=Ci, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+    fn = lambda: ops.gemm(x, w, out, conv=geo)
+for _ in range(5): fn()
+torch.cuda.synchronize()

@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32),
         ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int32),
         ("C2", C.c_void_p), ("ldc2", C.c_int64),
-        ("split_k", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -63,6 +63,7 @@ _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
     "tb_last_hip_error": ([], C.c_char_p),
+    "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_groupnorm_ws_floats": ([_I, _I, _I, _I], _I64),
     "tb_groupnorm_fwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
     "tb_groupnorm_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I, _I, _I, _I, _I, _VP], C.c_int),

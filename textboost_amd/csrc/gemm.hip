@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int BK = 64;  // halfs per k-tile (128 B per tile row)
+constexpr int BK = 64;  // K granularity required of callers (halfs)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -32,45 +32,189 @@ __device__ __forceinline__ void glds16(const f16* src, f16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n) {
+// Epilogue for 8 consecutive output columns n..n+7 of row m (shared by the MFMA kernel and the split-K reducer):
+// v = alpha*acc + bias + rowbias + R ; activation ; store C (fp16 | fp32), optionally C2 (pre-activation).
+// All global accesses are 16-byte vectors when the row pitch / base alignment allow (EpiFlags), else scalar.
+struct EpiFlags {
+  bool c_vec, r_vec, c2_vec;
+};
+__device__ __forceinline__ EpiFlags epi_flags(const tb_gemm_desc& p) {
+  EpiFlags f;
+  f.c_vec = (p.ldc % 8 == 0) && (((uintptr_t)p.C) % 16 == 0);
+  f.r_vec = p.R && (p.ldr % 8 == 0) && (((uintptr_t)p.R) % 16 == 0);
+  f.c2_vec = p.C2 && (p.ldc2 % 8 == 0) && (((uintptr_t)p.C2) % 16 == 0);
+  return f;
+}
+__device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n, float* v) {
+  const bool full = n + 7 < p.N;
+  const float* rb = p.rowbias ? p.rowbias + (m / p.rows_per_group) * p.ldrb : nullptr;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] *= p.alpha;
+    if (full || n + e < p.N) {
+      if (p.bias) v[e] += p.bias[n + e];
+      if (rb) v[e] += rb[n + e];
+    }
+  }
+  if (p.R) {
+    if (p.r_dtype == TB_F32) {
+      const float* rp = (const float*)p.R + m * p.ldr + n;
+      if (full && f.r_vec) {
+        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += r0[e];
+          v[4 + e] += r1[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) v[e] += rp[e];
+      }
+    } else {
+      const f16* rp = (const f16*)p.R + m * p.ldr + n;
+      if (full && f.r_vec) {
+        const f16x8 rv = *(const f16x8*)rp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) v[e] += (float)rp[e];
+      }
+    }
+  }
+  if (p.act == TB_ACT_QUICK_GELU) {
+    f16x8 pre;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pre[e] = (f16)v[e];
+      v[e] = quick_gelu_f((float)pre[e]);  // fp16 linear output feeds the activation, as under autocast
+    }
+    if (p.C2) {
+      f16* c2 = (f16*)p.C2 + m * p.ldc2 + n;
+      if (full && f.c2_vec) *(f16x8*)c2 = pre;
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) c2[e] = pre[e];
+      }
+    }
+  } else if (p.act == TB_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+  } else if (p.act == TB_ACT_QUICK_GELU_GRAD) {
+    const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + n;
+    if (full && f.c2_vec) {
+      const f16x8 pv = *(const f16x8*)c2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f((float)pv[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) v[e] *= quick_gelu_grad_f((float)c2[e]);
+    }
+  }
+  if (p.c_dtype == TB_F32) {
+    float* c = (float*)p.C + m * p.ldc + n;
+    if (full && f.c_vec) {
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = v[e];
+        o1[e] = v[4 + e];
+      }
+      *(f32x4*)c = o0;
+      *(f32x4*)(c + 4) = o1;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) c[e] = v[e];
+    }
+  } else {
+    f16* c = (f16*)p.C + m * p.ldc + n;
+    if (full && f.c_vec) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+      *(f16x8*)c = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) c[e] = (f16)v[e];
+    }
+  }
+}
+
+// split-K second pass: C = epilogue(sum_s ws[s][m][n]); ws is fp32 [S][M][Npad] with Npad = N rounded up to 8
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p, const float* __restrict__ ws, int S, int64_t npad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t groups = npad >> 3;
+  if (idx >= p.M * groups) return;
+  const int64_t m = idx / groups;
+  const int64_t n = (idx - m * groups) << 3;
+  const EpiFlags f = epi_flags(p);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const float* src = ws + ((int64_t)s * p.M + m) * npad + n;
+    const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] += x0[e];
+      v[4 + e] += x1[e];
+    }
+  }
+  epilogue8(p, f, m, n, v);
+}
+
+// BKT: halfs per k-tile (64 -> 128-byte LDS rows, 32 -> 64-byte rows); NST: LDS stages (2, or 3 with counted vmcnt)
+template <int BM, int BN, int MODE, int BKT, int NST>
+__global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int S, float* __restrict__ ws, int64_t npad, int abl) {
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   f16* smem = reinterpret_cast<f16*>(smem_raw);
+  constexpr int BK = BKT;
   constexpr int A_TILE = BM * BK, B_TILE = BN * BK, STAGE = A_TILE + B_TILE;
+  constexpr int CPR = BK / 8;          // 16-byte chunks per LDS row
+  constexpr int RPI = 64 / CPR;        // rows filled by one wave-wide global_load_lds
+#define SWZ(row) (BKT == 64 ? (((row) >> 1) & 7) : (((row) >> 2) & 3))
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
-  constexpr int AI = BM / 32, BI = BN / 32;  // global_load_lds instructions per wave per k-tile (8 rows each)
+  constexpr int AI = BM / 4 / RPI, BI = BN / 4 / RPI;  // global_load_lds instructions per wave per k-tile
 
   // ---- XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a contiguous run of tiles
-  const int nwg = tiles_m * tiles_n;
-  int tile;
+  const int nwg = tiles_m * tiles_n * S;
+  int tile, slice;
   {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile = logical / S;       // the S k-slices of one tile are adjacent (same XCD)
+    slice = logical - tile * S;
   }
-  const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
-  const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
+  // walk the SMALLER operand fastest so it stays L2-resident while the larger one streams through once per XCD
+  const bool m_fastest = MODE == TB_A_LINEAR && p.N > p.M;
+  const int64_t m0 = (int64_t)(m_fastest ? tile % tiles_m : tile / tiles_n) * BM;
+  const int64_t n0 = (int64_t)(m_fastest ? tile / tiles_m : tile % tiles_n) * BN;
 
-  const int cp = lane & 7;   // 16-byte chunk position inside the 128-byte LDS row this lane fills
-  const int rl = lane >> 3;  // row within the 8-row group of one load instruction
+  const int cp = lane % CPR;  // 16-byte chunk position inside the LDS row this lane fills
+  const int rl = lane / CPR;  // row within the row group of one load instruction
 
   // ---- per-lane source descriptors (rows are fixed across k-tiles)
   const f16* a_ptr[AI];
   const f16* a2_ptr[AI];
   bool a_ok[AI];
-  int py[AI], px[AI], a_sw[AI];
+  int py[AI], px[AI], a_sw[AI], a_step[AI];
   int64_t pbase[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int row = wave * (BM / 4) + i * 8 + rl;
+    const int row = wave * (BM / 4) + i * RPI + rl;
     const int64_t m = m0 + row;
     a_ok[i] = m < p.M;
     const int64_t mm = a_ok[i] ? m : 0;
-    a_sw[i] = (cp ^ ((row >> 1) & 7)) * 8;  // source chunk (halfs) that belongs at LDS chunk position cp of this row
+    a_sw[i] = (cp ^ SWZ(row)) * 8;  // source chunk (halfs) that belongs at LDS chunk position cp of this row
     if (MODE == TB_A_LINEAR) {
       a_ptr[i] = (const f16*)p.A + mm * p.lda + a_sw[i];
       a2_ptr[i] = p.A2 ? (const f16*)p.A2 + mm * p.lda2 + a_sw[i] : nullptr;
@@ -88,21 +232,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int 
   bool w_ok[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int row = wave * (BN / 4) + i * 8 + rl;
+    const int row = wave * (BN / 4) + i * RPI + rl;
     const int64_t n = n0 + row;
     w_ok[i] = n < p.N;
     const int64_t nn = w_ok[i] ? n : 0;
-    const int sw = (cp ^ ((row >> 1) & 7)) * 8;
+    const int sw = (cp ^ SWZ(row)) * 8;
     w_ptr[i] = (const f16*)p.W + nn * p.ldw + sw;
     w2_ptr[i] = p.W2 ? (const f16*)p.W2 + nn * p.ldw2 + sw : nullptr;
   }
 
-  const int nk = (int)(p.K / BK);
+  const int nk_all = (int)(p.K / BK);
   const int nk1 = (int)(p.K1 / BK);
+  const int kt_begin = (int)((int64_t)nk_all * slice / S), kt_end = (int)((int64_t)nk_all * (slice + 1) / S);
+  const int nk = kt_end - kt_begin;  // k-tiles of this block; stage()/loops below index them relative to kt_begin
   const int kpt = (MODE == TB_A_CONV3X3) ? p.Cin / BK : 1;  // k-tiles per tap
   const f16* zero = g_zero_line;
 
-  auto stage = [&](int kt, int buf) {
+  auto stage = [&](int kt_rel, int buf) {
+    const int kt = kt_begin + kt_rel;
     f16* As = smem + buf * STAGE + (wave * (BM / 4)) * BK;
     f16* Bs = smem + buf * STAGE + A_TILE + (wave * (BN / 4)) * BK;
     if (MODE == TB_A_LINEAR) {
@@ -111,36 +258,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int 
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const f16* src = a_ok[i] ? (second ? a2_ptr[i] : a_ptr[i]) + koff : zero;
-        glds16(src, As + i * 8 * BK);
+        glds16(src, As + i * RPI * BK);
       }
     } else {
       const int tap = kt / kpt;
       const int cc = kt - tap * kpt;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      if (cc == 0 || kt_rel == 0) {  // tap changed (or first tile of this block): recompute the gathered row pointers
+        const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        int sy, sx;
-        bool ok;
-        if (p.upsample) {
-          const int uy = py[i] + ky - 1, ux = px[i] + kx - 1;
-          ok = uy >= 0 && ux >= 0 && uy < 2 * p.Hin && ux < 2 * p.Win;
-          sy = uy >> 1;
-          sx = ux >> 1;
-        } else if (p.transposed) {
-          const int ty = py[i] + 1 - ky, tx = px[i] + 1 - kx;
-          ok = ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
-          sy = ty >> 1;
-          sx = tx >> 1;
-          ok = ok && sy < p.Hin && sx < p.Win;
-        } else {
-          sy = py[i] * p.stride + p.sign * (ky - 1);
-          sx = px[i] * p.stride + p.sign * (kx - 1);
-          ok = sy >= 0 && sx >= 0 && sy < p.Hin && sx < p.Win;
+        for (int i = 0; i < AI; ++i) {
+          int sy, sx;
+          bool ok;
+          if (p.upsample) {
+            const int uy = py[i] + ky - 1, ux = px[i] + kx - 1;
+            ok = uy >= 0 && ux >= 0 && uy < 2 * p.Hin && ux < 2 * p.Win;
+            sy = uy >> 1;
+            sx = ux >> 1;
+          } else if (p.transposed) {
+            const int ty = py[i] + 1 - ky, tx = px[i] + 1 - kx;
+            ok = ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
+            sy = ty >> 1;
+            sx = tx >> 1;
+            ok = ok && sy < p.Hin && sx < p.Win;
+          } else {
+            sy = py[i] * p.stride + p.sign * (ky - 1);
+            sx = px[i] * p.stride + p.sign * (kx - 1);
+            ok = sy >= 0 && sx >= 0 && sy < p.Hin && sx < p.Win;
+          }
+          ok = ok && a_ok[i];
+          // invalid taps read the zero line with a zero per-tile stride
+          a_ptr[i] = ok ? (const f16*)p.A + (pbase[i] + (int64_t)sy * p.Win + sx) * p.lda + a_sw[i] : zero;
+          a_step[i] = ok ? BK : 0;
         }
-        ok = ok && a_ok[i];
-        const f16* src = ok ? (const f16*)p.A + (pbase[i] + (int64_t)sy * p.Win + sx) * p.lda + cc * BK + a_sw[i] : zero;
-        glds16(src, As + i * 8 * BK);
       }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) glds16(a_ptr[i] + (int64_t)cc * a_step[i], As + i * RPI * BK);
     }
     {
       const bool second = kt >= nk1;
@@ -148,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int 
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         const f16* src = w_ok[i] ? (second ? w2_ptr[i] : w_ptr[i]) + koff : zero;
-        glds16(src, Bs + i * 8 * BK);
+        glds16(src, Bs + i * RPI * BK);
       }
     }
   };
@@ -161,16 +313,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int l31 = lane & 31, hi = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const f16* Ab = smem + cur * STAGE + (wm * WTM) * BK;
-    const f16* Bb = smem + cur * STAGE + A_TILE + (wn * WTN) * BK;
+  auto compute = [&](int buf) {
+    const f16* Ab = smem + buf * STAGE + (wm * WTM) * BK;
+    const f16* Bb = smem + buf * STAGE + A_TILE + (wn * WTN) * BK;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       f16x8 af[TM], bf[TN];
@@ -178,12 +324,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = i * 32 + l31;
-        af[i] = *(const f16x8*)(Ab + row * BK + ((ch ^ ((row >> 1) & 7)) << 3));
+        af[i] = *(const f16x8*)(Ab + row * BK + ((ch ^ SWZ(row)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = j * 32 + l31;
-        bf[j] = *(const f16x8*)(Bb + row * BK + ((ch ^ ((row >> 1) & 7)) << 3));
+        bf[j] = *(const f16x8*)(Bb + row * BK + ((ch ^ SWZ(row)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -191,180 +337,202 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tb_gemm_desc p, int 
         for (int j = 0; j < TN; ++j)  // transposed accumulator: rows = n (from W), cols = m (from A)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
+  };
+  if constexpr (NST == 2) {
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
-
-  // ---- epilogue: lane owns row m = .. + l31 and, per register quad r4, columns n = .. + 8*r4 + 4*hi + {0,1,2,3}
-  const float alpha = p.alpha;
-  const bool c_vec = (p.ldc % 4 == 0) && (((uintptr_t)p.C) % 16 == 0);
-  if (p.act == TB_ACT_GEGLU) {
-    if constexpr (TN == 2) {
-      const bool c2_vec = p.C2 && (p.ldc2 % 4 == 0) && (((uintptr_t)p.C2) % 8 == 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int64_t m = m0 + wm * WTM + i * 32 + l31;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int nl = 8 * r4 + 4 * hi;                 // 0..31 inside the 32-wide h (and g) block
-          const int64_t nh = n0 + wn * WTN + nl;          // packed column of h; g is nh + 32
-          const int64_t nout = (n0 + wn * WTN) / 2 + nl;
-          f16x4 oh, og, oo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float vh = alpha * acc[i][0][4 * r4 + e] + (p.bias ? p.bias[nh + e] : 0.f);
-            const float vg = alpha * acc[i][1][4 * r4 + e] + (p.bias ? p.bias[nh + 32 + e] : 0.f);
-            oh[e] = (f16)vh;
-            og[e] = (f16)vg;
-            // gate on the fp16-rounded projections, as a fp16 module would (diffusers GEGLU on fp16 tensors)
-            oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og[e]));
-          }
-          if (p.C2) {
-            f16* c2 = (f16*)p.C2 + m * p.ldc2;
-            if (c2_vec) {
-              *(f16x4*)(c2 + nh) = oh;
-              *(f16x4*)(c2 + nh + 32) = og;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                c2[nh + e] = oh[e];
-                c2[nh + 32 + e] = og[e];
-              }
-            }
-          }
-          f16* c = (f16*)p.C + m * p.ldc + nout;
-          if (c_vec) *(f16x4*)c = oo;
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c[e] = oo[e];
-          }
-        }
-      }
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk && !(abl & 1)) stage(kt + 1, cur ^ 1);
+      if (!(abl & 2)) compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    return;
+  } else {
+    // 3 stages, tiles kt+1 and kt+2 in flight while kt is multiplied.  Each wave issues AI+BI loads per tile, so
+    // "tile kt has landed" == at most (AI+BI) younger loads outstanding: counted vmcnt, raw barrier (cdna guide T3/T4).
+    constexpr int LPT = AI + BI;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);  // (kt+2)%3 == (buf+2)%3; that buffer was last read in iteration kt-1
+      compute(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
   }
-  const bool r_vec = p.R && (p.ldr % 4 == 0) && (((uintptr_t)p.R) % 16 == 0);
-  const bool c2_vec = p.C2 && (p.ldc2 % 4 == 0) && (((uintptr_t)p.C2) % 8 == 0);
+#undef SWZ
+
+  // ---- epilogue, staged through LDS so every global access is a full 16-byte, row-contiguous vector:
+  //  (a) each lane owns row m = .. + l31 and, per register quad r4, 4 consecutive columns: dump raw fp32 accumulators into
+  //      Cs[BM][BN] (16-byte chunks XOR-swizzled by row & 7: conflict-free for these writes and for the row reads below);
+  //  (b) barrier; (c) thread t walks (row, 8-column group) units: bias / residual / activation / stores in 16-byte vectors.
+  if (abl & 4) return;  // profiling: no epilogue
+  float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int64_t m = m0 + wm * WTM + i * 32 + l31;
-    if (m >= p.M) continue;
-    const float* rb = p.rowbias ? p.rowbias + (m / p.rows_per_group) * p.ldrb : nullptr;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int64_t n = n0 + wn * WTN + j * 32 + 8 * r4 + 4 * hi;
-        if (n >= p.N) continue;
-        const bool full = n + 3 < p.N;
-        float v[4];
+        const int row = wm * WTM + i * 32 + l31;
+        const int ch = (wn * WTN + j * 32 + 8 * r4 + 4 * hi) >> 2;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
+        *(f32x4*)(Cs + row * BN + ((ch ^ (row & 7)) << 2)) = o;
+      }
+  __syncthreads();
+  const EpiFlags ef = epi_flags(p);
+  if (p.act == TB_ACT_GEGLU) {
+    // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
+    constexpr int UPR = BN / 16;  // units per row
+    for (int u = t; u < BM * UPR; u += 256) {
+      const int row = u / UPR, og = u - row * UPR;
+      const int64_t m = m0 + row;
+      if (m >= p.M) continue;
+      const int hcol = (og >> 2) * 64 + (og & 3) * 8;  // tile-local packed column of h; g is +32
+      float vh[8], vg[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 a = *(const f32x4*)(Cs + row * BN + ((((hcol >> 2) + q) ^ (row & 7)) << 2));
+        const f32x4 b = *(const f32x4*)(Cs + row * BN + (((((hcol + 32) >> 2) + q) ^ (row & 7)) << 2));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = alpha * acc[i][j][4 * r4 + e];
-          if (full || n + e < p.N) {
-            if (p.bias) v[e] += p.bias[n + e];
-            if (rb) v[e] += rb[n + e];
-          }
+          vh[4 * q + e] = a[e];
+          vg[4 * q + e] = b[e];
         }
-        if (p.R) {
-          if (p.r_dtype == TB_F32) {
-            const float* rp = (const float*)p.R + m * p.ldr + n;
-            if (full && r_vec) {
-              const f32x4 rv = *(const f32x4*)rp;
+      }
+      const int64_t nh = n0 + hcol;
+      f16x8 oh, og8, oo;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += rv[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) v[e] += rp[e];
-            }
-          } else {
-            const f16* rp = (const f16*)p.R + m * p.ldr + n;
-            if (full && r_vec) {
-              const f16x4 rv = *(const f16x4*)rp;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) v[e] += (float)rp[e];
-            }
-          }
-        }
-        if (p.act == TB_ACT_QUICK_GELU) {
-          f16x4 pre;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            pre[e] = (f16)v[e];
-            v[e] = quick_gelu_f((float)pre[e]);  // fp16 linear output feeds the activation, as under autocast
-          }
-          if (p.C2) {
-            f16* c2 = (f16*)p.C2 + m * p.ldc2 + n;
-            if (full && c2_vec) *(f16x4*)c2 = pre;
-            else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) c2[e] = pre[e];
-            }
-          }
-        } else if (p.act == TB_ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-        } else if (p.act == TB_ACT_QUICK_GELU_GRAD) {
-          const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] *= quick_gelu_grad_f((float)c2[e]);
-        }
-        if (p.c_dtype == TB_F32) {
-          float* c = (float*)p.C + m * p.ldc + n;
-          if (full && c_vec) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = v[e];
-            *(f32x4*)c = o;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) c[e] = v[e];
-          }
+      for (int e = 0; e < 8; ++e) {
+        oh[e] = (f16)(p.alpha * vh[e] + (p.bias ? p.bias[nh + e] : 0.f));
+        og8[e] = (f16)(p.alpha * vg[e] + (p.bias ? p.bias[nh + 32 + e] : 0.f));
+        // gate on the fp16-rounded projections, as a fp16 module would (diffusers GEGLU on fp16 tensors)
+        oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));
+      }
+      if (p.C2) {
+        f16* c2 = (f16*)p.C2 + m * p.ldc2 + nh;
+        if (ef.c2_vec) {
+          *(f16x8*)c2 = oh;
+          *(f16x8*)(c2 + 32) = og8;
         } else {
-          f16* c = (f16*)p.C + m * p.ldc + n;
-          if (full && c_vec) {
-            f16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-            *(f16x4*)c = o;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) c[e] = (f16)v[e];
+          for (int e = 0; e < 8; ++e) {
+            c2[e] = oh[e];
+            c2[32 + e] = og8[e];
           }
         }
       }
+      f16* c = (f16*)p.C + m * p.ldc + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
+      if (ef.c_vec) *(f16x8*)c = oo;
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = oo[e];
+      }
+    }
+    return;
+  }
+  constexpr int UPR = BN / 8;  // (row, 8-column) units per row
+  for (int u = t; u < BM * UPR; u += 256) {
+    const int row = u / UPR, cg = u - row * UPR;
+    const int64_t m = m0 + row, n = n0 + cg * 8;
+    if (m >= p.M || n >= p.N) continue;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 a = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
+    }
+    if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
+      float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = v[e];
+        o1[e] = v[4 + e];
+      }
+      *(f32x4*)dst = o0;
+      *(f32x4*)(dst + 4) = o1;
+    } else {
+      epilogue8(p, ef, m, n, v);
+    }
   }
 }
 
-template <int BM, int BN, int MODE>
-int launch(const tb_gemm_desc& d, hipStream_t s) {
+int g_ablate = 0;   // profiling only (tb_gemm_set_variant(2000 + bits)): 1 = skip k-loop loads, 2 = skip k-loop MFMAs
+int g_variant = 0;  // tuning knob (tb_gemm_set_variant): 0 = BK64 x 2 stages, 1 = BK32 x 3 stages, 2 = BK32 x 2 stages
+
+template <int BM, int BN, int MODE, int BKT, int NST>
+int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   const int tiles_m = (int)((d.M + BM - 1) / BM), tiles_n = (int)((d.N + BN - 1) / BN);
-  const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(f16);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds, s, d, tiles_m, tiles_n);
+  const int64_t npad = (d.N + 7) / 8 * 8;
+  size_t lds = (size_t)NST * (BM + BN) * BKT * sizeof(f16);
+  if (lds < (size_t)BM * BN * sizeof(float)) lds = (size_t)BM * BN * sizeof(float);  // epilogue stages the fp32 tile in LDS
+  static bool attr_done = false;
+  if (!attr_done && lds > 65536) {
+    if (hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return TB_ELAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, BKT, NST>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, d, tiles_m,
+                     tiles_n, S, (float*)d.ws, npad, g_ablate);
+  if (S > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
+                       npad);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
+
+template <int BM, int BN, int MODE>
+int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
+  switch (g_variant) {
+    case 1: return launch_v<BM, BN, MODE, 32, 3>(d, s, S);
+    case 2: return launch_v<BM, BN, MODE, 32, 2>(d, s, S);
+    default: return launch_v<BM, BN, MODE, 64, 2>(d, s, S);
+  }
+}
+
+int g_split_target = 512;  // aim for at least this many blocks (2 per CU) before splitting K  (tb_gemm_set_variant(1000 + n))
 
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
   // N that is an odd multiple of 64 (320, 960, ...) tiles exactly with BN = 64
   const bool narrow = (d.N % 128) != 0 && (d.N % 128) <= 64;
-  const int64_t blocks128 = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
-  if (blocks128 < 192) return launch<64, 64, MODE>(d, s);  // small problems: more, smaller tiles to fill 256 CUs
-  return narrow ? launch<128, 64, MODE>(d, s) : launch<128, 128, MODE>(d, s);
+  const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
+  int S = 1;
+  if (blocks < 384 && d.ws && g_split_target > 0) {
+    // too few tiles to fill 256 CUs: split K across blocks (fp32 partials in ws, fixed-order reduction -> deterministic)
+    const int64_t nk = d.K / 64;
+    const int64_t npad = (d.N + 7) / 8 * 8;
+    int64_t want = blocks < 192 && nk >= 32 ? (g_split_target + blocks - 1) / blocks : 1;  // short K: a second pass costs more
+    if (want > nk / 8) want = nk / 8;  // keep >= 8 k-tiles per slice
+    if (want > 16) want = 16;
+    const int64_t fit = d.ws_bytes / (int64_t)(d.M * npad * sizeof(float));
+    if (want > fit) want = fit;
+    if (want > 1) S = (int)want;
+  }
+  if (S == 1 && blocks < 192) return launch<64, 64, MODE>(d, s);  // small problems without workspace: smaller tiles
+  return narrow ? launch<128, 64, MODE>(d, s, S) : launch<128, 128, MODE>(d, s, S);
 }
 
 }  // namespace
+
+extern "C" int tb_gemm_set_variant(int v) {
+  const int old = g_variant;
+  if (v >= 2000) g_ablate = v - 2000;
+  else if (v >= 1000) g_split_target = v - 1000;  // 1000 disables split-K, 1512 = default target of 512 blocks
+  else g_variant = v;
+  return old;
+}
 
 extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
@@ -382,7 +550,6 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if (d.rowbias && d.ldrb < d.N) d.ldrb = d.N;
   if (d.act == TB_ACT_QUICK_GELU_GRAD && !d.C2) return TB_EINVAL;
   if (d.act < 0 || d.act > TB_ACT_QUICK_GELU_GRAD) return TB_EINVAL;
-  if (d.split_k > 1) return TB_EINVAL;
   if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;
     if (d.M != (int64_t)d.B * d.Hout * d.Wout) return TB_EINVAL;
@@ -393,7 +560,7 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   }
   if (d.act == TB_ACT_GEGLU) {
     if (d.N % 128 || d.R || d.rowbias || d.c_dtype != TB_F16) return TB_EINVAL;
-    return d.a_mode == TB_A_LINEAR ? launch<128, 128, TB_A_LINEAR>(d, s) : TB_EINVAL;
+    return d.a_mode == TB_A_LINEAR ? launch<128, 128, TB_A_LINEAR>(d, s, 1) : TB_EINVAL;
   }
   return d.a_mode == TB_A_LINEAR ? dispatch_tile<TB_A_LINEAR>(d, s) : dispatch_tile<TB_A_CONV3X3>(d, s);
 }

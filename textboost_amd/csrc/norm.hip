@@ -102,6 +102,50 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
   gn_block_group_reduce(mp, s, q, C, G, lds, part + ((int64_t)b * nchunks + chunk) * G * 2);
 }
 
+// per-(b, group) totals of the chunk partials, 8 lanes per group + LDS tree (fixed order -> deterministic).
+// mode 0 (forward): out = (mean, rstd);  mode 1 (backward): out = (sum1 / n, sum2 / n)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int HW, int C, int G,
+                                                          int nchunks, float eps, int mode) {
+  __shared__ float ls[8][64], lq[8][64];
+  const int b = blockIdx.x;
+  const int g = threadIdx.x & 31, sub = threadIdx.x >> 5;  // G <= 32 handled per pass
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int gg = g0 + g;
+    float s = 0.f, q = 0.f;
+    if (gg < G)
+      for (int c = sub; c < nchunks; c += 8) {
+        const float* p = part + ((int64_t)b * nchunks + c) * G * 2 + gg * 2;
+        s += p[0];
+        q += p[1];
+      }
+    ls[sub][g] = s;
+    lq[sub][g] = q;
+    __syncthreads();
+    if (sub == 0 && gg < G) {
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        S += ls[k][g];
+        Q += lq[k][g];
+      }
+      const float n = (float)(C / G) * (float)HW;
+      float o0, o1;
+      if (mode == 0) {
+        const float mean = S / n;
+        const float var = fmaxf(Q / n - mean * mean, 0.f);
+        o0 = mean;
+        o1 = rsqrtf(var + eps);
+      } else {
+        o0 = S / n;
+        o1 = Q / n;
+      }
+      out[((int64_t)b * G + gg) * 2 + 0] = o0;
+      out[((int64_t)b * G + gg) * 2 + 1] = o1;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ part, float* __restrict__ stats, int HW, int C,
@@ -111,23 +155,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ X
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int gs = C / G;
   if (threadIdx.x < G) {
-    const int g = threadIdx.x;
-    float s = 0.f, q = 0.f;
-    for (int c = 0; c < nchunks; ++c) {
-      const float* p = part + ((int64_t)b * nchunks + c) * G * 2 + g * 2;
-      s += p[0];
-      q += p[1];
-    }
-    const float n = (float)gs * (float)HW;
-    const float mean = s / n;
-    const float var = fmaxf(q / n - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    mean_s[g] = mean;
-    rstd_s[g] = rstd;
-    if (chunk == 0) {
-      stats[((int64_t)b * G + g) * 2 + 0] = mean;
-      stats[((int64_t)b * G + g) * 2 + 1] = rstd;
-    }
+    mean_s[threadIdx.x] = stats[((int64_t)b * G + threadIdx.x) * 2 + 0];
+    rstd_s[threadIdx.x] = stats[((int64_t)b * G + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
   if (!mp.active) return;
@@ -221,17 +250,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict
   const GnMap mp(C);
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int gs = C / G;
-  if (threadIdx.x < G) {
-    const int g = threadIdx.x;
-    float s = 0.f, q = 0.f;
-    for (int c = 0; c < nchunks; ++c) {
-      const float* p = part + ((int64_t)b * nchunks + c) * G * 2 + g * 2;
-      s += p[0];
-      q += p[1];
-    }
-    const float n = (float)gs * (float)HW;
-    s1_s[g] = s / n;
-    s2_s[g] = q / n;
+  if (threadIdx.x < G) {  // part = finalized per-(b, group) means of dyh and dyh*xhat
+    s1_s[threadIdx.x] = part[((int64_t)b * G + threadIdx.x) * 2 + 0];
+    s2_s[threadIdx.x] = part[((int64_t)b * G + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
   if (!mp.active) return;
@@ -418,7 +439,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dY,
 
 }  // namespace
 
-extern "C" int64_t tb_groupnorm_ws_floats(int B, int HW, int C, int G) { return (int64_t)B * gn_chunks(B, HW, C) * G * 2; }
+extern "C" int64_t tb_groupnorm_ws_floats(int B, int HW, int C, int G) {
+  return (int64_t)B * gn_chunks(B, HW, C) * G * 2 + (int64_t)B * G * 2;
+}
 
 extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                                 float* stats, float* ws, int B, int HW, int C, int G, float eps, int silu, tb_stream_t stream) {
@@ -428,6 +451,7 @@ extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, ws, HW, C, G, nch);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, stats, HW, C, G, nch, eps, 0);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, ws, stats, HW, C,
                      G, nch, eps, silu);
   TB_CHECK_LAUNCH();
@@ -444,8 +468,10 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
                      ws, HW, C, G, nch, silu);
+  float* fin = ws + (int64_t)B * nch * G * 2;  // finalized sums live behind the partials
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, fin, HW, C, G, nch, 0.f, 1);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
-                     ws, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, nch, silu);
+                     fin, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, nch, silu);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -44,6 +44,17 @@ class _rec:
             _REC.append((self.name, self.flops, self.bytes, self.e0, self.e1))
 
 
+_gemm_ws = {}
+GEMM_WS_BYTES = 128 << 20  # split-K partials (fp32); allocated once per device, before any graph capture
+
+
+def _gemm_workspace(dev):
+    ws = _gemm_ws.get(dev)
+    if ws is None:
+        ws = _gemm_ws[dev] = torch.empty(GEMM_WS_BYTES // 4, device=dev, dtype=torch.float32)
+    return ws
+
+
 def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_per_group=0, R=None, act=L.ACT_NONE,
          alpha=1.0, C2=None, conv=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
@@ -81,6 +92,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
     d.C, d.ldc, d.c_dtype = L.ptr(out), out.stride(0), _dt(out)
     if C2 is not None:
         d.C2, d.ldc2 = L.ptr(C2), C2.stride(0)
+    ws = _gemm_workspace(out.device)
+    d.ws, d.ws_bytes = L.ptr(ws), ws.numel() * 4
     if _REC is not None:
         narrow = (N % 128) != 0 and (N % 128) <= 64 and act != L.ACT_GEGLU
         name = f"gemm_kernel<128,{64 if narrow else 128},{'CONV3X3' if conv is not None else 'LINEAR'}>"

@@ -87,7 +87,7 @@ class HipUNet:
         self.tape: List = []
         self._pack(state_dict)
         # tb_groupnorm_ws_floats = B * chunks * G * 2 with B * chunks <= 2048 (+B when chunks clamps to 1)
-        self.gn_ws = torch.empty((2048 + batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
+        self.gn_ws = torch.empty((2048 + 2 * batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name, rows, cols, dtype=torch.float16):
