@@ -22,6 +22,8 @@ constexpr int KVT = 64;      // keys (or queries, in the dK/dV kernel) per LDS t
 constexpr int TLD = KVT + 4; // row stride (halfs) of transposed tiles: 136 B -> conflict-free ds_read_b64 across d
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1e30f;
+// single v_exp_f32 (no denormal-range fixup: softmax probabilities below 2^-126 may flush to 0)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int WD>
 struct RM {  // row-major [64][WD] tile, rows padded by 16 B
@@ -33,19 +35,54 @@ struct TR {  // transposed [WD][64] tile
   static constexpr int SIZE = WD * TLD;
 };
 
-// Stage rows [row0, row0+64) x cols [0, WD) of a (rows x hd) matrix (row stride ld) into LDS; zero outside.
+// Staging of rows [row0, row0+64) x cols [0, WD) of a (rows x hd) matrix (row stride ld) into LDS, zero outside, split in
+// two halves so the global loads of tile t+1 are in flight while tile t is multiplied (cdna guide T14):
+//   tile_load : global -> registers.  One work item = 4 consecutive rows x one 16-byte column chunk.
+//   tile_store: registers -> LDS, row-major (4 x ds_write_b128) and/or transposed (8 x ds_write_b64: for each of the 8
+//               columns the 4 consecutive rows are adjacent in the [WD][64] transposed image).
+template <int WD>
+struct TileRegs {
+  static constexpr int CPR = WD / 8;                  // 16-byte chunks per row
+  static constexpr int ITEMS = (KVT / 4) * CPR;       // work items per tile
+  static constexpr int NI = (ITEMS + 255) / 256;      // items per thread
+  f16x8 v[NI][4];
+};
+template <int WD>
+__device__ __forceinline__ void tile_load(TileRegs<WD>& t, const f16* g, int64_t ld, int row0, int nrows, int hd) {
+  constexpr int CPR = TileRegs<WD>::CPR;
+#pragma unroll
+  for (int it = 0; it < TileRegs<WD>::NI; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int kg = idx / CPR, ch = idx - kg * CPR;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = row0 + kg * 4 + k;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (idx < TileRegs<WD>::ITEMS && row < nrows && ch * 8 < hd) v = *(const f16x8*)(g + (int64_t)row * ld + ch * 8);
+      t.v[it][k] = v;
+    }
+  }
+}
 template <int WD, bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void stage_tile(f16* rm, f16* tr, const f16* g, int64_t ld, int row0, int nrows, int hd) {
-  constexpr int CPR = WD / 8;
-  for (int idx = threadIdx.x; idx < KVT * CPR; idx += 256) {
-    const int r = idx / CPR, ch = idx - r * CPR;
-    const int row = row0 + r;
-    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < nrows && ch * 8 < hd) v = *(const f16x8*)(g + (int64_t)row * ld + ch * 8);
-    if (ROWMAJOR) *(f16x8*)(rm + r * RM<WD>::LD + ch * 8) = v;
+__device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* tr) {
+  constexpr int CPR = TileRegs<WD>::CPR;
+#pragma unroll
+  for (int it = 0; it < TileRegs<WD>::NI; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    if (idx >= TileRegs<WD>::ITEMS) continue;
+    const int kg = idx / CPR, ch = idx - kg * CPR;
+    if (ROWMAJOR) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *(f16x8*)(rm + (kg * 4 + k) * RM<WD>::LD + ch * 8) = t.v[it][k];
+    }
     if (TRANSPOSED) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) tr[(ch * 8 + i) * TLD + r] = v[i];
+      for (int i = 0; i < 8; ++i) {
+        f16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = t.v[it][k][i];
+        *(f16x4*)(tr + (ch * 8 + i) * TLD + kg * 4) = o;
+      }
     }
   }
 }
@@ -110,11 +147,25 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_f
   const float c = p.scale * LOG2E;
   int kv_end = p.Skv;
   if (p.causal) kv_end = min(p.Skv, qblk + 128);  // keys beyond the block's last query are never visible
+  constexpr bool PF = DT <= 3;  // register prefetch of the next tile (skipped for wide heads: the registers are needed for O)
+  TileRegs<WD> kreg, vreg;
+  if (PF) {
+    tile_load<WD>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+  }
   for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
     __syncthreads();
-    stage_tile<WD, true, false>(Ks, nullptr, Kg, p.ldk, kv0, p.Skv, p.hd);
-    stage_tile<WD, false, true>(nullptr, Vt, Vg, p.ldv, kv0, p.Skv, p.hd);
+    if (!PF) {
+      tile_load<WD>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
+      tile_load<WD>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
+    }
+    tile_store<WD, true, false>(kreg, Ks, nullptr);
+    tile_store<WD, false, true>(vreg, nullptr, Vt);
     __syncthreads();
+    if (PF && kv0 + KVT < kv_end) {  // next tile's loads fly under this tile's MFMAs
+      tile_load<WD>(kreg, Kg, p.ldk, kv0 + KVT, p.Skv, p.hd);
+      tile_load<WD>(vreg, Vg, p.ldv, kv0 + KVT, p.Skv, p.hd);
+    }
     f32x16 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -123,30 +174,39 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_f
       for (int j = 0; j < KS; ++j)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s[kt], 0, 0, 0);
     }
-    float mx = NEG_BIG;
+    // masking is needed only on the ragged last tile / the causal diagonal: wave-uniform test keeps it off the common path
+    const bool need_mask = (kv0 + KVT > p.Skv) || (p.causal && kv0 + KVT - 1 > qblk + wave * 32);
+    if (need_mask) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kt * 32 + mfma32_row(r, hi);
+          const bool ok = key < p.Skv && (!p.causal || key <= q);
+          s[kt][r] = ok ? s[kt][r] : -INFINITY;
+        }
+    }
+    float mx = NEG_BIG;  // running max in the log2 domain: max(s) * c  (c > 0)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kt * 32 + mfma32_row(r, hi);
-        const bool ok = key < p.Skv && (!p.causal || key <= q);
-        s[kt][r] = ok ? s[kt][r] * c : -INFINITY;
-        mx = fmaxf(mx, s[kt][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
     const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
+    if (__any(m_new > m)) {  // rescale only when some row's max moved (rare after the first tiles)
+      const float alpha = fast_exp2(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
     m = m_new;
-    l *= alpha;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[kt][r] - m_new);
+        const float pv = fast_exp2(fmaf(s[kt][r], c, -m_new));
         s[kt][r] = pv;
         l += pv;
       }
@@ -228,11 +288,25 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dq_kernel(con
   for (int d = 0; d < DT; ++d) ZERO16(dq[d]);
   int kv_end = p.Skv;
   if (p.causal) kv_end = min(p.Skv, qblk + 128);
+  constexpr bool PF = DT <= 2;
+  TileRegs<WD> kreg, vreg;
+  if (PF) {
+    tile_load<WD>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+  }
   for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
     __syncthreads();
-    stage_tile<WD, true, true>(Ks, Kt, Kg, p.ldk, kv0, p.Skv, p.hd);
-    stage_tile<WD, true, false>(Vs, nullptr, Vg, p.ldv, kv0, p.Skv, p.hd);
+    if (!PF) {
+      tile_load<WD>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
+      tile_load<WD>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
+    }
+    tile_store<WD, true, true>(kreg, Ks, Kt);
+    tile_store<WD, true, false>(vreg, Vs, nullptr);
     __syncthreads();
+    if (PF && kv0 + KVT < kv_end) {
+      tile_load<WD>(kreg, Kg, p.ldk, kv0 + KVT, p.Skv, p.hd);
+      tile_load<WD>(vreg, Vg, p.ldv, kv0 + KVT, p.Skv, p.hd);
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16 s, dp;
@@ -243,12 +317,18 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dq_kernel(con
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Vs, kt * 32 + l31, 2 * j + hi), dof[j], dp, 0, 0, 0);
       }
+      const bool need_mask = (kv0 + kt * 32 + 32 > p.Skv) || (p.causal && kv0 + kt * 32 + 31 > qblk + wave * 32) || (qblk + wave * 32 + 32 > p.Sq);
+      if (need_mask) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kt * 32 + mfma32_row(r, hi);
-        const bool ok = qok && key < p.Skv && (!p.causal || key <= q);
-        const float pv = ok ? exp2f(s[r] * c - lse2) : 0.f;
-        s[r] = pv * (dp[r] - delta) * p.scale;  // dS^T
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kt * 32 + mfma32_row(r, hi);
+          const bool ok = qok && key < p.Skv && (!p.causal || key <= q);
+          const float pv = ok ? fast_exp2(fmaf(s[r], c, -lse2)) : 0.f;
+          s[r] = pv * p.scale * (dp[r] - delta);  // dS^T
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c, -lse2)) * p.scale * (dp[r] - delta);
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -315,16 +395,30 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   int q_begin = qslice * q_chunk;
   const int q_end = min(p.Sq, q_begin + q_chunk);
   if (p.causal) q_begin = max(q_begin, (kblk / KVT) * KVT);  // queries before the block's first key see none of its keys
+  constexpr bool PF = DT <= 2;
+  TileRegs<WD> qreg, doreg;
+  if (PF && q_begin < q_end) {
+    tile_load<WD>(qreg, Qg, p.ldq, q_begin, p.Sq, p.hd);
+    tile_load<WD>(doreg, dOg, p.lddo, q_begin, p.Sq, p.hd);
+  }
   for (int q0 = q_begin; q0 < q_end; q0 += KVT) {
     __syncthreads();
-    stage_tile<WD, true, true>(Qs, Qt, Qg, p.ldq, q0, p.Sq, p.hd);
-    stage_tile<WD, true, true>(dOs, dOt, dOg, p.lddo, q0, p.Sq, p.hd);
+    if (!PF) {
+      tile_load<WD>(qreg, Qg, p.ldq, q0, p.Sq, p.hd);
+      tile_load<WD>(doreg, dOg, p.lddo, q0, p.Sq, p.hd);
+    }
+    tile_store<WD, true, true>(qreg, Qs, Qt);
+    tile_store<WD, true, true>(doreg, dOs, dOt);
     if (threadIdx.x < KVT) {
       const int qq = q0 + threadIdx.x;
       lse_s[threadIdx.x] = qq < p.Sq ? LSEg[qq] * LOG2E : 0.f;
       del_s[threadIdx.x] = qq < p.Sq ? DELg[qq] : 0.f;
     }
     __syncthreads();
+    if (PF && q0 + KVT < q_end) {
+      tile_load<WD>(qreg, Qg, p.ldq, q0 + KVT, p.Sq, p.hd);
+      tile_load<WD>(doreg, dOg, p.lddo, q0 + KVT, p.Sq, p.hd);
+    }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       f32x16 s, dp;
@@ -335,14 +429,30 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Qs, qt * 32 + l31, 2 * j + hi), kf[j], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(dOs, qt * 32 + l31, 2 * j + hi), vf[j], dp, 0, 0, 0);
       }
+      // per-row lse / delta: rows of register quad g are 8g + 4hi + {0..3} -> one 16-byte LDS read per quad
+      f32x4 lq[4], dq4[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = qt * 32 + mfma32_row(r, hi);
-        const int qq = q0 + ql;
-        const bool ok = kok && qq < p.Sq && (!p.causal || key <= qq);
-        const float pv = ok ? exp2f(s[r] * c - lse_s[ql]) : 0.f;
-        s[r] = pv;                                          // P
-        dp[r] = pv * (dp[r] - del_s[ql]) * p.scale;         // dS
+      for (int g4 = 0; g4 < 4; ++g4) {
+        lq[g4] = *(const f32x4*)(lse_s + qt * 32 + 8 * g4 + 4 * hi);
+        dq4[g4] = *(const f32x4*)(del_s + qt * 32 + 8 * g4 + 4 * hi);
+      }
+      const bool need_mask = (q0 + qt * 32 + 32 > p.Sq) || (kblk + wave * 32 + 32 > p.Skv) || (p.causal && kblk + wave * 32 + 31 > q0 + qt * 32);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = q0 + qt * 32 + mfma32_row(r, hi);
+          const bool ok = kok && qq < p.Sq && (!p.causal || key <= qq);
+          const float pv = ok ? fast_exp2(fmaf(s[r], c, -lq[r >> 2][r & 3])) : 0.f;
+          s[r] = pv;                                                   // P
+          dp[r] = pv * p.scale * (dp[r] - dq4[r >> 2][r & 3]);         // dS
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(fmaf(s[r], c, -lq[r >> 2][r & 3]));
+          s[r] = pv;
+          dp[r] = pv * p.scale * (dp[r] - dq4[r >> 2][r & 3]);
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
