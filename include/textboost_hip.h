@@ -66,6 +66,8 @@ typedef struct tb_gemm_desc {
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
 /* tuning knob for the k-tile / pipeline-depth variant of tb_gemm (returns the previous value); 0 is the default */
 int tb_gemm_set_variant(int v);
+/* {BM, BN, a_mode, k_tile*10 + stages, split_k} of the most recent tb_gemm launch (profiling aid) */
+void tb_gemm_last_config(int* out5);
 
 /* text of the HIP error behind the most recent -5 (launch failure) return; diagnostics only */
 const char* tb_last_hip_error(void);

@@ -97,3 +97,34 @@ def make_wrapper():
 if __name__ == "__main__":
     make_clip()
     make_wrapper()
+
+
+def make_cli_flags():
+    """Interface facts of the reference CLI (train_textboost.py:49-450): flag names, types, defaults, actions, nargs, choices,
+    required -- extracted from the argparse calls by AST (the file itself cannot be imported: diffusers/peft are absent)."""
+    import ast
+    import json
+    src = open(os.path.join(REF, "train_textboost.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "parse_args"][0]
+    flags = []
+    for node in ast.walk(fn):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument":
+            names = [a.value for a in node.args if isinstance(a, ast.Constant)]
+            spec = {"flags": names}
+            for kw in node.keywords:
+                if kw.arg == "help":
+                    continue
+                if kw.arg == "type":
+                    spec["type"] = kw.value.id
+                else:
+                    spec[kw.arg] = ast.literal_eval(kw.value)
+            flags.append(spec)
+    flags.sort(key=lambda s: s["flags"][0])
+    with open(os.path.join(OUT, "cli_flags.json"), "w") as f:
+        json.dump(flags, f, indent=1, sort_keys=True)
+    print("cli golden:", len(flags), "flags")
+
+
+if __name__ == "__main__":
+    make_cli_flags()

@@ -205,3 +205,33 @@ def test_graph_replay_equals_eager():
         outs.append((step.te.lora_A.clone(), step.te.lora_B.clone(), step.te.token_table[49408:].clone(), step.state.clone()))
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_cli_end_to_end_writes_reference_layout(tmp_path):
+    """train_textboost.py with the reference's flags on synthetic latents: 6 steps, a checkpoint, the final adapter + token files."""
+    import json
+    import os
+    import sys
+    from safetensors.torch import load_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+    out = str(tmp_path / "run")
+    args = T.parse_args(["--pretrained_model_name_or_path", "/nonexistent/sd15", "--output_dir", out, "--train_batch_size", "2",
+                         "--resolution", "128", "--max_train_steps", "6", "--checkpointing_steps", "4", "--placeholder_token", "<dog>",
+                         "--augment_inversion", "--lora_rank", "4", "--mixed_precision", "fp16", "--learning_rate", "5e-5",
+                         "--emb_learning_rate", "1e-3", "--seed", "42"])
+    T.main(args)
+    assert os.path.exists(os.path.join(out, "training.log"))
+    files = set(os.listdir(out))
+    assert {"text_encoder", "dog.bin", "checkpoint-4", "grayscale_0.bin", "right_2.bin", "crop.bin"} <= files
+    assert len([f for f in files if f.endswith(".bin")]) == 17           # 1 placeholder + 16 augmentation vectors
+    sd = load_file(os.path.join(out, "text_encoder", "adapter_model.safetensors"))
+    assert len(sd) == 72 and sd["base_model.model.text_model.encoder.layers.11.self_attn.v_proj.lora_B.weight"].shape == (768, 4)
+    assert any(v.abs().max() > 0 for k, v in sd.items() if "lora_B" in k)   # B left zero-init only if nothing trained
+    ck = set(os.listdir(os.path.join(out, "checkpoint-4")))
+    assert {"text_encoder", "model.safetensors", "optimizer.bin", "scheduler.bin", "scaler.pt", "random_states_0.pkl", "dog.bin"} <= ck
+    cfg = json.load(open(os.path.join(out, "text_encoder", "adapter_config.json")))
+    assert cfg["base_model_name_or_path"] == "/nonexistent/sd15"
+    d = torch.load(os.path.join(out, "dog.bin"))
+    assert d["<dog>"].shape == (768,) and torch.isfinite(d["<dog>"]).all()

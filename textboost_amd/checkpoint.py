@@ -1,0 +1,112 @@
+"""Output / checkpoint layout of the reference (train_textboost.py:1157-1209, :1236-1266), so that inference.py:55-68 and
+eval_dreambooth.py:193-206 / :329-337 read the results unchanged:
+
+  <out>/text_encoder/adapter_config.json + adapter_model.safetensors     PEFT LoRA adapter, fp32, keys
+        base_model.model.text_model.encoder.layers.{i}.self_attn.{q,k,v}_proj.lora_{A,B}.weight
+  <out>/{tok}.bin                                                        torch.save({"<tok>": tensor}); placeholder tokens save a
+        1-D [D] row (:1189-1193), augmentation tokens a 2-D [1, D] slice (:1201-1205); '<' '>' stripped from the FILE name only
+  <out>/checkpoint-{step}/ (same two things) + trainer state: model.safetensors, optimizer.bin, scheduler.bin, scaler.pt,
+        random_states_0.pkl (the file names accelerate.save_state uses; the readers skip optimizer.bin / scheduler.bin)
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+import shutil
+from typing import Dict
+
+import torch
+from safetensors.torch import load_file, save_file
+
+
+def lora_state_dict(te) -> Dict[str, torch.Tensor]:
+    """flat [L,3r,D] / [L,3D,r] masters -> PEFT key layout (adapter name stripped on save, like peft does)."""
+    sd = {}
+    D, r = te.geo.hidden_size, te.r
+    for i in range(te.geo.num_layers):
+        for p, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            base = f"base_model.model.text_model.encoder.layers.{i}.self_attn.{name}"
+            sd[base + ".lora_A.weight"] = te.lora_A[i, p * r:(p + 1) * r].detach().float().cpu().contiguous()
+            sd[base + ".lora_B.weight"] = te.lora_B[i, p * D:(p + 1) * D].detach().float().cpu().contiguous()
+    return sd
+
+
+def load_lora_state_dict(te, sd):
+    D, r = te.geo.hidden_size, te.r
+    for i in range(te.geo.num_layers):
+        for p, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            base = f"base_model.model.text_model.encoder.layers.{i}.self_attn.{name}"
+            te.lora_A[i, p * r:(p + 1) * r].copy_(sd[base + ".lora_A.weight"])
+            te.lora_B[i, p * D:(p + 1) * D].copy_(sd[base + ".lora_B.weight"])
+
+
+def adapter_config(rank: int, base_model_name_or_path: str) -> dict:
+    """peft 0.13.2 LoraConfig JSON for LoraConfig(r, lora_alpha=r, init_lora_weights="gaussian", target q/k/v) (:702-709)."""
+    return {"alpha_pattern": {}, "auto_mapping": None, "base_model_name_or_path": base_model_name_or_path, "bias": "none",
+            "fan_in_fan_out": False, "inference_mode": True, "init_lora_weights": "gaussian", "layer_replication": None,
+            "layers_pattern": None, "layers_to_transform": None, "loftq_config": {}, "lora_alpha": rank, "lora_dropout": 0.0,
+            "megatron_config": None, "megatron_core": "megatron.core", "modules_to_save": None, "peft_type": "LORA", "r": rank,
+            "rank_pattern": {}, "revision": None, "target_modules": ["q_proj", "k_proj", "v_proj"], "task_type": None,
+            "use_dora": False, "use_rslora": False}
+
+
+def save_text_encoder_adapter(te, out_dir: str, base_model_name_or_path: str):
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "adapter_config.json"), "w") as f:
+        json.dump(adapter_config(te.r, base_model_name_or_path), f, indent=2, sort_keys=True)
+    save_file(lora_state_dict(te), os.path.join(out_dir, "adapter_model.safetensors"), metadata={"format": "pt"})
+
+
+def save_token_embeddings(te, out_dir: str, added_tokens: Dict[str, int], aug_token_dict: Dict[str, int] | None):
+    os.makedirs(out_dir, exist_ok=True)
+    W = te.token_table.detach().float().cpu()
+    for token, tid in added_tokens.items():
+        torch.save({token: W[tid].clone()}, os.path.join(out_dir, token.replace("<", "").replace(">", "") + ".bin"))   # 1-D [D]
+    for token, tid in (aug_token_dict or {}).items():
+        torch.save({token: W[tid:tid + 1].clone()}, os.path.join(out_dir, token.replace("<", "").replace(">", "") + ".bin"))  # [1, D]
+
+
+def rotate_checkpoints(output_dir: str, total_limit):
+    """:1159-1175"""
+    if total_limit is None:
+        return
+    cks = sorted([d for d in os.listdir(output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
+    if len(cks) >= total_limit:
+        for d in cks[: len(cks) - total_limit + 1]:
+            shutil.rmtree(os.path.join(output_dir, d))
+
+
+def save_trainer_state(step_obj, ckpt_dir: str):
+    te = step_obj.te
+    os.makedirs(ckpt_dir, exist_ok=True)
+    model = dict(lora_state_dict(te))
+    model["token_embedding.added_rows"] = te.token_table[te.first_added:].detach().float().cpu().contiguous()
+    save_file(model, os.path.join(ckpt_dir, "model.safetensors"))
+    torch.save({"m_lora": step_obj.m_lora.cpu(), "v_lora": step_obj.v_lora.cpu(), "m_emb": step_obj.m_emb.cpu(),
+                "v_emb": step_obj.v_emb.cpu(), "state": step_obj.state.cpu(),
+                "orig_rows_decay_steps": float(step_obj.state[2].item())}, os.path.join(ckpt_dir, "optimizer.bin"))
+    torch.save({"last_epoch": float(step_obj.state[2].item()), "type": "constant"}, os.path.join(ckpt_dir, "scheduler.bin"))
+    torch.save({"scale": float(step_obj.state[0].item()), "growth_tracker": float(step_obj.state[1].item()), "growth_factor": 2.0,
+                "backoff_factor": 0.5, "growth_interval": step_obj.hp.growth_interval}, os.path.join(ckpt_dir, "scaler.pt"))
+    with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "wb") as f:
+        pickle.dump({"torch_manual_seed": torch.get_rng_state(),
+                     "torch_cuda_manual_seed": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []}, f)
+
+
+def load_trainer_state(step_obj, ckpt_dir: str):
+    te = step_obj.te
+    model = load_file(os.path.join(ckpt_dir, "model.safetensors"))
+    load_lora_state_dict(te, model)
+    te.token_table[te.first_added:].copy_(model["token_embedding.added_rows"])
+    opt = torch.load(os.path.join(ckpt_dir, "optimizer.bin"))
+    for k in ("m_lora", "v_lora", "m_emb", "v_emb", "state"):
+        getattr(step_obj, k).copy_(opt[k])
+    # rows below first_added only ever see the decoupled decay: re-apply it for the steps already taken
+    n = opt["orig_rows_decay_steps"]
+    te.token_table[: te.first_added].mul_((1.0 - step_obj.hp.emb_lr * step_obj.hp.wd) ** n)
+    with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "rb") as f:
+        rs = pickle.load(f)
+    torch.set_rng_state(rs["torch_manual_seed"])
+    if rs["torch_cuda_manual_seed"]:
+        torch.cuda.set_rng_state_all(rs["torch_cuda_manual_seed"])

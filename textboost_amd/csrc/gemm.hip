@@ -350,21 +350,27 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
       __syncthreads();
     }
   } else {
-    // 3 stages, tiles kt+1 and kt+2 in flight while kt is multiplied.  Each wave issues AI+BI loads per tile, so
-    // "tile kt has landed" == at most (AI+BI) younger loads outstanding: counted vmcnt, raw barrier (cdna guide T3/T4).
+    // NST stages: tiles kt+1 .. kt+NST-2 stay in flight while tile kt is multiplied.  Each wave issues AI+BI loads per tile,
+    // so "tile kt has landed" == at most (tiles still in flight) * (AI+BI) younger loads outstanding: counted vmcnt + raw
+    // barrier (cdna guide T3/T4) -- a plain __syncthreads() would drain the queue.
     constexpr int LPT = AI + BI;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < nk) stage(i, i);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      const int ahead = min(nk - kt - 1, NST - 2);  // tiles issued after kt that may still be in flight
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + 2 < nk) stage(kt + 2, buf == 0 ? 2 : buf - 1);  // (kt+2)%3 == (buf+2)%3; that buffer was last read in iteration kt-1
-      compute(buf);
-      buf = buf == 2 ? 0 : buf + 1;
+      // buffer (kt-1) % NST was last read in iteration kt-1, which every wave has left (barrier above)
+      if (kt + NST - 1 < nk && !(abl & 1)) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+      if (!(abl & 2)) compute(buf);
+      buf = buf == NST - 1 ? 0 : buf + 1;
     }
+    __syncthreads();  // all waves done with the operand tiles before the epilogue reuses the LDS
   }
 #undef SWZ
 
@@ -467,12 +473,14 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
   }
 }
 
+int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
 int g_ablate = 0;   // profiling only (tb_gemm_set_variant(2000 + bits)): 1 = skip k-loop loads, 2 = skip k-loop MFMAs
 int g_variant = 0;  // tuning knob (tb_gemm_set_variant): 0 = BK64 x 2 stages, 1 = BK32 x 3 stages, 2 = BK32 x 2 stages
 
 template <int BM, int BN, int MODE, int BKT, int NST>
 int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   const int tiles_m = (int)((d.M + BM - 1) / BM), tiles_n = (int)((d.N + BN - 1) / BN);
+  g_last_cfg[0] = BM, g_last_cfg[1] = BN, g_last_cfg[2] = MODE, g_last_cfg[3] = BKT * 10 + NST, g_last_cfg[4] = S;
   const int64_t npad = (d.N + 7) / 8 * 8;
   size_t lds = (size_t)NST * (BM + BN) * BKT * sizeof(f16);
   if (lds < (size_t)BM * BN * sizeof(float)) lds = (size_t)BM * BN * sizeof(float);  // epilogue stages the fp32 tile in LDS
@@ -497,6 +505,8 @@ int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
   switch (g_variant) {
     case 1: return launch_v<BM, BN, MODE, 32, 3>(d, s, S);
     case 2: return launch_v<BM, BN, MODE, 32, 2>(d, s, S);
+    case 3: return launch_v<BM, BN, MODE, 32, 4>(d, s, S);
+    case 4: return launch_v<BM, BN, MODE, 64, 3>(d, s, S);
     default: return launch_v<BM, BN, MODE, 64, 2>(d, s, S);
   }
 }
@@ -525,6 +535,10 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" void tb_gemm_last_config(int* out5) {
+  for (int i = 0; i < 5; ++i) out5[i] = g_last_cfg[i];
+}
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;

@@ -94,13 +94,13 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
         d.C2, d.ldc2 = L.ptr(C2), C2.stride(0)
     ws = _gemm_workspace(out.device)
     d.ws, d.ws_bytes = L.ptr(ws), ws.numel() * 4
-    if _REC is not None:
-        narrow = (N % 128) != 0 and (N % 128) <= 64 and act != L.ACT_GEGLU
-        name = f"gemm_kernel<128,{64 if narrow else 128},{'CONV3X3' if conv is not None else 'LINEAR'}>"
-    else:
-        name = "gemm"
-    with _rec(name, 2.0 * M * N * d.K):
+    with _rec("gemm", 2.0 * M * N * d.K) as r:
         L.check(L.lib().tb_gemm(d, L.stream()), "tb_gemm")
+        if _REC is not None:  # name the launch exactly as rocprofv3 prints the kernel
+            import ctypes
+            cfg = (ctypes.c_int * 5)()
+            L.lib().tb_gemm_last_config(cfg)
+            r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>" + (f"+splitk{cfg[4]}" if cfg[4] > 1 else "")
     return out
 
 

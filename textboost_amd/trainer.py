@@ -45,6 +45,23 @@ def alphas_cumprod(T=1000, beta_start=0.00085, beta_end=0.012, device="cuda"):
     return torch.cumprod(1.0 - betas, dim=0).to(device)
 
 
+def average_gradients(flat_grad: torch.Tensor, world_size: int):
+    """sum over ranks, then 1/W: what DDP's bucketed all-reduce does to every trainable gradient.  Row masking (:1114-1117)
+    commutes with the average, so reducing only the k added rows + the LoRA tensors is identical to the reference's dense
+    reduction.  Backend-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.mul_(1.0 / world_size)
+    return flat_grad
+
+
+def shard_indices(n_samples: int, batch: int, it: int, rank: int, world: int):
+    """data-parallel sample assignment: global sample (it*W + rank)*B + b, wrapped over the dataset, so every rank's shard is
+    non-empty even with ONE training image (the reference's Wrapper hangs for rank >= 1 there)."""
+    return [((it * world + rank) * batch + b) % n_samples for b in range(batch)]
+
+
 class TextBoostStep:
     def __init__(self, unet: HipUNet, text_encoder: HipTextEncoder, teacher: Optional[HipTextEncoder], hyper: StepHyper,
                  latent_shape, device="cuda", world_size: int = 1, generator: Optional[torch.Generator] = None):
@@ -134,10 +151,7 @@ class TextBoostStep:
     def all_reduce(self):
         """DDP gradient averaging (:919-926): ONE RCCL all-reduce of the flat trainable-gradient buffer
         (k*D + 2*L*3*r*D floats ~ 0.94 MB at SD1.5, r=4) instead of the reference's dense 152.7 MB."""
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.flat_grad.mul_(1.0 / self.world)
+        average_gradients(self.flat_grad, self.world)
 
     def optimizer_step(self):
         hp, te, st = self.hp, self.te, self.state

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""TextBoost training entry point on MI355X -- drop-in for the reference's `train_textboost.py` CLI.
+
+    python train_textboost.py --pretrained_model_name_or_path <dir> --placeholder_token "<dog>" ... (same flags as the reference)
+    python -m torch.distributed.run --nproc-per-node=N train_textboost.py ...                       (README.md:82 of the reference)
+
+What runs here is the reference's hot path (train_textboost.py:1024-1150) on the HIP kernels of libtextboost_hip.so, behind
+the reference's flags (:49-450) and output layout (:1157-1209, :1236-1266).  Out of scope in this round:
+the VAE encoder, the PIL/augmentation data pipeline, validation sampling.  The trainer therefore consumes LATENTS:
+
+  * `<instance_data_dir>/latents.pt`   -- a [N,4,h,w] fp32 tensor of `vae.encode(x).latent_dist.sample()*scaling_factor`
+    (+ optional `input_ids.pt` [N,77] / `prior_input_ids.pt` [M,77] int64 from the reference's tokenizer), or
+  * synthetic latents and token ids when no such file exists -- there is no network, tokenizer or checkpoint in
+    the build image; weights then come from a seeded random init of the exact SD1.5 / CLIP-L shapes unless
+    `<pretrained_model_name_or_path>/{unet/diffusion_pytorch_model,text_encoder/model}.safetensors` exist locally.
+"""
+import json
+import logging
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from textboost_amd import checkpoint as ckpt  # noqa: E402
+from textboost_amd import models  # noqa: E402
+from textboost_amd.cli import parse_args  # noqa: E402
+
+logger = logging.getLogger("textboost_amd")
+
+# number of embedding vectors per augmentation token = BPE pieces of its initialiser (textboost/utils.py:180-199); the
+# tokenizer is not available offline, the counts are the `_i` suffixes the reference's augmentation code emits
+AUG_TOKENS_OBJECT = [("<grayscale>", 2), ("<zoom-in>", 2), ("<zoom-out>", 2), ("<collage>", 2), ("<crop>", 1), ("<hflip>", 1),
+                     ("<left>", 3), ("<right>", 3)]
+AUG_TOKENS_STYLE = [("<hflip>", 1)]
+
+
+def multi_vector_names(token: str, n: int):
+    """textboost/utils.py:133-141: `<x>` -> `<x_0>`, `<x_1>`, ... when the initialiser has several pieces."""
+    if n == 1:
+        return [token]
+    stem = token[:-1] if token.endswith(">") else token
+    tail = ">" if token.endswith(">") else ""
+    return [f"{stem}_{i}{tail}" for i in range(n)]
+
+
+def load_local_state_dict(path):
+    from safetensors.torch import load_file
+    return load_file(path) if os.path.exists(path) else None
+
+
+def main(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train_textboost.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        if args.gradient_accumulation_steps > 1:  # :573-577
+            raise ValueError("Gradient accumulation is not supported when training with multiple processes.")
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    is_main = rank == 0
+    if is_main:
+        os.makedirs(args.output_dir, exist_ok=True)
+        fh = logging.FileHandler(os.path.join(args.output_dir, "training.log"))  # <output_dir>/training.log, :583-588
+        fh.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(name)s - %(message)s"))
+        logger.addHandler(fh)
+        logger.setLevel(logging.INFO)
+    if args.seed is not None:
+        torch.manual_seed(args.seed)  # set_seed(args.seed): the same seed on every rank (:601)
+    from textboost_amd import _lib
+    _lib.lib()
+    from textboost_amd.text_encoder import HipTextEncoder
+    from textboost_amd.trainer import StepHyper, TextBoostStep, shard_indices
+    from textboost_amd.unet import HipUNet
+    from textboost_amd.workload import BOS, EOS, synthetic_ids
+
+    # ---- models (:629-656)
+    mdir = args.pretrained_model_name_or_path
+    usd = load_local_state_dict(os.path.join(mdir, "unet", "diffusion_pytorch_model.safetensors")) if os.path.isdir(mdir) else None
+    csd = load_local_state_dict(os.path.join(mdir, "text_encoder", "model.safetensors")) if os.path.isdir(mdir) else None
+    unet_geo, clip_geo = models.SD15_UNET, models.SD15_CLIP
+    if usd is None or csd is None:
+        logger.warning("no local weights under %s: seeded random-init SD1.5 / CLIP-L shapes are used", mdir)
+        usd = models.random_state_dict(models.unet_shapes(unet_geo), 1234, device=dev)
+        csd = models.random_state_dict(models.clip_shapes(clip_geo), 1235, device=dev)
+    B = args.train_batch_size
+    latent = args.resolution // 8
+    lat_path = os.path.join(args.instance_data_dir or "", "latents.pt")
+    latents = torch.load(lat_path) if args.instance_data_dir and os.path.exists(lat_path) else None
+    if latents is not None:
+        latent = latents.shape[-1]
+    unet = HipUNet(unet_geo, usd, B, latent, latent, text_len=clip_geo.max_pos, device=dev)
+    del usd
+    teacher = HipTextEncoder(clip_geo, csd, B, mode="half", device=dev) if args.kpl_weight > 0 else None
+    frozen = HipTextEncoder(clip_geo, csd, 1, mode="autocast", device=dev)
+    null_ids = torch.full((1, clip_geo.max_pos), EOS, dtype=torch.int64, device=dev)
+    null_ids[0, 0] = BOS
+    null = frozen.forward(null_ids, pins=False).clone()  # SD1.x null embedding (the reference ships one only for SD2.1: SURVEY 0.5)
+    del frozen
+    te = HipTextEncoder(clip_geo, csd, B, mode="autocast", lora_rank=args.lora_rank, n_slots=1, device=dev, seed=args.seed)
+    del csd
+    te.set_null_embedding(null)
+    if teacher is not None:
+        teacher.set_null_embedding(null)
+
+    # ---- tokens (:658-694; utils.py:117-214): placeholder vectors first, then augmentation vectors; ids contiguous from 49408
+    g = torch.Generator().manual_seed(args.seed or 0)
+    added_tokens, aug_token_dict = {}, {}
+    n_place = 1
+    for name in multi_vector_names(args.placeholder_token, n_place):
+        added_tokens[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
+    if args.augment_inversion:
+        for tok, n in (AUG_TOKENS_OBJECT if args.augment_ops == "object" else AUG_TOKENS_STYLE):
+            for name in multi_vector_names(tok, n):
+                aug_token_dict[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
+    added_ids = list(added_tokens.values()) + list(aug_token_dict.values())
+
+    hp = StepHyper(lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
+                   beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
+                   max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight)
+    if args.kpl_type != "cos":
+        raise NotImplementedError("--kpl_type mse is not wired in this round (reference default is cos, :116)")
+    if args.mixing or args.with_image_prior or args.unet_params_to_train != "none":
+        raise NotImplementedError("--mixing / --with_image_prior / --unet_params_to_train are outside this round's hot path")
+    step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
+
+    # ---- data: latents (+ ids) from disk, else synthetic; rank r takes samples r, r+W, ... (every shard non-empty: SURVEY 0.6)
+    dg = torch.Generator().manual_seed(1000 + rank)
+    ids_path = os.path.join(args.instance_data_dir or "", "input_ids.pt")
+    pids_path = os.path.join(args.instance_data_dir or "", "prior_input_ids.pt")
+    inst_ids = torch.load(ids_path) if os.path.exists(ids_path) else None
+    prior_ids = torch.load(pids_path) if os.path.exists(pids_path) else None
+
+    def next_batch(it):
+        if latents is not None:
+            idx = shard_indices(latents.shape[0], B, it, rank, world)
+            step.x0.copy_(latents[idx])
+            if inst_ids is not None:
+                step.input_ids.copy_(inst_ids[[i % inst_ids.shape[0] for i in idx]])
+        else:
+            step.x0.copy_(torch.randn(B, 4, latent, latent, generator=dg))
+        if latents is None or inst_ids is None:
+            step.input_ids.copy_(synthetic_ids(B, added_ids, dg))
+        if prior_ids is not None:
+            j = torch.randint(0, prior_ids.shape[0], (B,), generator=dg)
+            step.prior_ids.copy_(prior_ids[j])
+        else:
+            step.prior_ids.copy_(synthetic_ids(B, added_ids, dg, prior=True, null_prob=args.null_prob))
+
+    # ---- resume (:959-981)
+    first_step = 0
+    if args.resume_from_checkpoint:
+        path = args.resume_from_checkpoint
+        if path == "latest":
+            dirs = sorted([d for d in os.listdir(args.output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
+            path = os.path.join(args.output_dir, dirs[-1]) if dirs else None
+        if path:
+            ckpt.load_trainer_state(step, path)
+            first_step = int(os.path.basename(path.rstrip("/")).split("-")[1])
+    if is_main:
+        logger.info("mean_norm %.6f | added tokens %s | world %d | per-GPU batch %d", step.mean_norm, list(added_tokens) +
+                    list(aug_token_dict), world, B)
+        print("Mean norm:", step.mean_norm)
+
+    next_batch(0)
+    step.capture(warmup=0)
+    t0 = time.perf_counter()
+    for it in range(first_step, args.max_train_steps):
+        next_batch(it)
+        step.replay()
+        done = it + 1
+        if is_main and (done % 50 == 0 or done == args.max_train_steps):  # scalars are read off the hot loop
+            sc = step.scalars()
+            logger.info("step %d loss %.6f mse %.6f kpl %.6f scale %.0f grad_norm %.4f", done, sc["loss"], sc["loss_mse"],
+                        sc["loss_kpl"], sc["loss_scale"], sc["grad_norm"])
+            print(f"step {done}: loss {sc['loss']:.5f} lr {args.learning_rate}", flush=True)
+        if is_main and done % args.checkpointing_steps == 0:  # :1157-1209
+            ckpt.rotate_checkpoints(args.output_dir, args.checkpoints_total_limit)
+            cdir = os.path.join(args.output_dir, f"checkpoint-{done}")
+            ckpt.save_trainer_state(step, cdir)
+            ckpt.save_text_encoder_adapter(te, os.path.join(cdir, "text_encoder"), mdir)
+            ckpt.save_token_embeddings(te, cdir, added_tokens, aug_token_dict if args.augment_inversion else None)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()  # accelerator.wait_for_everyone() :1235
+    if is_main:  # :1236-1266
+        if args.lora_rank > 0:
+            ckpt.save_text_encoder_adapter(te, os.path.join(args.output_dir, "text_encoder"), mdir)
+        ckpt.save_token_embeddings(te, args.output_dir, added_tokens, aug_token_dict if args.augment_inversion else None)
+        dt = time.perf_counter() - t0
+        logger.info("Training took %.2f seconds", dt)  # :1268-1269
+        print(json.dumps({"steps": args.max_train_steps - first_step, "seconds": round(dt, 3),
+                          "steps_per_s": round((args.max_train_steps - first_step) / max(dt, 1e-9), 3)}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(parse_args())
