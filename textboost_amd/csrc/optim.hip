@@ -9,22 +9,22 @@
 
 namespace {
 
-// deterministic sum of squares by a single 1024-thread block (n <= a few 1e5)
-__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
-  __shared__ float red[16];
+// deterministic sum of squares: 64 blocks write partials, the LAST-launched tiny kernel adds them in a fixed order
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  __shared__ float red[4];
   float a = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = x[i];
     a += v * v;
   }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  const int lane = threadIdx.x;  // 64 threads
+  float a = lane < nb ? part[lane] : 0.f;
   a = wave_sum(a);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < 16; ++i) s += red[i];
-    out[0] = s;
-  }
+  if (lane == 0) out[0] = a;
 }
 
 // one thread: derive every per-step scalar from the two gradient sums of squares
@@ -123,10 +123,11 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
 extern "C" int tb_last_hip_error_code_ = 0;
 extern "C" const char* tb_last_hip_error(void) { return hipGetErrorString((hipError_t)tb_last_hip_error_code_); }
 
-extern "C" int tb_sumsq(const float* x, int64_t n, float* out, tb_stream_t stream) {
+extern "C" int tb_sumsq(const float* x, int64_t n, float* out, float* ws64, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!x || !out || n <= 0) return TB_EINVAL;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+  if (!x || !out || !ws64 || n <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, x, n, ws64);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws64, 64, out);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

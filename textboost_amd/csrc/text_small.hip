@@ -22,11 +22,28 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 // block a owns token id first_added + a; deterministic accumulation over the M positions.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dh, const int64_t* __restrict__ ids,
                                                         float* __restrict__ g, int64_t M, int D, int64_t first_added) {
+  // positions holding this block's token are collected in ascending order (-> deterministic sum) by wave 0 with ballots
+  __shared__ int pos[4096];
+  __shared__ int npos;
   const int64_t tok = first_added + blockIdx.x;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int count = 0;
+    for (int64_t base = 0; base < M; base += 64) {
+      const int64_t m = base + lane;
+      const bool hit = m < M && ids[m] == tok;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) pos[count + __popcll(mask & ((1ull << lane) - 1ull))] = (int)m;
+      count += __popcll(mask);
+    }
+    if (lane == 0) npos = count;
+  }
+  __syncthreads();
+  const int n = npos;
+  if (n == 0) return;
   for (int c = threadIdx.x; c < D; c += 256) {
     float a = g[(int64_t)blockIdx.x * D + c];
-    for (int64_t m = 0; m < M; ++m)
-      if (ids[m] == tok) a += dh[m * D + c];
+    for (int i = 0; i < n; ++i) a += dh[(int64_t)pos[i] * D + c];
     g[(int64_t)blockIdx.x * D + c] = a;
   }
 }
@@ -55,17 +72,31 @@ __global__ __launch_bounds__(256) void pin_bwd_kernel(float* __restrict__ dh, co
 }
 
 // ---- LoRA down projection t[m, j] = sum_k x[m,k] * fp16(A[j,k]),  j < R (R = 3r: q,k,v adapters stacked)
+// one wave per row; the row of x is read ONCE and dotted against all R adapter rows (A is tiny and L1/L2 resident)
 __global__ __launch_bounds__(256) void lora_down_kernel(const f16* __restrict__ x, int64_t ldx, const float* __restrict__ A,
                                                         f16* __restrict__ t, int64_t ldt, int64_t M, int K, int R) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  for (int j = 0; j < R; ++j) {
-    float a = 0.f;
-    for (int k = lane; k < K; k += 64) a += (float)x[row * ldx + k] * (float)(f16)A[(int64_t)j * K + k];
-    a = wave_sum(a);
-    if (lane == 0) t[row * ldt + j] = (f16)a;
+  float acc[24];
+#pragma unroll
+  for (int j = 0; j < 24; ++j) acc[j] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const f16x8 xv = *(const f16x8*)(x + row * ldx + k);
+#pragma unroll
+    for (int j = 0; j < 24; ++j)
+      if (j < R) {
+        const f32x4 a0 = *(const f32x4*)(A + (int64_t)j * K + k), a1 = *(const f32x4*)(A + (int64_t)j * K + k + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j] += (float)xv[e] * (float)(f16)a0[e] + (float)xv[4 + e] * (float)(f16)a1[e];
+      }
   }
+#pragma unroll
+  for (int j = 0; j < 24; ++j)
+    if (j < R) {
+      const float v = wave_sum(acc[j]);
+      if (lane == 0) t[row * ldt + j] = (f16)v;
+    }
 }
 
 // ---- W2[p*D + n, p*r + j] = scaling * B[(p*D + n)*r + j] (fp16, block diagonal, zero elsewhere; 64 columns)
@@ -181,7 +212,7 @@ extern "C" int tb_embed_fwd(const int64_t* ids, const void* tok, const void* pos
 extern "C" int tb_embed_bwd(const float* dh, const int64_t* ids, float* g_added, int64_t M, int D, int64_t first_added, int n_added,
                             tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!dh || !ids || !g_added || n_added <= 0) return TB_EINVAL;
+  if (!dh || !ids || !g_added || n_added <= 0 || M > 4096) return TB_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_added), dim3(256), 0, (hipStream_t)stream, dh, ids, g_added, M, D, first_added);
   TB_CHECK_LAUNCH();
   return TB_OK;
@@ -214,7 +245,7 @@ extern "C" int tb_textboost_pin_bwd(float* dh, const int64_t* ids, int B, int T,
 extern "C" int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t, int64_t ldt, int64_t M, int K, int R,
                             tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!x || !A || !t || R <= 0 || R > 64) return TB_EINVAL;
+  if (!x || !A || !t || R <= 0 || R > 24 || K % 8 || ldx % 8) return TB_EINVAL;
   hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, A, (f16*)t,
                      ldt, M, K, R);
   TB_CHECK_LAUNCH();

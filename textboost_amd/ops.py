@@ -48,10 +48,27 @@ _gemm_ws = {}
 GEMM_WS_BYTES = 128 << 20  # split-K partials (fp32); allocated once per device, before any graph capture
 
 
+_ws_slot = 0  # one split-K workspace per concurrently running stream (0 = main, 1 = side stream of the trainer)
+
+
+class workspace_slot:
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        global _ws_slot
+        self.prev, _ws_slot = _ws_slot, self.slot
+
+    def __exit__(self, *a):
+        global _ws_slot
+        _ws_slot = self.prev
+
+
 def _gemm_workspace(dev):
-    ws = _gemm_ws.get(dev)
+    key = (dev, _ws_slot)
+    ws = _gemm_ws.get(key)
     if ws is None:
-        ws = _gemm_ws[dev] = torch.empty(GEMM_WS_BYTES // 4, device=dev, dtype=torch.float32)
+        ws = _gemm_ws[key] = torch.empty(GEMM_WS_BYTES // 4, device=dev, dtype=torch.float32)
     return ws
 
 
@@ -267,8 +284,14 @@ def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None):
 
 
 # ------------------------------------------------------------------ optimizer tail
+_sumsq_ws = {}
+
+
 def sumsq(x, out):
-    L.check(L.lib().tb_sumsq(L.ptr(x), x.numel(), L.ptr(out), L.stream()), "tb_sumsq")
+    ws = _sumsq_ws.get((x.device, out.data_ptr()))
+    if ws is None:
+        ws = _sumsq_ws[(x.device, out.data_ptr())] = torch.empty(64, device=x.device)
+    L.check(L.lib().tb_sumsq(L.ptr(x), x.numel(), L.ptr(out), L.ptr(ws), L.stream()), "tb_sumsq")
 
 
 def scaler_update(state, max_norm=1.0, beta1=0.9, beta2=0.999, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,

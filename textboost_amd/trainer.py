@@ -121,6 +121,7 @@ class TextBoostStep:
         self.added_norms = torch.empty(max(te.n_added, 1), device=device)
         self.graph = None
         self.external_noise = False
+        self.side = torch.cuda.Stream(device=device) if self.kpl else None
 
     # ------------------------------------------------------------------ pieces
     def draw(self):
@@ -138,13 +139,20 @@ class TextBoostStep:
         BT = B * te.T
         h_all = te.forward(self.ids_all, slot=0)                                   # :1054-1059 and :1099 in one batch
         ops.convert(h_all[:BT], self.ehs16)                                        # .to(unet.dtype) :1066
+        main = torch.cuda.current_stream()
+        if self.kpl:                                                               # :1096-1106
+            # the frozen fp16 teacher + KPL loss depend only on the student's hidden states: run them on a side stream while
+            # the UNet forward/backward occupies the main one (captured as a fork/join inside the HIP graph)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side), ops.workspace_slot(1):
+                h0 = self.teacher.forward(self.prior_ids, slot=0)
+                ops.kpl_cos(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
         pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)           # :1063-1067
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
         ops.mse_loss(pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
-        if self.kpl:                                                               # :1096-1106
-            h0 = self.teacher.forward(self.prior_ids, slot=0)
-            ops.kpl_cos(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
         self.unet.backward(self.dpred, d_ehs_out=self.d_ehs)                       # :1108 (UNet part, dgrad only)
+        if self.kpl:
+            main.wait_stream(self.side)
         self.flat_grad.zero_()
         te.backward(self.d_all, slot=0)
 
