@@ -131,9 +131,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("TB_FORCE_DIST") == "1"  # exercise the RCCL + two-graph path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     from textboost_amd.build import LIB  # noqa: F401
     from textboost_amd import _lib
@@ -145,6 +147,7 @@ def main():
     torch.manual_seed(42)  # the reference seeds every rank identically (train_textboost.py:601); data is offset by rank
     step, added = build_step(batch=args.batch, latent=args.latent, data_seed=1000 + rank, world_size=world,
                              device=torch.device("cuda", local))
+    step.force_dist = force_dist
     if args.no_graph:
         for _ in range(2):
             step.step_eager()
@@ -201,9 +204,13 @@ def main():
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
                 json.dump(table, f, indent=1)
-        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # before the JSON line: RCCL prints its banner on teardown
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's banner sits in C stdio buffers: flush it so the JSON line is the LAST line
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -235,3 +235,37 @@ def test_cli_end_to_end_writes_reference_layout(tmp_path):
     assert cfg["base_model_name_or_path"] == "/nonexistent/sd15"
     d = torch.load(os.path.join(out, "dog.bin"))
     assert d["<dog>"].shape == (768,) and torch.isfinite(d["<dog>"]).all()
+
+
+def test_collective_two_graph_path_with_one_rank_group():
+    """The N>1 code path (eager RCCL all-reduce between two HIP graphs) exercised with a 1-rank nccl group: results must equal
+    the single-graph path bit for bit (mean over one rank is the identity)."""
+    import os
+    import torch.distributed as dist
+    from oracle import train_step as ts
+    B, hw, D = 2, 16, 64
+    outs = []
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        for force in (False, True):
+            st_ref, step, added = build_step(B, hw, D)
+            step.force_dist = force
+            g = torch.Generator().manual_seed(8)
+            step.input_ids.copy_(ts.synthetic_ids(B, added, g)); step.prior_ids.copy_(ts.synthetic_ids(B, added, g, prior=True))
+            step.x0.copy_(torch.randn(B, 4, hw, hw, generator=g)); step.noise.copy_(torch.randn(B, 4, hw, hw, generator=g))
+            step.timesteps.copy_(torch.randint(0, 1000, (B,), generator=g))
+            step.capture(warmup=1)
+            assert len(step.graph) == (2 if force else 1)
+            step.replay(); step.replay()
+            torch.cuda.synchronize()
+            outs.append((step.te.lora_A.clone(), step.te.lora_B.clone(), step.te.token_table[49408:].clone()))
+        for a, b in zip(*outs):
+            torch.testing.assert_close(a, b, rtol=0, atol=0)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -45,11 +45,11 @@ def alphas_cumprod(T=1000, beta_start=0.00085, beta_end=0.012, device="cuda"):
     return torch.cumprod(1.0 - betas, dim=0).to(device)
 
 
-def average_gradients(flat_grad: torch.Tensor, world_size: int):
+def average_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = False):
     """sum over ranks, then 1/W: what DDP's bucketed all-reduce does to every trainable gradient.  Row masking (:1114-1117)
     commutes with the average, so reducing only the k added rows + the LoRA tensors is identical to the reference's dense
     reduction.  Backend-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
-    if world_size > 1:
+    if world_size > 1 or force:
         import torch.distributed as dist
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         flat_grad.mul_(1.0 / world_size)
@@ -67,6 +67,7 @@ class TextBoostStep:
                  latent_shape, device="cuda", world_size: int = 1, generator: Optional[torch.Generator] = None):
         self.unet, self.te, self.teacher, self.hp, self.dev = unet, text_encoder, teacher, hyper, device
         self.world = world_size
+        self.force_dist = False  # tests: exercise the collective + two-graph path with a 1-rank process group
         self.gen = generator
         B, C, H, W = latent_shape
         self.B = B
@@ -159,7 +160,7 @@ class TextBoostStep:
     def all_reduce(self):
         """DDP gradient averaging (:919-926): ONE RCCL all-reduce of the flat trainable-gradient buffer
         (k*D + 2*L*3*r*D floats ~ 0.94 MB at SD1.5, r=4) instead of the reference's dense 152.7 MB."""
-        average_gradients(self.flat_grad, self.world)
+        average_gradients(self.flat_grad, self.world, force=self.force_dist)
 
     def optimizer_step(self):
         hp, te, st = self.hp, self.te, self.state
@@ -197,18 +198,19 @@ class TextBoostStep:
                 self.step_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.world > 1 or self.force_dist:
             # keep the collective outside the graphs: two graphs around one eager RCCL call
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1):
+            # thread_local: the RCCL watchdog thread keeps polling its events while this thread captures
+            with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
                 self.draw()
                 self.forward_backward()
-            with torch.cuda.graph(self.g2):
+            with torch.cuda.graph(self.g2, capture_error_mode="thread_local"):
                 self.optimizer_step()
             self.graph = (self.g1, self.g2)
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.draw()
                 self.forward_backward()
                 self.optimizer_step()
