@@ -45,44 +45,59 @@ __device__ __forceinline__ EpiFlags epi_flags(const tb_gemm_desc& p) {
   f.c2_vec = p.C2 && (p.ldc2 % 8 == 0) && (((uintptr_t)p.C2) % 16 == 0);
   return f;
 }
-__device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n, float* v) {
+// residual (R) and the QUICK_GELU_GRAD pre-activation (C2) are fetched by the two loaders below so that callers can issue the
+// loads of all their units back to back BEFORE the arithmetic (cold HBM latency is paid once, not once per unit).
+__device__ __forceinline__ void epi_load_r8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n, float* r) {
+  const bool full = n + 7 < p.N;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = 0.f;
+  if (!p.R) return;
+  if (p.r_dtype == TB_F32) {
+    const float* rp = (const float*)p.R + m * p.ldr + n;
+    if (full && f.r_vec) {
+      const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r[e] = r0[e];
+        r[4 + e] = r1[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) r[e] = rp[e];
+    }
+  } else {
+    const f16* rp = (const f16*)p.R + m * p.ldr + n;
+    if (full && f.r_vec) {
+      const f16x8 rv = *(const f16x8*)rp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (float)rv[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) r[e] = (float)rp[e];
+    }
+  }
+}
+__device__ __forceinline__ f16x8 epi_load_aux8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n) {
+  f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.act != TB_ACT_QUICK_GELU_GRAD) return a;
+  const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + n;
+  if (n + 7 < p.N && f.c2_vec) return *(const f16x8*)c2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (n + e < p.N) a[e] = c2[e];
+  return a;
+}
+// bias8: bias[n..n+7] (0 when absent / out of range), r: preloaded residual, aux: preloaded pre-activation
+__device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n, float* v, const float* bias8,
+                                          const float* r, const f16x8& aux) {
   const bool full = n + 7 < p.N;
   const float* rb = p.rowbias ? p.rowbias + (m / p.rows_per_group) * p.ldrb : nullptr;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    v[e] *= p.alpha;
-    if (full || n + e < p.N) {
-      if (p.bias) v[e] += p.bias[n + e];
-      if (rb) v[e] += rb[n + e];
-    }
-  }
-  if (p.R) {
-    if (p.r_dtype == TB_F32) {
-      const float* rp = (const float*)p.R + m * p.ldr + n;
-      if (full && f.r_vec) {
-        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] += r0[e];
-          v[4 + e] += r1[e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.N) v[e] += rp[e];
-      }
-    } else {
-      const f16* rp = (const f16*)p.R + m * p.ldr + n;
-      if (full && f.r_vec) {
-        const f16x8 rv = *(const f16x8*)rp;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.N) v[e] += (float)rp[e];
-      }
-    }
+    v[e] = v[e] * p.alpha + bias8[e] + r[e];
+    if (rb && (full || n + e < p.N)) v[e] += rb[n + e];
   }
   if (p.act == TB_ACT_QUICK_GELU) {
     f16x8 pre;
@@ -104,16 +119,8 @@ __device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags&
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
   } else if (p.act == TB_ACT_QUICK_GELU_GRAD) {
-    const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + n;
-    if (full && f.c2_vec) {
-      const f16x8 pv = *(const f16x8*)c2;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f((float)pv[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (n + e < p.N) v[e] *= quick_gelu_grad_f((float)c2[e]);
-    }
+    for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f((float)aux[e]);
   }
   if (p.c_dtype == TB_F32) {
     float* c = (float*)p.C + m * p.ldc + n;
@@ -146,6 +153,11 @@ __device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags&
   }
 }
 
+__device__ __forceinline__ void epi_load_bias8(const tb_gemm_desc& p, int64_t n, float* b) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+}
+
 // split-K second pass: C = epilogue(sum_s ws[s][m][n]); ws is fp32 [S][M][Npad] with Npad = N rounded up to 8
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p, const float* __restrict__ ws, int S, int64_t npad) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -154,17 +166,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
   const int64_t m = idx / groups;
   const int64_t n = (idx - m * groups) << 3;
   const EpiFlags f = epi_flags(p);
+  float r8[8], b8[8];
+  epi_load_r8(p, f, m, n, r8);
+  const f16x8 aux = epi_load_aux8(p, f, m, n);
+  epi_load_bias8(p, n, b8);
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < S; ++s) {
-    const float* src = ws + ((int64_t)s * p.M + m) * npad + n;
-    const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
+  const float* src = ws + m * npad + n;
+  const int64_t plane = p.M * npad;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {  // 4 slices per trip: 8 independent 16-byte loads in flight, summed in slice order
+    f32x4 x[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      x[2 * k] = *(const f32x4*)(src + (s + k) * plane);
+      x[2 * k + 1] = *(const f32x4*)(src + (s + k) * plane + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += x[2 * k][e];
+        v[4 + e] += x[2 * k + 1][e];
+      }
+  }
+  for (; s < S; ++s) {
+    const f32x4 x0 = *(const f32x4*)(src + s * plane), x1 = *(const f32x4*)(src + s * plane + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[e] += x0[e];
       v[4 + e] += x1[e];
     }
   }
-  epilogue8(p, f, m, n, v);
+  epilogue8(p, f, m, n, v, b8, r8, aux);
 }
 
 // BKT: halfs per k-tile (64 -> 128-byte LDS rows, 32 -> 64-byte rows); NST: LDS stages (2, or 3 with counted vmcnt)
@@ -445,11 +478,41 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
     }
     return;
   }
-  constexpr int UPR = BN / 8;  // (row, 8-column) units per row
-  for (int u = t; u < BM * UPR; u += 256) {
-    const int row = u / UPR, cg = u - row * UPR;
-    const int64_t m = m0 + row, n = n0 + cg * 8;
-    if (m >= p.M || n >= p.N) continue;
+  constexpr int UPR = BN / 8;          // (row, 8-column) units per row
+  constexpr int RS = 256 / UPR;        // rows covered per pass of the 256 threads
+  constexpr int NU = BM / RS;          // units per thread: same column group, rows row0 + it*RS
+  const int cg = t % UPR, row0 = t / UPR;
+  const int64_t n = n0 + cg * 8;
+  if (n >= p.N) return;
+  if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+      const int row = row0 + it * RS;
+      const int64_t m = m0 + row;
+      if (m >= p.M) continue;
+      float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+    }
+    return;
+  }
+  float b8[8];
+  epi_load_bias8(p, n, b8);
+  float r8[NU][8];
+  f16x8 aux[NU];
+#pragma unroll
+  for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
+    const int64_t m = m0 + row0 + it * RS;
+    const int64_t mm = m < p.M ? m : p.M - 1;
+    epi_load_r8(p, ef, mm, n, r8[it]);
+    aux[it] = epi_load_aux8(p, ef, mm, n);
+  }
+#pragma unroll
+  for (int it = 0; it < NU; ++it) {
+    const int row = row0 + it * RS;
+    const int64_t m = m0 + row;
+    if (m >= p.M) continue;
     float v[8];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -457,19 +520,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
     }
-    if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
-      float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
-      f32x4 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o0[e] = v[e];
-        o1[e] = v[4 + e];
-      }
-      *(f32x4*)dst = o0;
-      *(f32x4*)(dst + 4) = o1;
-    } else {
-      epilogue8(p, ef, m, n, v);
-    }
+    epilogue8(p, ef, m, n, v, b8, r8[it], aux[it]);
   }
 }
 
