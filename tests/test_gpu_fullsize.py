@@ -1,0 +1,113 @@
+"""Full-size (BASELINE.json shapes) parity on the GPU box: SD1.5 UNet (859.5M) and CLIP-L with random-init weights at B=1 / B=2
+against the CPU oracle (~20 s of host time), plus size-independent properties at the metric's B=8."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def test_sd15_unet_full_size_forward_backward_vs_oracle():
+    from oracle.unet_sd import UNet2DCondition, UNetConfig
+    from textboost_amd import models
+    from textboost_amd.unet import HipUNet
+    torch.manual_seed(0)
+    sd = models.random_state_dict(models.unet_shapes(models.SD15_UNET), 77, device="cpu")
+    sd = {k: v.half().float() for k, v in sd.items()}
+    with torch.device("meta"):
+        ref = UNet2DCondition(UNetConfig.sd15())
+    ref = ref.to_empty(device="cpu")
+    ref.load_state_dict(sd)
+    B = 1
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 4, 64, 64, generator=g).half().float()
+    t = torch.tensor([611])
+    ehs = torch.randn(B, 77, 768, generator=g).half().float().requires_grad_(True)
+    pred_ref = ref(x, t, ehs)
+    dpred = torch.randn(B, 4, 64, 64, generator=g)
+    pred_ref.backward(dpred)
+    hip = HipUNet(models.SD15_UNET, {k: v.to(dev) for k, v in sd.items()}, B, 64, 64, device=dev)
+    pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, 768).to(dev).contiguous())
+    e = rel_err(pred, pred_ref)
+    assert e < 2e-2, f"SD1.5 UNet forward rel-L2 {e}"
+    d_ehs = hip.backward(dpred.to(dev))
+    e = rel_err(d_ehs.view(B, 77, 768), ehs.grad)
+    assert e < 5e-2, f"SD1.5 UNet d_ehs rel-L2 {e}"
+
+
+def test_clip_l_full_size_forward_backward_vs_oracle():
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle import train_step as ts
+    from textboost_amd import models
+    from textboost_amd.text_encoder import HipTextEncoder
+    torch.manual_seed(0)
+    csd = models.random_state_dict(models.clip_shapes(models.SD15_CLIP), 78, device="cpu")
+    ref = TextBoostEncoder(CLIPTextCfg.sd15(), r=4)
+    ref.load_hf_state_dict(csd)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.02)
+        null = ref.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    ref.set_null_embedding(null)
+    added = add_tokens(ref, [11, 22, 33])
+    B = 2
+    hip = HipTextEncoder(models.SD15_CLIP, csd, B, mode="autocast", lora_rank=4, device=dev, seed=0)
+    hip.set_null_embedding(null)
+    hip.add_tokens([11, 22, 33])
+    for i, layer in enumerate(ref.layers):
+        hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
+        hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
+    g = torch.Generator().manual_seed(3)
+    ids = ts.synthetic_ids(B, added, g)
+    out_ref = ref(ids)
+    R = torch.randn(B, 77, 768, generator=g)
+    (out_ref * R).sum().backward()
+    hip.pack_lora()
+    out = hip.forward(ids.to(dev))
+    assert rel_err(out.view(B, 77, 768), out_ref) < 5e-3
+    hip.zero_grad()
+    hip.backward(R.view(B * 77, 768).to(dev).contiguous())
+    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
+    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
+    assert rel_err(hip.grad_A, gA) < 3e-2 and rel_err(hip.grad_B, gB) < 3e-2
+    assert rel_err(hip.grad_added, ref.token_embedding.weight.grad[added]) < 3e-2
+
+
+def test_metric_config_properties_at_batch_8():
+    """B=8, 64x64 latents, SD1.5 + CLIP-L (the bench workload): size-independent invariants of the reference step."""
+    from textboost_amd import _lib as L
+    from textboost_amd.workload import build_step
+    torch.manual_seed(42)
+    step, added = build_step(batch=8, latent=64)
+    te = step.te
+    w0 = te.token_table.clone()
+    A0, B0 = te.lora_A.clone(), te.lora_B.clone()
+    n = 3
+    for _ in range(n):
+        step.step_eager()
+    torch.cuda.synchronize()
+    sc = step.scalars()
+    assert sc["found_inf"] == 0.0 and sc["opt_steps"] == float(n) and sc["loss_scale"] == 65536.0
+    assert 0.5 < sc["loss_mse"] < 2.0 and sc["loss_kpl"] >= 0.0          # eps-prediction of a random UNet vs unit noise
+    first = te.first_added
+    # rows below min(added_token_ids): gradient zeroed (:1109-1117) -> only AdamW's decoupled decay, every step
+    torch.testing.assert_close(te.token_table[:first], w0[:first] * (1 - 1e-3 * 1e-2) ** n, rtol=2e-6, atol=0)
+    # added rows moved, stay finite and are norm-clamped to mean_norm (:1138-1149)
+    added_rows = te.token_table[first:]
+    assert torch.isfinite(added_rows).all() and not torch.equal(added_rows, w0[first:])
+    assert (added_rows.norm(dim=-1) <= step.mean_norm * (1 + 1e-5)).all()
+    # LoRA: B leaves zero after the first step, A moves after the second (B = 0 makes dA = 0 at step 1: peft gaussian init)
+    assert te.lora_B.abs().max() > 0 and not torch.equal(te.lora_A, A0)
+    # Adam's per-step move is bounded by ~lr
+    assert (te.lora_B - B0).abs().max().item() <= n * 5e-5 * 1.05 + 1e-9
+    # pins: null prompts and position 0 come out as the null embedding, bit-exact
+    ids = step.ids_all.clone()
+    ids[0, 1:] = 49407
+    h = te.forward(ids, slot=0).view(ids.shape[0], 77, -1)
+    assert torch.equal(h[0], te.null_embedding) and torch.equal(h[3, 0], te.null_embedding[0])
