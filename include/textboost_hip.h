@@ -25,7 +25,8 @@ typedef void* tb_stream_t; /* hipStream_t */
 
 /* ---- dtype / activation codes ------------------------------------------------------------- */
 enum { TB_F16 = 0, TB_F32 = 1 };
-enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2, TB_ACT_SILU = 3, TB_ACT_QUICK_GELU_GRAD = 4 };
+enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2, TB_ACT_SILU = 3, TB_ACT_QUICK_GELU_GRAD = 4, TB_ACT_GELU = 5,
+       TB_ACT_GELU_GRAD = 6 };
 enum { TB_A_LINEAR = 0, TB_A_CONV3X3 = 1 };
 
 /* ---- MFMA GEMM family: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), fp16 in, fp32 accumulate ------
@@ -57,8 +58,8 @@ typedef struct tb_gemm_desc {
   int32_t act;                   /* GEGLU: W rows interleaved in 32-row blocks [h|g]; C is [M, N/2] */
   void* C; int64_t ldc; int32_t c_dtype;
   void* C2; int64_t ldc2;        /* fp16 [M,N] aux: GEGLU: raw pre-gate output (packed order), written;
-                                  * QUICK_GELU: pre-activation, written (if non-NULL);
-                                  * QUICK_GELU_GRAD: pre-activation, READ: v *= quick_gelu'(C2[m,n]) */
+                                  * QUICK_GELU / GELU: pre-activation, written (if non-NULL);
+                                  * QUICK_GELU_GRAD / GELU_GRAD: pre-activation, READ: v *= act'(C2[m,n]) */
   void* ws; int64_t ws_bytes;    /* optional scratch: lets small-M / long-K problems split K over blocks (fp32 partials,
                                   * fixed-order reduction => deterministic); NULL disables */
 } tb_gemm_desc;
@@ -140,6 +141,9 @@ int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss
 int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,
                float* partial, float* loss_out, const float* loss_scale, float weight, int64_t M, int D, tb_stream_t stream);
 /* backward of diffusers GEGLU on the packed [h32|g32] layout tb_gemm(TB_ACT_GEGLU) saved in C2 */
+/* knowledge-preservation loss, mse variant (--kpl_type mse, :1104-1105): loss_out = mean((h - h0)^2) */
+int tb_kpl_mse(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,
+               float* partial, float* loss_out, const float* loss_scale, float weight, int64_t M, int D, tb_stream_t stream);
 int tb_geglu_bwd(const void* dout, int64_t lddo, const void* raw, int64_t ldr, void* dproj, int64_t lddp, int64_t M,
                  int inner, tb_stream_t stream);
 /* backward of F.interpolate(scale 2, nearest): dx[b,y,x,:] = sum of the 2x2 block of du (NHWC fp16) */

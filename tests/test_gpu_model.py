@@ -21,11 +21,14 @@ def round_fp16_(module):
     return module
 
 
-def make_unet(B=2, hw=16, cross_dim=64, seed=0):
+def make_unet(B=2, hw=16, cross_dim=64, seed=0, sd2=False):
     from oracle.unet_sd import UNet2DCondition, UNetConfig
     from textboost_amd.unet import HipUNet, UNetGeometry
     torch.manual_seed(seed)
     cfg = UNetConfig.tiny(cross_dim)
+    if sd2:  # SD2.x structure: Linear proj_in/out, per-level head counts with a uniform head dim of 64
+        cfg.use_linear_projection = True
+        cfg.num_heads = (1, 2, 2, 2)
     ref = round_fp16_(UNet2DCondition(cfg))
     with torch.no_grad():   # default-init norms are identity: perturb so affine params matter
         for n, p in ref.named_parameters():
@@ -33,7 +36,7 @@ def make_unet(B=2, hw=16, cross_dim=64, seed=0):
                 p.add_(torch.randn_like(p) * 0.1)
         round_fp16_(ref)
     geo = UNetGeometry(block_out_channels=cfg.block_out_channels, num_heads=cfg.num_heads, cross_attention_dim=cross_dim,
-                       cross_attn_levels=cfg.cross_attn_levels)
+                       cross_attn_levels=cfg.cross_attn_levels, use_linear_projection=cfg.use_linear_projection)
     hip = HipUNet(geo, ref.state_dict(), B, hw, hw, text_len=77, device=dev)
     return ref, hip, cfg
 
@@ -56,12 +59,13 @@ def test_unet_forward_and_dgrad_backward_match_oracle():
     assert e < 3e-2, f"unet d_ehs rel err {e}"
 
 
-def make_encoders(B=2, D=64, r=4, n_added=3, seed=0):
+def make_encoders(B=2, D=64, r=4, n_added=3, seed=0, act="quick_gelu"):
     from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
     from oracle import train_step as ts
     from textboost_amd.text_encoder import CLIPGeometry, HipTextEncoder
     torch.manual_seed(seed)
     ccfg = CLIPTextCfg.tiny(D)
+    ccfg.act = act
     base = TextBoostEncoder(ccfg, r=0)
     with torch.no_grad():
         for n, p in base.named_parameters():
@@ -79,7 +83,8 @@ def make_encoders(B=2, D=64, r=4, n_added=3, seed=0):
             if "lora_B" in n:
                 p.normal_(std=0.05)     # non-zero B so every LoRA gradient path is exercised
     added = add_tokens(student, [100, 200, 300][:n_added])
-    geo = CLIPGeometry(hidden_size=D, intermediate_size=ccfg.intermediate_size, num_layers=ccfg.num_layers, num_heads=ccfg.num_heads)
+    geo = CLIPGeometry(hidden_size=D, intermediate_size=ccfg.intermediate_size, num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
+                       act=act)
     sd = {hf: dict(base.named_parameters())[ours].detach() for ours, hf in base.hf_key_map().items()}
     hip = HipTextEncoder(geo, sd, B, mode="autocast", lora_rank=r, n_slots=2, device=dev, seed=0)
     hip.set_null_embedding(null)
@@ -126,13 +131,13 @@ def test_text_encoder_forward_backward_match_oracle():
     assert rel_err(t_out.view(B, 77, D), t_ref) < 1e-2
 
 
-def build_step(B=2, hw=16, D=64, use_scaler=True):
+def build_step(B=2, hw=16, D=64, use_scaler=True, sd2=False, kpl_type="cos", mixing=None):
     from oracle import train_step as ts
     from textboost_amd.trainer import StepHyper, TextBoostStep
-    ref_unet, hip_unet, _ = make_unet(B, hw, D, seed=3)
-    student, teacher, hip_te, hip_teacher, added, null = make_encoders(B, D, seed=4)
-    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig())
-    hp = StepHyper(use_grad_scaler=use_scaler, init_scale=65536.0 if use_scaler else 1.0)
+    ref_unet, hip_unet, _ = make_unet(B, hw, D, seed=3, sd2=sd2)
+    student, teacher, hip_te, hip_teacher, added, null = make_encoders(B, D, seed=4, act="gelu" if sd2 else "quick_gelu")
+    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig(kpl_type=kpl_type, mixing=mixing))
+    hp = StepHyper(use_grad_scaler=use_scaler, init_scale=65536.0 if use_scaler else 1.0, kpl_type=kpl_type, mixing=mixing)
     step = TextBoostStep(hip_unet, hip_te, hip_teacher, hp, (B, 4, hw, hw), device=dev)
     step.external_noise = True
     return st_ref, step, added
@@ -269,3 +274,30 @@ def test_collective_two_graph_path_with_one_rank_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_sd2_style_models_kpl_mse_and_mixing_match_oracle():
+    """BASELINE config 4 structure at small size: Linear proj_in/out + hd 64 UNet, erf-GELU text MLP, plus --kpl_type mse and
+    --mixing (object): gradients and updated weights vs the oracle."""
+    from oracle import train_step as ts
+    B, hw, D = 2, 16, 64
+    st_ref, step, added = build_step(B, hw, D, sd2=True, kpl_type="mse", mixing="object")
+    g = torch.Generator().manual_seed(9)
+    ids = ts.synthetic_ids(B, added, g); pids = ts.synthetic_ids(B, added, g, prior=True)
+    x0 = torch.randn(B, 4, hw, hw, generator=g); noise = torch.randn(B, 4, hw, hw, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    out = st_ref.step(x0, noise, t, ids, pids)
+    step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t); step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+    step.step_eager()
+    sc = step.scalars()
+    assert sc["found_inf"] == 0.0
+    assert abs(sc["loss_mse"] - out["mse"]) < 2e-2 * abs(out["mse"]) + 1e-4
+    assert abs(sc["loss_kpl"] - out["kpl"]) < 5e-2 * abs(out["kpl"]) + 1e-6
+    te_ref = st_ref.te
+    clip = min(1.0, 1.0 / (out["lora_grad_norm"] + 1e-6))
+    inv = 1.0 / 65536.0
+    gB = torch.stack([torch.cat(out["g_lora"][6 * l + 1: 6 * l + 6: 2]) for l in range(len(te_ref.layers))])
+    assert rel_err(step.te.grad_B * inv * clip, gB) < 5e-2
+    gBv = step.te.grad_B.view(len(te_ref.layers), 3, D, 4)
+    assert gBv[:, :, 1::2].abs().max().item() == 0.0 and gBv[:, :, 0::2].abs().max().item() > 0.0   # :1119-1126, object
+    assert rel_err(step.te.grad_added * inv, out["g_emb_added"]) < 5e-2

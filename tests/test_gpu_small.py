@@ -241,3 +241,29 @@ def test_gemm_extra_epilogues():
     ops.gemm(A, W, o2, rowbias=rb[:, 100:100 + N], rows_per_group=50)
     ref = A.float() @ W.float().T + rb[:, 100:100 + N].repeat_interleave(50, 0)
     assert rel_err(o2, ref) < 2e-3
+
+
+def test_gelu_epilogues_and_kpl_mse():
+    ops, L = _ops()
+    torch.manual_seed(7)
+    M, N, K = 150, 256, 128
+    A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) / 11).half(); b = torch.randn(N, device=dev)
+    o16 = torch.empty(M, N, device=dev, dtype=torch.float16); pre = torch.empty_like(o16)
+    ops.gemm(A, W, o16, bias=b, act=L.ACT_GELU, C2=pre)
+    z = A.float() @ W.float().T + b
+    assert rel_err(pre, z) < 1e-3 and rel_err(o16, F.gelu(z)) < 2e-3
+    dY = torch.randn(M, K, device=dev).half(); Wt = (torch.randn(N, K, device=dev) / 11).half()
+    dz = torch.empty(M, N, device=dev, dtype=torch.float16)
+    ops.gemm(dY, Wt, dz, act=L.ACT_GELU_GRAD, C2=pre)
+    pz = pre.float().requires_grad_(True)
+    F.gelu(pz).backward(dY.float() @ Wt.float().T)
+    assert rel_err(dz, pz.grad) < 2e-3
+    Mh, D = 100, 768
+    h = torch.randn(Mh, D, device=dev); h0 = (h + 0.3 * torch.randn(Mh, D, device=dev)).half()
+    dh = torch.empty_like(h); part = torch.empty(Mh, device=dev); loss = torch.zeros(1, device=dev); ls = torch.tensor([512.0], device=dev)
+    ops.kpl_mse(h, h0, dh, part, loss, ls, 0.1)
+    hr = h.clone().requires_grad_(True)
+    ref = F.mse_loss(hr, h0.float())
+    (0.1 * 512 * ref).backward()
+    torch.testing.assert_close(loss[0], ref.detach(), rtol=1e-4, atol=1e-6)
+    assert rel_err(dh, hr.grad) < 1e-5

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtextboost_hip.so")
 
 TB_F16, TB_F32 = 0, 1
-ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2, 3, 4, 5, 6
 (ST_LOSS_SCALE, ST_GROWTH_TRACKER, ST_STEP, ST_FOUND_INF, ST_COEF_LORA, ST_COEF_EMB, ST_BC1, ST_BC2, ST_GRAD_NORM,
  ST_SUMSQ_LORA, ST_SUMSQ_EMB, ST_LOSS_MSE, ST_LOSS_KPL) = range(13)
 ST_COUNT = 16
@@ -78,6 +78,7 @@ _SIGS = {
     "tb_conv_to4": ([_VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _VP], C.c_int),
     "tb_mse_loss": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP], C.c_int),
     "tb_kpl_cos": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),
+    "tb_kpl_mse": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),
     "tb_geglu_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_pool2x2_sum": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
     "tb_add_f16": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),

@@ -154,6 +154,25 @@ __global__ __launch_bounds__(256) void kpl_cos_kernel(const float* __restrict__ 
   }
 }
 
+// ---- :1104-1105 KPL mse variant: mean over all M*D elements of (h - h0)^2; one wave per row, partial[row] = row sum / D
+template <typename T0>
+__global__ __launch_bounds__(256) void kpl_mse_kernel(const float* __restrict__ h, int64_t ldh, const T0* __restrict__ h0, int64_t ldh0,
+                                                      float* __restrict__ dh, int64_t lddh, float* __restrict__ partial,
+                                                      const float* __restrict__ loss_scale, float weight, int64_t M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float coef = 2.f * weight * (loss_scale ? loss_scale[0] : 1.f) / ((float)M * (float)D);
+  float a = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = h[row * ldh + c] - (float)h0[row * ldh0 + c];
+    a += d * d;
+    if (dh) dh[row * lddh + c] = coef * d;
+  }
+  a = wave_sum(a);
+  if (lane == 0) partial[row] = a / (float)D;
+}
+
 // deterministic sum of n floats by one block; out[0] = scale * sum
 __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float scale) {
   __shared__ float red[4];
@@ -313,6 +332,23 @@ extern "C" int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t l
                        weight, M, D);
   else
     hipLaunchKernelGGL(kpl_cos_kernel<f16>, grid, dim3(256), 0, s, h, ldh, (const f16*)h0, ldh0, dh, lddh, partial, loss_scale, weight,
+                       M, D);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, partial, loss_out, M, 1.f / (float)M);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_kpl_mse(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,
+                          float* partial, float* loss_out, const float* loss_scale, float weight, int64_t M, int D, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!h || !h0 || !partial || !loss_out || M <= 0 || D <= 0) return TB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (h0_dtype == TB_F32)
+    hipLaunchKernelGGL(kpl_mse_kernel<float>, grid, dim3(256), 0, s, h, ldh, (const float*)h0, ldh0, dh, lddh, partial, loss_scale,
+                       weight, M, D);
+  else
+    hipLaunchKernelGGL(kpl_mse_kernel<f16>, grid, dim3(256), 0, s, h, ldh, (const f16*)h0, ldh0, dh, lddh, partial, loss_scale, weight,
                        M, D);
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, partial, loss_out, M, 1.f / (float)M);
   TB_CHECK_LAUNCH();

@@ -81,7 +81,7 @@ __device__ __forceinline__ void epi_load_r8(const tb_gemm_desc& p, const EpiFlag
 }
 __device__ __forceinline__ f16x8 epi_load_aux8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n) {
   f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (p.act != TB_ACT_QUICK_GELU_GRAD) return a;
+  if (p.act != TB_ACT_QUICK_GELU_GRAD && p.act != TB_ACT_GELU_GRAD) return a;
   const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + n;
   if (n + 7 < p.N && f.c2_vec) return *(const f16x8*)c2;
 #pragma unroll
@@ -115,12 +115,31 @@ __device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags&
           if (n + e < p.N) c2[e] = pre[e];
       }
     }
+  } else if (p.act == TB_ACT_GELU) {  // erf GELU (OpenCLIP-H text MLP of SD2.x), same save-pre-activation contract as QUICK_GELU
+    f16x8 pre;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pre[e] = (f16)v[e];
+      v[e] = gelu_erf_f((float)pre[e]);
+    }
+    if (p.C2) {
+      f16* c2 = (f16*)p.C2 + m * p.ldc2 + n;
+      if (full && f.c2_vec) *(f16x8*)c2 = pre;
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) c2[e] = pre[e];
+      }
+    }
   } else if (p.act == TB_ACT_SILU) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
   } else if (p.act == TB_ACT_QUICK_GELU_GRAD) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f((float)aux[e]);
+  } else if (p.act == TB_ACT_GELU_GRAD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad_f((float)aux[e]);
   }
   if (p.c_dtype == TB_F32) {
     float* c = (float*)p.C + m * p.ldc + n;
@@ -613,8 +632,8 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if (((uintptr_t)d.A) % 16 || ((uintptr_t)d.W) % 16 || ((uintptr_t)d.A2) % 16 || ((uintptr_t)d.W2) % 16) return TB_EINVAL;
   if (d.rowbias && d.rows_per_group <= 0) return TB_EINVAL;
   if (d.rowbias && d.ldrb < d.N) d.ldrb = d.N;
-  if (d.act == TB_ACT_QUICK_GELU_GRAD && !d.C2) return TB_EINVAL;
-  if (d.act < 0 || d.act > TB_ACT_QUICK_GELU_GRAD) return TB_EINVAL;
+  if ((d.act == TB_ACT_QUICK_GELU_GRAD || d.act == TB_ACT_GELU_GRAD) && !d.C2) return TB_EINVAL;
+  if (d.act < 0 || d.act > TB_ACT_GELU_GRAD) return TB_EINVAL;
   if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;
     if (d.M != (int64_t)d.B * d.Hout * d.Wout) return TB_EINVAL;

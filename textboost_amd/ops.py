@@ -219,6 +219,12 @@ def kpl_cos(h, h0, dh, partial, loss_out, loss_scale, weight):
                                L.ptr(partial), L.ptr(loss_out), L.ptr(loss_scale), weight, M, D, L.stream()), "tb_kpl_cos")
 
 
+def kpl_mse(h, h0, dh, partial, loss_out, loss_scale, weight):
+    M, D = h.shape
+    L.check(L.lib().tb_kpl_mse(L.ptr(h), h.stride(0), L.ptr(h0), h0.stride(0), _dt(h0), L.ptr(dh), dh.stride(0) if dh is not None else 0,
+                               L.ptr(partial), L.ptr(loss_out), L.ptr(loss_scale), weight, M, D, L.stream()), "tb_kpl_mse")
+
+
 def geglu_bwd(dout, raw, dproj):
     M, inner = dout.shape
     L.check(L.lib().tb_geglu_bwd(L.ptr(dout), dout.stride(0), L.ptr(raw), raw.stride(0), L.ptr(dproj), dproj.stride(0), M, inner,

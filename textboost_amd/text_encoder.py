@@ -47,7 +47,8 @@ class HipTextEncoder:
                  lora_alpha: Optional[float] = None, n_slots: int = 1, device="cuda", seed: Optional[int] = None):
         """state_dict uses transformers CLIPTextModel keys (`text_model.embeddings.token_embedding.weight`, ...)."""
         assert mode in ("autocast", "half")
-        assert geo.act == "quick_gelu", "only the SD1.x quick_gelu MLP is wired in this round"
+        assert geo.act in ("quick_gelu", "gelu")  # SD1.x CLIP-L / SD2.x OpenCLIP-H
+        self.act_fwd, self.act_bwd = (L.ACT_QUICK_GELU, L.ACT_QUICK_GELU_GRAD) if geo.act == "quick_gelu" else (L.ACT_GELU, L.ACT_GELU_GRAD)
         self.geo, self.B, self.T, self.mode, self.dev = geo, batch, geo.max_pos, mode, device
         self.r = lora_rank
         self.scaling = (lora_alpha if lora_alpha is not None else lora_rank) / lora_rank if lora_rank else 0.0
@@ -172,7 +173,7 @@ class HipTextEncoder:
             ops.layernorm_fwd(h2, x2, W["ln2.g"], W["ln2.b"], ls2, geo.eps)
             a = self.buf(s + "a", M, I, f16)
             pre = self.buf(p + "pre", M, I, f16)
-            ops.gemm(x2, W["fc1.w"], a, bias=W["fc1.b"], act=L.ACT_QUICK_GELU, C2=pre)
+            ops.gemm(x2, W["fc1.w"], a, bias=W["fc1.b"], act=self.act_fwd, C2=pre)
             h3 = self.buf(p + "h3", M, D, rdt)
             ops.gemm(a, W["fc2.w"], h3, bias=W["fc2.b"], R=h2)
             h = h3
@@ -218,7 +219,7 @@ class HipTextEncoder:
             dh16 = self.buf("g.dh16", M, D, f16)
             ops.convert(dh, dh16)
             dpre = self.buf("g.dpre", M, I, f16)
-            ops.gemm(dh16, W["fc2.wd"], dpre, act=L.ACT_QUICK_GELU_GRAD, C2=pre)
+            ops.gemm(dh16, W["fc2.wd"], dpre, act=self.act_bwd, C2=pre)
             dx2 = self.buf("g.dx", M, D, f16)
             ops.gemm(dpre, W["fc1.wd"], dx2)
             dh2 = dh_other

@@ -32,6 +32,8 @@ class StepHyper:
     eps: float = 1e-8
     max_grad_norm: float = 1.0
     kpl_weight: float = 0.1       # :115
+    kpl_type: str = "cos"         # :116 ("cos" | "mse")
+    mixing: Optional[str] = None  # --mixing with --augment_ops object|style: zero odd / even rows of every lora_B.grad (:1119-1126)
     prediction_type: str = "epsilon"
     use_grad_scaler: bool = True  # --mixed_precision=fp16 (accelerate GradScaler)
     init_scale: float = 65536.0
@@ -147,7 +149,8 @@ class TextBoostStep:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side), ops.workspace_slot(1):
                 h0 = self.teacher.forward(self.prior_ids, slot=0)
-                ops.kpl_cos(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
+                kpl = ops.kpl_cos if hp.kpl_type == "cos" else ops.kpl_mse
+                kpl(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
         pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)           # :1063-1067
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
         ops.mse_loss(pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
@@ -156,6 +159,9 @@ class TextBoostStep:
             main.wait_stream(self.side)
         self.flat_grad.zero_()
         te.backward(self.d_all, slot=0)
+        if hp.mixing is not None:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
+            gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
+            gB[:, :, (1 if hp.mixing == "object" else 0)::2, :].zero_()
 
     def all_reduce(self):
         """DDP gradient averaging (:919-926): ONE RCCL all-reduce of the flat trainable-gradient buffer

@@ -125,11 +125,10 @@ def main(args):
 
     hp = StepHyper(lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
                    beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
-                   max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight)
-    if args.kpl_type != "cos":
-        raise NotImplementedError("--kpl_type mse is not wired in this round (reference default is cos, :116)")
-    if args.mixing or args.with_image_prior or args.unet_params_to_train != "none":
-        raise NotImplementedError("--mixing / --with_image_prior / --unet_params_to_train are outside this round's hot path")
+                   max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight, kpl_type="cos" if args.kpl_type == "cos" else "mse",
+                   mixing=(args.augment_ops if args.augment_ops == "object" else "style") if args.mixing else None)
+    if args.with_image_prior or args.unet_params_to_train != "none":
+        raise NotImplementedError("--with_image_prior (broken in the reference, SURVEY 0.6) / --unet_params_to_train are outside this round's hot path")
     step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
 
     # ---- data: latents (+ ids) from disk, else synthetic; rank r takes samples r, r+W, ... (every shard non-empty: SURVEY 0.6)
