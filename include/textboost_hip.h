@@ -26,7 +26,7 @@ typedef void* tb_stream_t; /* hipStream_t */
 /* ---- dtype / activation codes ------------------------------------------------------------- */
 enum { TB_F16 = 0, TB_F32 = 1 };
 enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2, TB_ACT_SILU = 3, TB_ACT_QUICK_GELU_GRAD = 4, TB_ACT_GELU = 5,
-       TB_ACT_GELU_GRAD = 6 };
+       TB_ACT_GELU_GRAD = 6, TB_ACT_GEGLU_GRAD = 7 };
 enum { TB_A_LINEAR = 0, TB_A_CONV3X3 = 1 };
 
 /* ---- MFMA GEMM family: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), fp16 in, fp32 accumulate ------
@@ -59,7 +59,8 @@ typedef struct tb_gemm_desc {
   void* C; int64_t ldc; int32_t c_dtype;
   void* C2; int64_t ldc2;        /* fp16 [M,N] aux: GEGLU: raw pre-gate output (packed order), written;
                                   * QUICK_GELU / GELU: pre-activation, written (if non-NULL);
-                                  * QUICK_GELU_GRAD / GELU_GRAD: pre-activation, READ: v *= act'(C2[m,n]) */
+                                  * QUICK_GELU_GRAD / GELU_GRAD: pre-activation, READ: v *= act'(C2[m,n]);
+                                  * GEGLU_GRAD: packed pre-gate [M,2N], READ; C becomes d(proj) [M,2N] fp16 (packed) */
   void* ws; int64_t ws_bytes;    /* optional scratch: lets small-M / long-K problems split K over blocks (fp32 partials,
                                   * fixed-order reduction => deterministic); NULL disables */
 } tb_gemm_desc;

@@ -267,3 +267,22 @@ def test_gelu_epilogues_and_kpl_mse():
     (0.1 * 512 * ref).backward()
     torch.testing.assert_close(loss[0], ref.detach(), rtol=1e-4, atol=1e-6)
     assert rel_err(dh, hr.grad) < 1e-5
+
+
+def test_geglu_grad_epilogue_matches_separate_kernel():
+    ops, L = _ops()
+    from tests.test_gpu_gemm import pack_geglu
+    torch.manual_seed(8)
+    M, C = 200, 64
+    inner = 4 * C
+    dY = torch.randn(M, C, device=dev).half()
+    Wd = (torch.randn(inner, C, device=dev) / 8).half()           # ff.net.2.weight^T : [4C, C]
+    proj = torch.randn(M, 2 * inner, device=dev).half()
+    raw = pack_geglu(proj.T.contiguous()).T.contiguous()
+    dproj = torch.empty(M, 2 * inner, device=dev, dtype=torch.float16)
+    ops.gemm(dY, Wd, dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
+    dgated = (dY.float() @ Wd.float().T)
+    pr = proj.float().requires_grad_(True)
+    hh, gg = pr.chunk(2, dim=-1)
+    (hh * F.gelu(gg)).backward(dgated)
+    assert rel_err(dproj, pack_geglu(pr.grad.T.contiguous()).T) < 3e-3

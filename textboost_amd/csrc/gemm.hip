@@ -79,8 +79,25 @@ __device__ __forceinline__ void epi_load_r8(const tb_gemm_desc& p, const EpiFlag
     }
   }
 }
+// second auxiliary vector: the g half of the packed pre-gate projections for GEGLU_GRAD (h comes through epi_load_aux8)
+__device__ __forceinline__ f16x8 epi_load_aux8b(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n) {
+  f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.act != TB_ACT_GEGLU_GRAD) return a;
+  const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + (n >> 5) * 64 + (n & 31) + 32;
+  if (f.c2_vec) return *(const f16x8*)c2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = c2[e];
+  return a;
+}
 __device__ __forceinline__ f16x8 epi_load_aux8(const tb_gemm_desc& p, const EpiFlags& f, int64_t m, int64_t n) {
   f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.act == TB_ACT_GEGLU_GRAD) {
+    const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + (n >> 5) * 64 + (n & 31);
+    if (f.c2_vec) return *(const f16x8*)c2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = c2[e];
+    return a;
+  }
   if (p.act != TB_ACT_QUICK_GELU_GRAD && p.act != TB_ACT_GELU_GRAD) return a;
   const f16* c2 = (const f16*)p.C2 + m * p.ldc2 + n;
   if (n + 7 < p.N && f.c2_vec) return *(const f16x8*)c2;
@@ -140,6 +157,31 @@ __device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags&
   } else if (p.act == TB_ACT_GELU_GRAD) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad_f((float)aux[e]);
+  }
+  if (p.act == TB_ACT_GEGLU_GRAD) {
+    // v = d(gated)[m, n..n+7]; C2 = packed pre-gate projections [M, 2N] ([h32|g32] blocks); C = d(proj) [M, 2N], same packing:
+    // d h = v * gelu(g),  d g = v * h * gelu'(g)          (backward of diffusers GEGLU fused into the ff.net.2 dgrad GEMM)
+    const int64_t pc = (n >> 5) * 64 + (n & 31);  // packed column of h for gate column n
+    f16* c = (f16*)p.C + m * p.ldc + pc;
+    const f16x8 hh = aux, gg = epi_load_aux8b(p, f, m, n);
+    f16x8 dh, dg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float g = (float)gg[e];
+      dh[e] = (f16)(v[e] * gelu_erf_f(g));
+      dg[e] = (f16)(v[e] * (float)hh[e] * gelu_erf_grad_f(g));
+    }
+    if (f.c_vec) {
+      *(f16x8*)c = dh;
+      *(f16x8*)(c + 32) = dg;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        c[e] = dh[e];
+        c[32 + e] = dg[e];
+      }
+    }
+    return;
   }
   if (p.c_dtype == TB_F32) {
     float* c = (float*)p.C + m * p.ldc + n;
@@ -632,8 +674,9 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if (((uintptr_t)d.A) % 16 || ((uintptr_t)d.W) % 16 || ((uintptr_t)d.A2) % 16 || ((uintptr_t)d.W2) % 16) return TB_EINVAL;
   if (d.rowbias && d.rows_per_group <= 0) return TB_EINVAL;
   if (d.rowbias && d.ldrb < d.N) d.ldrb = d.N;
-  if ((d.act == TB_ACT_QUICK_GELU_GRAD || d.act == TB_ACT_GELU_GRAD) && !d.C2) return TB_EINVAL;
-  if (d.act < 0 || d.act > TB_ACT_GELU_GRAD) return TB_EINVAL;
+  if ((d.act == TB_ACT_QUICK_GELU_GRAD || d.act == TB_ACT_GELU_GRAD || d.act == TB_ACT_GEGLU_GRAD) && !d.C2) return TB_EINVAL;
+  if (d.act == TB_ACT_GEGLU_GRAD && (d.N % 32 || d.c_dtype != TB_F16)) return TB_EINVAL;
+  if (d.act < 0 || d.act > TB_ACT_GEGLU_GRAD) return TB_EINVAL;
   if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;
     if (d.M != (int64_t)d.B * d.Hout * d.Wout) return TB_EINVAL;

@@ -77,7 +77,7 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
     conv = dict(B,Hin,Win,Cin,Hout,Wout,stride,sign,upsample,transposed) switches A to an NHWC 3x3 gather."""
     d = L.GemmDesc()
-    M, Nout = out.shape
+    M = out.shape[0]
     N = W.shape[0]
     d.M, d.N = M, N
     d.A, d.lda = L.ptr(A), A.stride(0)

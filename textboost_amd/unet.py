@@ -26,6 +26,10 @@ from . import _lib as L
 from . import ops
 
 
+import os as _os
+FUSE_GEGLU_BWD = _os.environ.get("TB_FUSE_GEGLU_BWD", "0") == "1"  # measured slower than the streaming kernel on MI355X
+
+
 @dataclass
 class UNetGeometry:
     in_channels: int = 4
@@ -315,10 +319,13 @@ class HipUNet:
         def bwd(dout, dx):
             dt3 = self.scratch("g1", M, C)
             ops.gemm(dout, P[prefix + ".proj_out.wd"], dt3)
-            dgated = self.scratch("gb", M, 4 * C)
-            ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dgated)
             dproj = self.scratch("gc", M, 8 * C)
-            ops.geglu_bwd(dgated, raw, dproj)
+            if FUSE_GEGLU_BWD:   # ff.net.2 dgrad with the GEGLU backward fused into its epilogue
+                ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
+            else:
+                dgated = self.scratch("gb", M, 4 * C)
+                ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dgated)
+                ops.geglu_bwd(dgated, raw, dproj)
             dl3 = self.scratch("g2", M, C)
             ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
             dt2 = self.scratch("g3", M, C)
