@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  (must be imported first so libamdhip64.so.7 resolves to the runtime torch uses)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtextboost_hip.so")
+LIB_PATH = os.path.join(_PKG, "libtextboost_hip" + os.environ.get("TB_LIB_SUFFIX", "") + ".so")
 
 TB_F16, TB_F32 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD, ACT_GELU, ACT_GELU_GRAD, ACT_GEGLU_GRAD = 0, 1, 2, 3, 4, 5, 6, 7

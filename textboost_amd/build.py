@@ -11,7 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libtextboost_hip.so")
+# kernel-tuning A/B: TB_LIB_SUFFIX=_alt TB_CFLAGS="-DTB_SOMETHING=1" builds / loads a second library next to the default one
+SUFFIX = os.environ.get("TB_LIB_SUFFIX", "")
+LIB = os.path.join(PKG, f"libtextboost_hip{SUFFIX}.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics"]
 
 
@@ -26,7 +28,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
     newest_hdr = max([os.path.getmtime(h) for h in hdrs] + [0.0])
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, "build" + SUFFIX)
+    extra = os.environ.get("TB_CFLAGS", "").split()
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -35,7 +38,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_hdr):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *extra, "-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

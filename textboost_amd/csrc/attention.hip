@@ -13,6 +13,7 @@
 // reading the A operand (V^T, staged transposed in LDS) with the same permutation, so no cross-lane traffic is
 // needed between the two matmuls.  The backward kernels use the same idea (lane owns a query in the dQ kernel,
 // a key in the dK/dV kernel).
+#define TB_ATTN_FUSED_DELTA 1  // A/B on MI355X: delta = rowsum(dO*O) inside the dQ kernel, +1.0 % steps/s vs its own launch
 #include "common.h"
 #include "../../include/textboost_hip.h"
 
@@ -281,7 +282,26 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dq_kernel(con
   const bool qok = q < p.Sq;
   const int64_t sidx = ((int64_t)b * p.H + h) * p.Sq + (qok ? q : 0);
   const float lse2 = p.LSE[sidx] * LOG2E;
+#ifdef TB_ATTN_FUSED_DELTA
+  float delta;  // rowsum(dO * O) computed here and published for the dK/dV kernel that runs next on the stream
+  {
+    const f16* Og = (const f16*)p.O + (int64_t)b * p.Sq * p.ldo + h * p.hd;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int col = 16 * j + 8 * hi;
+      if (qok && col < p.hd) {
+        const f16x8 ov = *(const f16x8*)(Og + (int64_t)q * p.ldo + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)ov[e] * (float)dof[j][e];
+      }
+    }
+    delta = a + __shfl_xor(a, 32, 64);
+    if (qok && hi == 0) p.Delta[sidx] = delta;
+  }
+#else
   const float delta = p.Delta[sidx];
+#endif
   const float c = p.scale * LOG2E;
   f32x16 dq[DT];
 #pragma unroll
@@ -537,10 +557,12 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
 template <int DT, int KS>
 int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
+#ifndef TB_ATTN_FUSED_DELTA
   {
     int64_t total = (int64_t)d.B * d.Sq * d.H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
   }
+#endif
   {
     size_t lds = (2 * RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16);
     static bool attr_done = false;

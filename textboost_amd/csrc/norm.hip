@@ -6,6 +6,7 @@
 // Replaces torch.nn.GroupNorm / F.silu / torch.nn.LayerNorm (and their autograd) that diffusers' ResnetBlock2D,
 // Transformer2DModel, BasicTransformerBlock and transformers' CLIPEncoderLayer dispatch from
 // train_textboost.py:1063-1067 (forward) and :1108 (backward).
+#define TB_GN_INBLOCK 1  // A/B on MI355X (same box, bench.py): in-block finalize +0.6 % steps/s vs a separate finalize launch
 #include "common.h"
 #include "../../include/textboost_hip.h"
 
@@ -146,6 +147,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+#ifdef TB_GN_INBLOCK
+// In-block version of the finalize step (saves a launch): all 256 threads sum the chunk partials of this image's groups
+__device__ __forceinline__ void gn_block_finalize(const float* __restrict__ part, int b, int HW, int C, int G, int nchunks, float eps,
+                                                  int mode, float* o0_s, float* o1_s, float (*ls)[64], float (*lq)[64]) {
+  const int g = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int gg = g0 + g;
+    float s = 0.f, q = 0.f;
+    if (gg < G)
+      for (int c = sub; c < nchunks; c += 8) {
+        const float* p = part + ((int64_t)b * nchunks + c) * G * 2 + gg * 2;
+        s += p[0];
+        q += p[1];
+      }
+    ls[sub][g] = s;
+    lq[sub][g] = q;
+    __syncthreads();
+    if (sub == 0 && gg < G) {
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        S += ls[k][g];
+        Q += lq[k][g];
+      }
+      const float n = (float)(C / G) * (float)HW;
+      if (mode == 0) {
+        const float mean = S / n;
+        o0_s[gg] = mean;
+        o1_s[gg] = rsqrtf(fmaxf(Q / n - mean * mean, 0.f) + eps);
+      } else {
+        o0_s[gg] = S / n;
+        o1_s[gg] = Q / n;
+      }
+    }
+    __syncthreads();
+  }
+}
+#endif
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ part, float* __restrict__ stats, int HW, int C,
@@ -154,11 +194,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ X
   const GnMap mp(C);
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int gs = C / G;
+#ifdef TB_GN_INBLOCK
+  __shared__ float ls[8][64], lq[8][64];
+  gn_block_finalize(part, b, HW, C, G, nchunks, eps, 0, mean_s, rstd_s, ls, lq);
+  if (chunk == 0 && threadIdx.x < G) {
+    stats[((int64_t)b * G + threadIdx.x) * 2 + 0] = mean_s[threadIdx.x];
+    stats[((int64_t)b * G + threadIdx.x) * 2 + 1] = rstd_s[threadIdx.x];
+  }
+#else
   if (threadIdx.x < G) {
     mean_s[threadIdx.x] = stats[((int64_t)b * G + threadIdx.x) * 2 + 0];
     rstd_s[threadIdx.x] = stats[((int64_t)b * G + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
+#endif
   if (!mp.active) return;
   const int rpc = (HW + nchunks - 1) / nchunks;
   const int r_begin = chunk * rpc, r_end = min(HW, r_begin + rpc);
@@ -250,11 +299,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict
   const GnMap mp(C);
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int gs = C / G;
+#ifdef TB_GN_INBLOCK
+  __shared__ float ls[8][64], lq[8][64];
+  gn_block_finalize(part, b, HW, C, G, nchunks, 0.f, 1, s1_s, s2_s, ls, lq);
+#else
   if (threadIdx.x < G) {  // part = finalized per-(b, group) means of dyh and dyh*xhat
     s1_s[threadIdx.x] = part[((int64_t)b * G + threadIdx.x) * 2 + 0];
     s2_s[threadIdx.x] = part[((int64_t)b * G + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
+#endif
   if (!mp.active) return;
   const int rpc = (HW + nchunks - 1) / nchunks;
   const int r_begin = chunk * rpc, r_end = min(HW, r_begin + rpc);
@@ -451,7 +505,9 @@ extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, ws, HW, C, G, nch);
+#ifndef TB_GN_INBLOCK
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, stats, HW, C, G, nch, eps, 0);
+#endif
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, ws, stats, HW, C,
                      G, nch, eps, silu);
   TB_CHECK_LAUNCH();
@@ -468,8 +524,12 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
                      ws, HW, C, G, nch, silu);
+#ifdef TB_GN_INBLOCK
+  float* fin = ws;
+#else
   float* fin = ws + (int64_t)B * nch * G * 2;  // finalized sums live behind the partials
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, fin, HW, C, G, nch, 0.f, 1);
+#endif
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
                      fin, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, nch, silu);
   TB_CHECK_LAUNCH();
