@@ -261,8 +261,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const tb_attn_desc p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+#ifndef TB_DQ_OCC
+#define TB_DQ_OCC 2
+#endif
 template <int DT, int KS>
-__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p) {
+__global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);

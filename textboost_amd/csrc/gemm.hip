@@ -284,7 +284,12 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
   int tile, slice;
   {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+#ifdef TB_GEMM_NO_XCD
+    const int logical = bid;
+    (void)xcd; (void)q; (void)r;
+#else
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#endif
     tile = logical / S;       // the S k-slices of one tile are adjacent (same XCD)
     slice = logical - tile * S;
   }
@@ -425,11 +430,13 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
         const int row = j * 32 + l31;
         bf[j] = *(const f16x8*)(Bb + row * BK + ((ch ^ SWZ(row)) << 3));
       }
+      __builtin_amdgcn_s_setprio(1);  // +0.2..0.5 % in situ: MFMA bursts win arbitration over the co-resident block's loads
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)  // transposed accumulator: rows = n (from W), cols = m (from A)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
   };
   if constexpr (NST == 2) {
@@ -642,7 +649,10 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
     if (want > fit) want = fit;
     if (want > 1) S = (int)want;
   }
-  if (S == 1 && blocks < 192) return launch<64, 64, MODE>(d, s);  // small problems without workspace: smaller tiles
+#ifndef TB_SMALL_TILE_BLOCKS
+#define TB_SMALL_TILE_BLOCKS 320  // A/B on one MI355X: 96 -1.6 %, 192 base, 320 +1.0 %, 512 -1.0 % steps/s
+#endif
+  if (S == 1 && blocks < TB_SMALL_TILE_BLOCKS) return launch<64, 64, MODE>(d, s);  // small problems without workspace: smaller tiles
   return narrow ? launch<128, 64, MODE>(d, s, S) : launch<128, 128, MODE>(d, s, S);
 }
 
