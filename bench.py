@@ -141,7 +141,8 @@ def main():
     from textboost_amd import _lib
     _lib.lib()  # fail loudly if the HIP extension is missing
     if os.environ.get("TB_GEMM_VARIANT"):  # kernel-tuning experiments only
-        _lib.lib().tb_gemm_set_variant(int(os.environ["TB_GEMM_VARIANT"]))
+        for v in os.environ["TB_GEMM_VARIANT"].split(","):
+            _lib.lib().tb_gemm_set_variant(int(v))
     from textboost_amd.workload import build_step
 
     torch.manual_seed(42)  # the reference seeds every rank identically (train_textboost.py:601); data is offset by rank

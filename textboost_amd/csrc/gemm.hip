@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
 
 // BKT: halfs per k-tile (64 -> 128-byte LDS rows, 32 -> 64-byte rows); NST: LDS stages (2, or 3 with counted vmcnt)
 template <int BM, int BN, int MODE, int BKT, int NST>
-__global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int S, float* __restrict__ ws, int64_t npad, int abl) {
+__global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int S, float* __restrict__ ws, int64_t npad, int abl,
+                                                                              int m_fastest) {
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   f16* smem = reinterpret_cast<f16*>(smem_raw);
   constexpr int BK = BKT;
@@ -293,10 +294,25 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
     tile = logical / S;       // the S k-slices of one tile are adjacent (same XCD)
     slice = logical - tile * S;
   }
-  // walk the SMALLER operand fastest so it stays L2-resident while the larger one streams through once per XCD
-  const bool m_fastest = MODE == TB_A_LINEAR && p.N > p.M;
-  const int64_t m0 = (int64_t)(m_fastest ? tile % tiles_m : tile / tiles_n) * BM;
-  const int64_t n0 = (int64_t)(m_fastest ? tile / tiles_m : tile % tiles_n) * BN;
+  // tile order (host cost model, see launch_v): keep one operand's panel L2-resident while the other streams through the XCD
+  int tm, tn;
+  if (m_fastest == 3) {  // grouped: 8 M-tiles x all N-tiles, M fastest inside the group -> the ~64 blocks that run together on one
+                         // XCD form an 8 x 8 patch of the tile grid (8 A-panel + 8 W-panel k-slices shared through its L2)
+    const int gsize = 8 * tiles_n;
+    const int gid = tile / gsize, first_m = gid * 8;
+    const int gm = min(tiles_m - first_m, 8);
+    const int in_g = tile - gid * gsize;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  } else if (m_fastest) {
+    tm = tile % tiles_m;
+    tn = tile / tiles_m;
+  } else {
+    tm = tile / tiles_n;
+    tn = tile % tiles_n;
+  }
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
 
   const int cp = lane % CPR;  // 16-byte chunk position inside the LDS row this lane fills
   const int rl = lane / CPR;  // row within the row group of one load instruction
@@ -593,6 +609,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
 }
 
 int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
+int g_order = 0;    // tile order: 0 = 8-row groups (default), 1 = n-fastest, 2 = m-fastest (tb_gemm_set_variant(3000 + v))
 int g_ablate = 0;   // profiling only (tb_gemm_set_variant(2000 + bits)): 1 = skip k-loop loads, 2 = skip k-loop MFMAs
 int g_variant = 0;  // tuning knob (tb_gemm_set_variant): 0 = BK64 x 2 stages, 1 = BK32 x 3 stages, 2 = BK32 x 2 stages
 
@@ -610,8 +627,11 @@ int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
       return TB_ELAUNCH;
     attr_done = true;
   }
+  // tile order inside each XCD's contiguous range (A/B in situ on one MI355X: n-fastest 22.39, m-fastest 21.62, a bytes-to-fabric
+  // cost model 22.11, 8-row groups 22.55 steps/s): what matters is that the ~64 blocks co-resident on an XCD share few k-slices
+  const int m_fastest = g_order == 0 ? 3 : (g_order == 2 ? 1 : 0);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, BKT, NST>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, d, tiles_m,
-                     tiles_n, S, (float*)d.ws, npad, g_ablate);
+                     tiles_n, S, (float*)d.ws, npad, g_ablate, m_fastest);
   if (S > 1)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
                        npad);
@@ -664,7 +684,8 @@ extern "C" void tb_gemm_last_config(int* out5) {
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
-  if (v >= 2000) g_ablate = v - 2000;
+  if (v >= 3000) g_order = v - 3000;
+  else if (v >= 2000) g_ablate = v - 2000;
   else if (v >= 1000) g_split_target = v - 1000;  // 1000 disables split-K, 1512 = default target of 512 blocks
   else g_variant = v;
   return old;
