@@ -117,7 +117,7 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
             import ctypes
             cfg = (ctypes.c_int * 5)()
             L.lib().tb_gemm_last_config(cfg)
-            r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>" + (f"+splitk{cfg[4]}" if cfg[4] > 1 else "")
+            r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
     return out
 
 
