@@ -28,10 +28,15 @@ def roofline_leg(step):
     region; the dominant family (largest summed duration) is reported against the dense fp16 MFMA peak."""
     from textboost_amd import ops
     torch.cuda.synchronize()
+    world, force = step.world, step.force_dist
+    step.world, step.force_dist = 1, False  # rank 0 runs this leg alone: no collective may be issued here
     ops.start_recording()
-    step.step_eager()
-    torch.cuda.synchronize()
-    rec = ops.stop_recording()
+    try:
+        step.step_eager()
+        torch.cuda.synchronize()
+    finally:
+        rec = ops.stop_recording()
+        step.world, step.force_dist = world, force
     agg = {}
     for name, flops, byts, e0, e1 in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
