@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+
   const int l31 = lane & 31, hi = lane >> 5;
   auto compute = [&](int buf) {
     const f16* Ab = smem + buf * STAGE + (wm * WTM) * BK;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
   for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
     const int64_t m = m0 + row0 + it * RS;
     const int64_t mm = m < p.M ? m : p.M - 1;
-    epi_load_r8(p, ef, mm, n, r8[it]);
+      epi_load_r8(p, ef, mm, n, r8[it]);
     aux[it] = epi_load_aux8(p, ef, mm, n);
   }
 #pragma unroll
@@ -650,7 +651,10 @@ int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
   }
 }
 
-int g_split_target = 512;  // aim for at least this many blocks (2 per CU) before splitting K  (tb_gemm_set_variant(1000 + n))
+int g_split_min_tiles = 8;   // k-tiles per slice lower bound (tb_gemm_set_variant(4000 + n))
+int g_split_blocks = 256;    // split only when the un-split grid has fewer blocks than this (5000 + n)
+int g_split_minnk = 32;      // ... and at least this many k-tiles (6000 + n)
+int g_split_target = 384;  // split K until about this many blocks exist (A/B: 256 22.7, 384 23.05, 512 22.6, 768 22.6, off 20.2 steps/s)  (tb_gemm_set_variant(1000 + n))
 
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
@@ -662,8 +666,8 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
     // too few tiles to fill 256 CUs: split K across blocks (fp32 partials in ws, fixed-order reduction -> deterministic)
     const int64_t nk = d.K / 64;
     const int64_t npad = (d.N + 7) / 8 * 8;
-    int64_t want = blocks < 192 && nk >= 32 ? (g_split_target + blocks - 1) / blocks : 1;  // short K: a second pass costs more
-    if (want > nk / 8) want = nk / 8;  // keep >= 8 k-tiles per slice
+    int64_t want = blocks < g_split_blocks && nk >= g_split_minnk ? (g_split_target + blocks - 1) / blocks : 1;  // short K: a second pass costs more
+    if (want > nk / g_split_min_tiles) want = nk / g_split_min_tiles;
     if (want > 16) want = 16;
     const int64_t fit = d.ws_bytes / (int64_t)(d.M * npad * sizeof(float));
     if (want > fit) want = fit;
@@ -684,7 +688,10 @@ extern "C" void tb_gemm_last_config(int* out5) {
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
-  if (v >= 3000) g_order = v - 3000;
+  if (v >= 6000) g_split_minnk = v - 6000;
+  else if (v >= 5000) g_split_blocks = v - 5000;
+  else if (v >= 4000) g_split_min_tiles = v - 4000;
+  else if (v >= 3000) g_order = v - 3000;
   else if (v >= 2000) g_ablate = v - 2000;
   else if (v >= 1000) g_split_target = v - 1000;  // 1000 disables split-K, 1512 = default target of 512 blocks
   else g_variant = v;
