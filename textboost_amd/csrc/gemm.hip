@@ -659,7 +659,11 @@ int g_split_target = 384;  // split K until about this many blocks exist (A/B: 2
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
   // N that is an odd multiple of 64 (320, 960, ...) tiles exactly with BN = 64
+#ifdef TB_NO_NARROW
+  const bool narrow = false;
+#else
   const bool narrow = (d.N % 128) != 0 && (d.N % 128) <= 64;
+#endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
   int S = 1;
   if (blocks < 384 && d.ws && g_split_target > 0) {
