@@ -46,7 +46,7 @@ def roofline_leg(step):
         a[3] += byts
     # the roofline object is about ONE kernel symbol: candidates are the single-kernel records (the attention-backward and
     # GroupNorm entry points launch 2-3 kernels per call and are listed in the table only)
-    single = {k: v for k, v in agg.items() if k.startswith("gemm_kernel<") or k == "attn_fwd_kernel"}
+    single = {k: v for k, v in agg.items() if k.startswith(("gemm_kernel<", "conv_halo_kernel<")) or k == "attn_fwd_kernel"}
     dom = max(single.items(), key=lambda kv: kv[1][1])
     name, (n, t, fl, _) = dom
     table = {k: {"launches": v[0], "total_ms": round(v[1] * 1e3, 3), "avg_us": round(v[1] / v[0] * 1e6, 2),

@@ -163,3 +163,34 @@ def test_gemm_rejects_bad_args():
     out = torch.zeros(8, 8, device="cuda", dtype=torch.float16)
     with pytest.raises(RuntimeError):
         ops.gemm(A, W, out)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(8, 64, 128, 64, 64), (8, 128, 320, 64, 64), (8, 64, 640, 32, 32), (8, 64, 2048, 16, 16),
+                                            (2, 192, 1280, 64, 64)])
+def test_conv3x3_halo_kernel_fwd_and_dgrad(B, Cin, Cout, H, W):
+    """shapes that take the LDS-halo path (whole image rows per 128-pixel tile, >= 256 tiles), checked against F.conv2d and
+    against the per-tap gather kernel (halo path switched off)."""
+    ops, L = _ops()
+    torch.manual_seed(7)
+    x = torch.randn(B, Cin, H, W, device="cuda").half()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    res = torch.randn(B * H * W, Cout, device="cuda").half()
+    xn = nhwc(x).view(B * H * W, Cin)
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cin, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=0)
+    outs = []
+    for halo in (1, 0):
+        L.lib().tb_gemm_set_variant(7000 + halo)
+        out = torch.empty(B * H * W, Cout, device="cuda", dtype=torch.float16)
+        ops.gemm(xn, pack_conv_w(w), out, bias=bias, R=res, conv=geo)
+        outs.append(out)
+    L.lib().tb_gemm_set_variant(7001)
+    ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * W, Cout) + res.float()
+    assert rel_err(outs[0], ref) < 2e-3
+    assert rel_err(outs[0], outs[1]) < 1e-3   # same products, different fp32 summation order (chunk-outer vs tap-outer)
+    dy = torch.randn(B, Cout, H, W, device="cuda").half()
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cout, Hout=H, Wout=W, stride=1, sign=-1, upsample=0, transposed=0)
+    dx = torch.empty(B * H * W, Cin, device="cuda", dtype=torch.float16)
+    ops.gemm(nhwc(dy).view(B * H * W, Cout), pack_conv_w_dgrad(w), dx, conv=geo)
+    refd = nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1))
+    assert rel_err(dx.view(B, H, W, Cin), refd) < 2e-3

@@ -261,6 +261,128 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
   epilogue8(p, f, m, n, v, b8, r8, aux);
 }
 
+// Shared epilogue of the MFMA kernels (gemm_kernel, conv_halo_kernel): accumulators -> LDS -> coalesced global writes.
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, int64_t m0, int64_t n0,
+                                              int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+  // ---- epilogue, staged through LDS so every global access is a full 16-byte, row-contiguous vector:
+  //  (a) each lane owns row m = .. + l31 and, per register quad r4, 4 consecutive columns: dump raw fp32 accumulators into
+  //      Cs[BM][BN] (16-byte chunks XOR-swizzled by row & 7: conflict-free for these writes and for the row reads below);
+  //  (b) barrier; (c) thread t walks (row, 8-column group) units: bias / residual / activation / stores in 16-byte vectors.
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = wm * WTM + i * 32 + l31;
+        const int ch = (wn * WTN + j * 32 + 8 * r4 + 4 * hi) >> 2;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
+        *(f32x4*)(Cs + row * BN + ((ch ^ (row & 7)) << 2)) = o;
+      }
+  __syncthreads();
+  const EpiFlags ef = epi_flags(p);
+  if (p.act == TB_ACT_GEGLU) {
+    // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
+    constexpr int UPR = BN / 16;  // units per row
+    for (int u = t; u < BM * UPR; u += 256) {
+      const int row = u / UPR, og = u - row * UPR;
+      const int64_t m = m0 + row;
+      if (m >= p.M) continue;
+      const int hcol = (og >> 2) * 64 + (og & 3) * 8;  // tile-local packed column of h; g is +32
+      float vh[8], vg[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 a = *(const f32x4*)(Cs + row * BN + ((((hcol >> 2) + q) ^ (row & 7)) << 2));
+        const f32x4 b = *(const f32x4*)(Cs + row * BN + (((((hcol + 32) >> 2) + q) ^ (row & 7)) << 2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vh[4 * q + e] = a[e];
+          vg[4 * q + e] = b[e];
+        }
+      }
+      const int64_t nh = n0 + hcol;
+      f16x8 oh, og8, oo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        oh[e] = (f16)(p.alpha * vh[e] + (p.bias ? p.bias[nh + e] : 0.f));
+        og8[e] = (f16)(p.alpha * vg[e] + (p.bias ? p.bias[nh + 32 + e] : 0.f));
+        // gate on the fp16-rounded projections, as a fp16 module would (diffusers GEGLU on fp16 tensors)
+        oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));
+      }
+      if (p.C2) {
+        f16* c2 = (f16*)p.C2 + m * p.ldc2 + nh;
+        if (ef.c2_vec) {
+          *(f16x8*)c2 = oh;
+          *(f16x8*)(c2 + 32) = og8;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            c2[e] = oh[e];
+            c2[32 + e] = og8[e];
+          }
+        }
+      }
+      f16* c = (f16*)p.C + m * p.ldc + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
+      if (ef.c_vec) *(f16x8*)c = oo;
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = oo[e];
+      }
+    }
+    return;
+  }
+  constexpr int UPR = BN / 8;          // (row, 8-column) units per row
+  constexpr int RS = 256 / UPR;        // rows covered per pass of the 256 threads
+  constexpr int NU = BM / RS;          // units per thread: same column group, rows row0 + it*RS
+  const int cg = t % UPR, row0 = t / UPR;
+  const int64_t n = n0 + cg * 8;
+  if (n >= p.N) return;
+  if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+      const int row = row0 + it * RS;
+      const int64_t m = m0 + row;
+      if (m >= p.M) continue;
+      float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+    }
+    return;
+  }
+  float b8[8];
+  epi_load_bias8(p, n, b8);
+  float r8[NU][8];
+  f16x8 aux[NU];
+#pragma unroll
+  for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
+    const int64_t m = m0 + row0 + it * RS;
+    const int64_t mm = m < p.M ? m : p.M - 1;
+      epi_load_r8(p, ef, mm, n, r8[it]);
+    aux[it] = epi_load_aux8(p, ef, mm, n);
+  }
+#pragma unroll
+  for (int it = 0; it < NU; ++it) {
+    const int row = row0 + it * RS;
+    const int64_t m = m0 + row;
+    if (m >= p.M) continue;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 a = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
+    }
+    epilogue8(p, ef, m, n, v, b8, r8[it], aux[it]);
+  }
+}
+
 // BKT: halfs per k-tile (64 -> 128-byte LDS rows, 32 -> 64-byte rows); NST: LDS stages (2, or 3 with counted vmcnt)
 template <int BM, int BN, int MODE, int BKT, int NST>
 __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int S, float* __restrict__ ws, int64_t npad, int abl,
@@ -492,125 +614,159 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
   }
 #undef SWZ
 
-  // ---- epilogue, staged through LDS so every global access is a full 16-byte, row-contiguous vector:
-  //  (a) each lane owns row m = .. + l31 and, per register quad r4, 4 consecutive columns: dump raw fp32 accumulators into
-  //      Cs[BM][BN] (16-byte chunks XOR-swizzled by row & 7: conflict-free for these writes and for the row reads below);
-  //  (b) barrier; (c) thread t walks (row, 8-column group) units: bias / residual / activation / stores in 16-byte vectors.
   if (abl & 4) return;  // profiling: no epilogue
-  float* Cs = reinterpret_cast<float*>(smem_raw);
+  tile_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with an LDS-resident input HALO tile (used when a 128-pixel output tile is a whole number of image
+// rows): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
+// fragments from that halo at shifted row addresses; only the weight tiles stream per tap.  Compared with gemm_kernel's
+// per-tap gather this moves 4.4x fewer activation bytes through the L2->LDS path that bounds the kernel.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int S,
+                                                             float* __restrict__ ws, int64_t npad) {
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
+  f16* smem = reinterpret_cast<f16*>(smem_raw);
+  constexpr int BM = 128, BK = 64;
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+  constexpr int BI = BN / 32;  // weight-tile load instructions per wave per tap
+  constexpr int MAXHI = 9;     // halo load instructions per wave (<= ceil(33 / 4))
+#define SWZ(row) ((((row) >> 1) & 7))
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int W = 1 << wshift, H = p.Hout, R = BM >> wshift;
+  const int HC = W + 2, NH = (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
+  f16* Hs = smem;
+  f16* Wst = smem + NH8 * BK;  // two weight stages of BN x 64 halfs
+
+  const int nwg = tiles_m * tiles_n * S;
+  int tile, slice;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile = logical / S;  // the S channel-chunk slices of one tile are adjacent (same XCD)
+    slice = logical - tile * S;
+  }
+  int tm, tn;
+  {
+    const int gsize = 8 * tiles_n;
+    const int gid = tile / gsize, first_m = gid * 8;
+    const int gm = min(tiles_m - first_m, 8);
+    const int in_g = tile - gid * gsize;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int hw = H * W;
+  const int b = (int)(m0 / hw);
+  const int y0 = (int)(m0 - (int64_t)b * hw) >> wshift;  // first image row of the tile
+
+  const int cp = lane & 7, rl = lane >> 3;
+  // ---- halo sources of this lane (fixed across channel chunks, + 64 halfs per chunk)
+  const f16* h_ptr[MAXHI];
+  int h_step[MAXHI];
+  const f16* zero = g_zero_line;
+#pragma unroll
+  for (int i = 0; i < MAXHI; ++i) {
+    const int j = wave + 4 * i;  // instruction index; rows j*8 .. j*8+7 of the halo image
+    const int hr = j * 8 + rl;
+    const int hy = hr / HC, hx = hr - hy * HC;
+    const int yy = y0 - 1 + hy, xx = hx - 1;
+    const bool ok = j < NI && hr < NH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    h_ptr[i] = ok ? (const f16*)p.A + ((int64_t)b * hw + (int64_t)yy * W + xx) * p.lda + ((cp ^ SWZ(hr)) << 3) : zero;
+    h_step[i] = ok ? BK : 0;
+  }
+  const f16* w_ptr[BI];
+  bool w_ok[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = wave * (BN / 4) + i * 8 + rl;
+    const int64_t n = n0 + row;
+    w_ok[i] = n < p.N;
+    w_ptr[i] = (const f16*)p.W + (w_ok[i] ? n : 0) * p.ldw + ((cp ^ SWZ(row)) << 3);
+  }
+  const int kpt = p.Cin / BK;
+  const int c_begin = (int)((int64_t)kpt * slice / S), c_end = (int)((int64_t)kpt * (slice + 1) / S);
+
+  auto stage_halo = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < MAXHI; ++i) {
+      const int j = wave + 4 * i;
+      if (j < NI) glds16(h_ptr[i] + (int64_t)c * h_step[i], Hs + j * 8 * BK);
+    }
+  };
+  auto stage_w = [&](int tap, int c, int buf) {
+    f16* dst = Wst + buf * (BN * BK) + (wave * (BN / 4)) * BK;
+    const int koff = (tap * kpt + c) * BK;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) glds16(w_ok[i] ? w_ptr[i] + koff : zero, dst + i * 8 * BK);
+  };
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = wm * WTM + i * 32 + l31;
-        const int ch = (wn * WTN + j * 32 + 8 * r4 + 4 * hi) >> 2;
-        f32x4 o;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  int hrow0[TM];  // halo row of this lane's output pixel for tap offset (0, 0)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
-        *(f32x4*)(Cs + row * BN + ((ch ^ (row & 7)) << 2)) = o;
-      }
-  __syncthreads();
-  const EpiFlags ef = epi_flags(p);
-  if (p.act == TB_ACT_GEGLU) {
-    // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
-    constexpr int UPR = BN / 16;  // units per row
-    for (int u = t; u < BM * UPR; u += 256) {
-      const int row = u / UPR, og = u - row * UPR;
-      const int64_t m = m0 + row;
-      if (m >= p.M) continue;
-      const int hcol = (og >> 2) * 64 + (og & 3) * 8;  // tile-local packed column of h; g is +32
-      float vh[8], vg[8];
+  for (int i = 0; i < TM; ++i) {
+    const int ml = wm * WTM + i * 32 + l31;
+    hrow0[i] = (ml >> wshift) * HC + (ml & (W - 1));
+  }
+
+  for (int c = c_begin; c < c_end; ++c) {
+    // every wave has left the previous chunk's last tap (barrier there), so the halo and weight stage 0 may be overwritten
+    stage_halo(c);
+    stage_w(0, c, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < 9) stage_w(tap + 1, c, cur ^ 1);
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int dy = p.sign > 0 ? ky : 2 - ky, dx = p.sign > 0 ? kx : 2 - kx;  // dgrad gathers with flipped offsets
+      const int shift = dy * HC + dx;
+      const f16* Bb = Wst + cur * (BN * BK) + (wn * WTN) * BK;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 a = *(const f32x4*)(Cs + row * BN + ((((hcol >> 2) + q) ^ (row & 7)) << 2));
-        const f32x4 b = *(const f32x4*)(Cs + row * BN + (((((hcol + 32) >> 2) + q) ^ (row & 7)) << 2));
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        f16x8 af[TM], bf[TN];
+        const int ch = kk * 2 + hi;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vh[4 * q + e] = a[e];
-          vg[4 * q + e] = b[e];
+        for (int i = 0; i < TM; ++i) {
+          const int row = hrow0[i] + shift;
+          af[i] = *(const f16x8*)(Hs + row * BK + ((ch ^ SWZ(row)) << 3));
         }
-      }
-      const int64_t nh = n0 + hcol;
-      f16x8 oh, og8, oo;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        oh[e] = (f16)(p.alpha * vh[e] + (p.bias ? p.bias[nh + e] : 0.f));
-        og8[e] = (f16)(p.alpha * vg[e] + (p.bias ? p.bias[nh + 32 + e] : 0.f));
-        // gate on the fp16-rounded projections, as a fp16 module would (diffusers GEGLU on fp16 tensors)
-        oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));
-      }
-      if (p.C2) {
-        f16* c2 = (f16*)p.C2 + m * p.ldc2 + nh;
-        if (ef.c2_vec) {
-          *(f16x8*)c2 = oh;
-          *(f16x8*)(c2 + 32) = og8;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            c2[e] = oh[e];
-            c2[32 + e] = og8[e];
-          }
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 32 + l31;
+          bf[j] = *(const f16x8*)(Bb + row * BK + ((ch ^ SWZ(row)) << 3));
         }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
       }
-      f16* c = (f16*)p.C + m * p.ldc + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
-      if (ef.c_vec) *(f16x8*)c = oo;
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) c[e] = oo[e];
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    return;
   }
-  constexpr int UPR = BN / 8;          // (row, 8-column) units per row
-  constexpr int RS = 256 / UPR;        // rows covered per pass of the 256 threads
-  constexpr int NU = BM / RS;          // units per thread: same column group, rows row0 + it*RS
-  const int cg = t % UPR, row0 = t / UPR;
-  const int64_t n = n0 + cg * 8;
-  if (n >= p.N) return;
-  if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
-#pragma unroll
-    for (int it = 0; it < NU; ++it) {
-      const int row = row0 + it * RS;
-      const int64_t m = m0 + row;
-      if (m >= p.M) continue;
-      float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
-    }
-    return;
-  }
-  float b8[8];
-  epi_load_bias8(p, n, b8);
-  float r8[NU][8];
-  f16x8 aux[NU];
-#pragma unroll
-  for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
-    const int64_t m = m0 + row0 + it * RS;
-    const int64_t mm = m < p.M ? m : p.M - 1;
-      epi_load_r8(p, ef, mm, n, r8[it]);
-    aux[it] = epi_load_aux8(p, ef, mm, n);
-  }
-#pragma unroll
-  for (int it = 0; it < NU; ++it) {
-    const int row = row0 + it * RS;
-    const int64_t m = m0 + row;
-    if (m >= p.M) continue;
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f32x4 a = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
-    }
-    epilogue8(p, ef, m, n, v, b8, r8[it], aux[it]);
-  }
+#undef SWZ
+  tile_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
 }
+
 
 int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
 int g_order = 0;    // tile order: 0 = 8-row groups (default), 1 = n-fastest, 2 = m-fastest (tb_gemm_set_variant(3000 + v))
+int g_halo = 1;     // 3x3 stride-1 convs on whole image rows use conv_halo_kernel (tb_gemm_set_variant(7000 + {0,1}))
 int g_ablate = 0;   // profiling only (tb_gemm_set_variant(2000 + bits)): 1 = skip k-loop loads, 2 = skip k-loop MFMAs
 int g_variant = 0;  // tuning knob (tb_gemm_set_variant): 0 = BK64 x 2 stages, 1 = BK32 x 3 stages, 2 = BK32 x 2 stages
 
@@ -656,6 +812,30 @@ int g_split_blocks = 256;    // split only when the un-split grid has fewer bloc
 int g_split_minnk = 32;      // ... and at least this many k-tiles (6000 + n)
 int g_split_target = 384;  // split K until about this many blocks exist (A/B: 256 22.7, 384 23.05, 512 22.6, 768 22.6, off 20.2 steps/s)  (tb_gemm_set_variant(1000 + n))
 
+template <int BN>
+int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
+  const int tiles_m = (int)(d.M / 128), tiles_n = (int)((d.N + BN - 1) / BN);
+  const int W = 1 << wshift, R = 128 >> wshift;
+  const int nh8 = ((R + 2) * (W + 2) + 7) & ~7;
+  size_t lds = (size_t)nh8 * 128 + 2 * (size_t)BN * 128;
+  if (lds < (size_t)128 * BN * sizeof(float)) lds = (size_t)128 * BN * sizeof(float);
+  g_last_cfg[0] = 128, g_last_cfg[1] = BN, g_last_cfg[2] = 2, g_last_cfg[3] = 642, g_last_cfg[4] = S;
+  const int64_t npad = (d.N + 7) / 8 * 8;
+  static bool attr_done = false;
+  if (!attr_done && lds > 65536) {
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return TB_ELAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<BN>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, d, tiles_m, tiles_n, wshift, S,
+                     (float*)d.ws, npad);
+  if (S > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
+                       npad);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
   // N that is an odd multiple of 64 (320, 960, ...) tiles exactly with BN = 64
@@ -665,6 +845,23 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
   const bool narrow = (d.N % 128) != 0 && (d.N % 128) <= 64;
 #endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
+  if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && d.Hin == d.Hout && d.Win == d.Wout &&
+      (d.Wout == 16 || d.Wout == 32 || d.Wout == 64) && ((int64_t)d.Hout * d.Wout) % 128 == 0) {
+    // too few tiles for 256 CUs: split the 64-channel chunks over S blocks per tile (fp32 partials + the split-K reducer)
+    int Sh = 1;
+    const int kpt = d.Cin / 64;
+    if (blocks < 256 && d.ws) {
+      int64_t want = (g_split_target + blocks - 1) / blocks;
+      if (want > kpt / 2) want = kpt / 2;  // >= 2 chunks (18 k-tiles) per slice
+      const int64_t fit = d.ws_bytes / (int64_t)(d.M * ((d.N + 7) / 8 * 8) * sizeof(float));
+      if (want > fit) want = fit;
+      if (want > 1) Sh = (int)want;
+    }
+    if (blocks * Sh >= 200) {
+      const int wshift = d.Wout == 64 ? 6 : (d.Wout == 32 ? 5 : 4);
+      return narrow ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
+    }
+  }
   int S = 1;
   if (blocks < 384 && d.ws && g_split_target > 0) {
     // too few tiles to fill 256 CUs: split K across blocks (fp32 partials in ws, fixed-order reduction -> deterministic)
@@ -692,7 +889,8 @@ extern "C" void tb_gemm_last_config(int* out5) {
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
-  if (v >= 6000) g_split_minnk = v - 6000;
+  if (v >= 7000) g_halo = v - 7000;
+  else if (v >= 6000) g_split_minnk = v - 6000;
   else if (v >= 5000) g_split_blocks = v - 5000;
   else if (v >= 4000) g_split_min_tiles = v - 4000;
   else if (v >= 3000) g_order = v - 3000;

@@ -117,7 +117,10 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
             import ctypes
             cfg = (ctypes.c_int * 5)()
             L.lib().tb_gemm_last_config(cfg)
-            r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
+            if cfg[2] == 2:
+                r.name = f"conv_halo_kernel<{cfg[1]}>"
+            else:
+                r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
     return out
 
 
