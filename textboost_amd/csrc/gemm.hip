@@ -262,124 +262,136 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
 }
 
 // Shared epilogue of the MFMA kernels (gemm_kernel, conv_halo_kernel): accumulators -> LDS -> coalesced global writes.
-template <int BM, int BN, int TM, int TN>
+// PASSES = 2 stages the tile in two halves of BM/2 rows (the rows of the waves with wm == pass), which halves the LDS the epilogue
+// needs: with 32-wide k-tiles the operand stages then bound the block's LDS and a third / fourth block fits on the CU.
+template <int BM, int BN, int TM, int TN, int PASSES>
 __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, int64_t m0, int64_t n0,
                                               int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int PR = BM / PASSES;  // rows staged per pass
+  static_assert(PASSES == 1 || PASSES == 2, "one or two passes");
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
   // ---- epilogue, staged through LDS so every global access is a full 16-byte, row-contiguous vector:
   //  (a) each lane owns row m = .. + l31 and, per register quad r4, 4 consecutive columns: dump raw fp32 accumulators into
-  //      Cs[BM][BN] (16-byte chunks XOR-swizzled by row & 7: conflict-free for these writes and for the row reads below);
+  //      Cs[PR][BN] (16-byte chunks XOR-swizzled by row & 7: conflict-free for these writes and for the row reads below);
   //  (b) barrier; (c) thread t walks (row, 8-column group) units: bias / residual / activation / stores in 16-byte vectors.
   float* Cs = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = wm * WTM + i * 32 + l31;
-        const int ch = (wn * WTN + j * 32 + 8 * r4 + 4 * hi) >> 2;
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
-        *(f32x4*)(Cs + row * BN + ((ch ^ (row & 7)) << 2)) = o;
-      }
-  __syncthreads();
   const EpiFlags ef = epi_flags(p);
-  if (p.act == TB_ACT_GEGLU) {
-    // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
-    constexpr int UPR = BN / 16;  // units per row
-    for (int u = t; u < BM * UPR; u += 256) {
-      const int row = u / UPR, og = u - row * UPR;
-      const int64_t m = m0 + row;
-      if (m >= p.M) continue;
-      const int hcol = (og >> 2) * 64 + (og & 3) * 8;  // tile-local packed column of h; g is +32
-      float vh[8], vg[8];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 a = *(const f32x4*)(Cs + row * BN + ((((hcol >> 2) + q) ^ (row & 7)) << 2));
-        const f32x4 b = *(const f32x4*)(Cs + row * BN + (((((hcol + 32) >> 2) + q) ^ (row & 7)) << 2));
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if (PASSES == 1 || wm == pass) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vh[4 * q + e] = a[e];
-          vg[4 * q + e] = b[e];
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = (PASSES == 1 ? wm * WTM : 0) + i * 32 + l31;
+            const int ch = (wn * WTN + j * 32 + 8 * r4 + 4 * hi) >> 2;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
+            *(f32x4*)(Cs + row * BN + ((ch ^ (row & 7)) << 2)) = o;
+          }
+    }
+    __syncthreads();
+    const int64_t mp = m0 + pass * PR;  // first global row of this pass
+    if (p.act == TB_ACT_GEGLU) {
+      // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
+      constexpr int UPR = BN / 16;  // units per row
+      for (int u = t; u < PR * UPR; u += 256) {
+        const int row = u / UPR, og = u - row * UPR;
+        const int64_t m = mp + row;
+        if (m >= p.M) continue;
+        const int hcol = (og >> 2) * 64 + (og & 3) * 8;  // tile-local packed column of h; g is +32
+        float vh[8], vg[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 a = *(const f32x4*)(Cs + row * BN + ((((hcol >> 2) + q) ^ (row & 7)) << 2));
+          const f32x4 b = *(const f32x4*)(Cs + row * BN + (((((hcol + 32) >> 2) + q) ^ (row & 7)) << 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vh[4 * q + e] = a[e];
+            vg[4 * q + e] = b[e];
+          }
+        }
+        const int64_t nh = n0 + hcol;
+        f16x8 oh, og8, oo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          oh[e] = (f16)(p.alpha * vh[e] + (p.bias ? p.bias[nh + e] : 0.f));
+          og8[e] = (f16)(p.alpha * vg[e] + (p.bias ? p.bias[nh + 32 + e] : 0.f));
+          // gate on the fp16-rounded projections, as a fp16 module would (diffusers GEGLU on fp16 tensors)
+          oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));
+        }
+        if (p.C2) {
+          f16* c2 = (f16*)p.C2 + m * p.ldc2 + nh;
+          if (ef.c2_vec) {
+            *(f16x8*)c2 = oh;
+            *(f16x8*)(c2 + 32) = og8;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              c2[e] = oh[e];
+              c2[32 + e] = og8[e];
+            }
+          }
+        }
+        f16* c = (f16*)p.C + m * p.ldc + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
+        if (ef.c_vec) *(f16x8*)c = oo;
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c[e] = oo[e];
         }
       }
-      const int64_t nh = n0 + hcol;
-      f16x8 oh, og8, oo;
+    } else {
+      constexpr int UPR = BN / 8;    // (row, 8-column) units per row
+      constexpr int RS = 256 / UPR;  // rows covered per sweep of the 256 threads
+      constexpr int NU = PR / RS;    // units per thread: same column group, rows row0 + it*RS
+      const int cg = t % UPR, row0 = t / UPR;
+      const int64_t n = n0 + cg * 8;
+      if (n < p.N) {
+        if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        oh[e] = (f16)(p.alpha * vh[e] + (p.bias ? p.bias[nh + e] : 0.f));
-        og8[e] = (f16)(p.alpha * vg[e] + (p.bias ? p.bias[nh + 32 + e] : 0.f));
-        // gate on the fp16-rounded projections, as a fp16 module would (diffusers GEGLU on fp16 tensors)
-        oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));
-      }
-      if (p.C2) {
-        f16* c2 = (f16*)p.C2 + m * p.ldc2 + nh;
-        if (ef.c2_vec) {
-          *(f16x8*)c2 = oh;
-          *(f16x8*)(c2 + 32) = og8;
+          for (int it = 0; it < NU; ++it) {
+            const int row = row0 + it * RS;
+            const int64_t m = mp + row;
+            if (m >= p.M) continue;
+            float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+          }
         } else {
+          float b8[8];
+          epi_load_bias8(p, n, b8);
+          float r8[NU][8];
+          f16x8 aux[NU];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            c2[e] = oh[e];
-            c2[32 + e] = og8[e];
+          for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
+            const int64_t m = mp + row0 + it * RS;
+            const int64_t mm = m < p.M ? m : p.M - 1;
+            epi_load_r8(p, ef, mm, n, r8[it]);
+            aux[it] = epi_load_aux8(p, ef, mm, n);
+          }
+#pragma unroll
+          for (int it = 0; it < NU; ++it) {
+            const int row = row0 + it * RS;
+            const int64_t m = mp + row;
+            if (m >= p.M) continue;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 a = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
+            }
+            epilogue8(p, ef, m, n, v, b8, r8[it], aux[it]);
           }
         }
       }
-      f16* c = (f16*)p.C + m * p.ldc + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
-      if (ef.c_vec) *(f16x8*)c = oo;
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) c[e] = oo[e];
-      }
     }
-    return;
-  }
-  constexpr int UPR = BN / 8;          // (row, 8-column) units per row
-  constexpr int RS = 256 / UPR;        // rows covered per pass of the 256 threads
-  constexpr int NU = BM / RS;          // units per thread: same column group, rows row0 + it*RS
-  const int cg = t % UPR, row0 = t / UPR;
-  const int64_t n = n0 + cg * 8;
-  if (n >= p.N) return;
-  if (S > 1) {  // split-K: raw fp32 partial, the reducer applies the epilogue
-#pragma unroll
-    for (int it = 0; it < NU; ++it) {
-      const int row = row0 + it * RS;
-      const int64_t m = m0 + row;
-      if (m >= p.M) continue;
-      float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
-    }
-    return;
-  }
-  float b8[8];
-  epi_load_bias8(p, n, b8);
-  float r8[NU][8];
-  f16x8 aux[NU];
-#pragma unroll
-  for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
-    const int64_t m = m0 + row0 + it * RS;
-    const int64_t mm = m < p.M ? m : p.M - 1;
-      epi_load_r8(p, ef, mm, n, r8[it]);
-    aux[it] = epi_load_aux8(p, ef, mm, n);
-  }
-#pragma unroll
-  for (int it = 0; it < NU; ++it) {
-    const int row = row0 + it * RS;
-    const int64_t m = m0 + row;
-    if (m >= p.M) continue;
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f32x4 a = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
-    }
-    epilogue8(p, ef, m, n, v, b8, r8[it], aux[it]);
+    if (pass + 1 < PASSES) __syncthreads();  // the next half overwrites the staging tile
   }
 }
 
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
 #undef SWZ
 
   if (abl & 4) return;  // profiling: no epilogue
-  tile_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
+  tile_epilogue<BM, BN, TM, TN, (BKT == 32 ? 2 : 1)>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
     }
   }
 #undef SWZ
-  tile_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
+  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
 }
 
 
@@ -776,7 +788,8 @@ int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   g_last_cfg[0] = BM, g_last_cfg[1] = BN, g_last_cfg[2] = MODE, g_last_cfg[3] = BKT * 10 + NST, g_last_cfg[4] = S;
   const int64_t npad = (d.N + 7) / 8 * 8;
   size_t lds = (size_t)NST * (BM + BN) * BKT * sizeof(f16);
-  if (lds < (size_t)BM * BN * sizeof(float)) lds = (size_t)BM * BN * sizeof(float);  // epilogue stages the fp32 tile in LDS
+  const size_t epi = (size_t)BM * BN * sizeof(float) / (BKT == 32 ? 2 : 1);  // epilogue stages the fp32 tile in LDS (two halves for BK32)
+  if (lds < epi) lds = epi;
   static bool attr_done = false;
   if (!attr_done && lds > 65536) {
     if (hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -807,6 +820,7 @@ int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
   }
 }
 
+int g_force_tile = 0;        // profiling: 1 = 64x64, 2 = 128x64, 3 = 128x128 for every un-split launch (tb_gemm_set_variant(8000 + v))
 int g_split_min_tiles = 8;   // k-tiles per slice lower bound (tb_gemm_set_variant(4000 + n))
 int g_split_blocks = 256;    // split only when the un-split grid has fewer blocks than this (5000 + n)
 int g_split_minnk = 32;      // ... and at least this many k-tiles (6000 + n)
@@ -838,11 +852,21 @@ int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
 
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
-  // N that is an odd multiple of 64 (320, 960, ...) tiles exactly with BN = 64
+  // BN = 64 tiles N that is an odd multiple of 64 (320, 960, ...) exactly.  For linear GEMMs it is also the faster tile whenever
+  // the 128x128 grid is not a single full round: 3 blocks of 48 KB LDS fit on a CU instead of 2, and these launches are bound by
+  // exposed latency (prologue, per-k-tile drain, residual loads), not by MFMA rate (scratch/tiles.py, one MI355X: 8192x640x640
+  // 26.2 -> 21.3 us, 2048x5120x1280 78 -> 57 us, 32768x1280x320 115 -> 95 us; 2048x3840x1280 (480 tiles = one round) 39.8 vs 46.8)
 #ifdef TB_NO_NARROW
-  const bool narrow = false;
+  bool narrow = false;
+  const bool by_rule = false;
 #else
-  const bool narrow = (d.N % 128) != 0 && (d.N % 128) <= 64;
+  const bool odd64 = (d.N % 128) != 0 && (d.N % 128) <= 64;
+  bool narrow = odd64;
+  if (MODE == TB_A_LINEAR && g_force_tile != 4) {
+    const int64_t b128 = ((d.M + 127) / 128) * ((d.N + 127) / 128);
+    if (b128 >= 256 && !(b128 >= 384 && b128 <= 512)) narrow = true;
+  }
+  const bool by_rule = narrow && !odd64;  // such grids are never small enough for the 64x64 fallback below
 #endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
   if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && d.Hin == d.Hout && d.Win == d.Wout &&
@@ -877,7 +901,9 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
 #ifndef TB_SMALL_TILE_BLOCKS
 #define TB_SMALL_TILE_BLOCKS 320  // A/B on one MI355X: 96 -1.6 %, 192 base, 320 +1.0 %, 512 -1.0 % steps/s
 #endif
-  if (S == 1 && blocks < TB_SMALL_TILE_BLOCKS) return launch<64, 64, MODE>(d, s);  // small problems without workspace: smaller tiles
+  if (g_force_tile && g_force_tile < 4 && S == 1)
+    return g_force_tile == 1 ? launch<64, 64, MODE>(d, s) : (g_force_tile == 2 ? launch<128, 64, MODE>(d, s) : launch<128, 128, MODE>(d, s));
+  if (S == 1 && !by_rule && blocks < TB_SMALL_TILE_BLOCKS) return launch<64, 64, MODE>(d, s);  // small problems without workspace: smaller tiles
   return narrow ? launch<128, 64, MODE>(d, s, S) : launch<128, 128, MODE>(d, s, S);
 }
 
@@ -889,7 +915,8 @@ extern "C" void tb_gemm_last_config(int* out5) {
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
-  if (v >= 7000) g_halo = v - 7000;
+  if (v >= 8000) g_force_tile = v - 8000;
+  else if (v >= 7000) g_halo = v - 7000;
   else if (v >= 6000) g_split_minnk = v - 6000;
   else if (v >= 5000) g_split_blocks = v - 5000;
   else if (v >= 4000) g_split_min_tiles = v - 4000;
@@ -927,7 +954,12 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   }
   if (d.act == TB_ACT_GEGLU) {
     if (d.N % 128 || d.R || d.rowbias || d.c_dtype != TB_F16) return TB_EINVAL;
-    return d.a_mode == TB_A_LINEAR ? launch<128, 128, TB_A_LINEAR>(d, s, 1) : TB_EINVAL;
+    if (d.a_mode != TB_A_LINEAR) return TB_EINVAL;
+    // packed [h32|g32] column blocks of 64 fit both tile widths; the narrow tile only pays for the shortest K (one MI355X:
+    // 32768x2560x320 207 -> 182 us, but 8192x5120x640 134 -> 145 us, 2048x10240x1280 109 -> 118 us)
+    const int64_t b128 = ((d.M + 127) / 128) * (d.N / 128);
+    const bool narrow = g_force_tile != 4 && g_force_tile != 3 && b128 > 512 && d.K <= 320;
+    return narrow ? launch<128, 64, TB_A_LINEAR>(d, s, 1) : launch<128, 128, TB_A_LINEAR>(d, s, 1);
   }
   return d.a_mode == TB_A_LINEAR ? dispatch_tile<TB_A_LINEAR>(d, s) : dispatch_tile<TB_A_CONV3X3>(d, s);
 }
