@@ -820,6 +820,7 @@ int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
   }
 }
 
+int g_conv_narrow = 0;       // experiment: bit 0 = conv_halo_kernel<64> always, bit 1 = convs do NOT follow the linear tile rule (9000 + bits)
 int g_force_tile = 0;        // profiling: 1 = 64x64, 2 = 128x64, 3 = 128x128 for every un-split launch (tb_gemm_set_variant(8000 + v))
 int g_split_min_tiles = 8;   // k-tiles per slice lower bound (tb_gemm_set_variant(4000 + n))
 int g_split_blocks = 256;    // split only when the un-split grid has fewer blocks than this (5000 + n)
@@ -852,17 +853,18 @@ int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
 
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
-  // BN = 64 tiles N that is an odd multiple of 64 (320, 960, ...) exactly.  For linear GEMMs it is also the faster tile whenever
-  // the 128x128 grid is not a single full round: 3 blocks of 48 KB LDS fit on a CU instead of 2, and these launches are bound by
+  // BN = 64 tiles N that is an odd multiple of 64 (320, 960, ...) exactly.  It is also the faster tile whenever the 128x128 grid
+  // is large enough not to be split and is not a single full round: 3 blocks of 48 KB LDS fit on a CU instead of 2, and these launches are bound by
   // exposed latency (prologue, per-k-tile drain, residual loads), not by MFMA rate (scratch/tiles.py, one MI355X: 8192x640x640
-  // 26.2 -> 21.3 us, 2048x5120x1280 78 -> 57 us, 32768x1280x320 115 -> 95 us; 2048x3840x1280 (480 tiles = one round) 39.8 vs 46.8)
+  // 26.2 -> 21.3 us, 2048x5120x1280 78 -> 57 us, 32768x1280x320 115 -> 95 us; 2048x3840x1280 (480 tiles = one round) 39.8 vs 46.8;
+  // halo conv 640->640 @32x32 94.5 -> 81.5 us, 1280->640 168 -> 151 us)
 #ifdef TB_NO_NARROW
   bool narrow = false;
   const bool by_rule = false;
 #else
   const bool odd64 = (d.N % 128) != 0 && (d.N % 128) <= 64;
   bool narrow = odd64;
-  if (MODE == TB_A_LINEAR && g_force_tile != 4) {
+  if ((MODE == TB_A_LINEAR || !(g_conv_narrow & 2)) && g_force_tile != 4) {
     const int64_t b128 = ((d.M + 127) / 128) * ((d.N + 127) / 128);
     if (b128 >= 256 && !(b128 >= 384 && b128 <= 512)) narrow = true;
   }
@@ -883,7 +885,7 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
     }
     if (blocks * Sh >= 200) {
       const int wshift = d.Wout == 64 ? 6 : (d.Wout == 32 ? 5 : 4);
-      return narrow ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
+      return (narrow || (g_conv_narrow & 1)) ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
     }
   }
   int S = 1;
@@ -915,7 +917,8 @@ extern "C" void tb_gemm_last_config(int* out5) {
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
-  if (v >= 8000) g_force_tile = v - 8000;
+  if (v >= 9000) g_conv_narrow = v - 9000;
+  else if (v >= 8000) g_force_tile = v - 8000;
   else if (v >= 7000) g_halo = v - 7000;
   else if (v >= 6000) g_split_minnk = v - 6000;
   else if (v >= 5000) g_split_blocks = v - 5000;
