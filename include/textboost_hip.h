@@ -166,8 +166,9 @@ int tb_textboost_pin_fwd(void* h, int h_dtype, const int64_t* ids, const float* 
 int tb_textboost_pin_bwd(float* dh, const int64_t* ids, int B, int T, int D, int use_fixed, int64_t eos_id, tb_stream_t stream);
 /* peft lora.Linear pieces (train_textboost.py:700-722): P adapters (q,k,v) stacked: A fp32 [P*r, K], Bcat fp32 [P*D, r] */
 int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t, int64_t ldt, int64_t M, int K, int R, tb_stream_t stream);
+/* `layers` stacked adapters in one launch: A [layers][P*r, K], Bcat [layers][P*D, r] -> w2_fwd [layers][P*D, 64], w2_dgrad [layers][K, 64] */
 int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd /*fp16 [P*D,64]*/, void* w2_dgrad /*fp16 [K,64]*/, int D, int K,
-                 int r, int P, float scaling, tb_stream_t stream);
+                 int r, int P, int layers, float scaling, tb_stream_t stream);
 int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P);
 int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
                 void* dt, int64_t lddt, float* dA /* += */, float* dB /* += */, float* ws, int64_t M, int D, int K, int r, int P,

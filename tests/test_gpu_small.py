@@ -154,6 +154,15 @@ def test_embed_pins_lora():
         ref[p_ * Dm:(p_ + 1) * Dm, p_ * r:(p_ + 1) * r] = Bc[p_ * Dm:(p_ + 1) * Dm]
     torch.testing.assert_close(w2f.float(), ref.half().float())
     torch.testing.assert_close(w2d[:, :P * r].float(), A.T.half().float())
+    assert w2d[:, P * r:].abs().max() == 0
+    # stacked layers in one launch == per-layer launches
+    A2l = torch.randn(2, P * r, K, device=dev) / r; B2l = torch.randn(2, P * Dm, r, device=dev) * 0.1
+    w2f2 = torch.empty(2, P * Dm, 64, device=dev, dtype=torch.float16); w2d2 = torch.empty(2, K, 64, device=dev, dtype=torch.float16)
+    ops.lora_pack(A2l, B2l, w2f2, w2d2, Dm, K, r, P, scaling=0.5, layers=2)
+    for l in range(2):
+        a1 = torch.empty(P * Dm, 64, device=dev, dtype=torch.float16); b1 = torch.empty(K, 64, device=dev, dtype=torch.float16)
+        ops.lora_pack(A2l[l], B2l[l], a1, b1, Dm, K, r, P, scaling=0.5)
+        assert torch.equal(a1, w2f2[l]) and torch.equal(b1, w2d2[l])
     # forward through the two-source GEMM equals x W^T + B(Ax)
     W = (torch.randn(P * Dm, K, device=dev) / 11).half()
     y = torch.empty(M, P * Dm, device=dev, dtype=torch.float16)

@@ -99,93 +99,195 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const f16* __restrict__ 
     }
 }
 
-// ---- W2[p*D + n, p*r + j] = scaling * B[(p*D + n)*r + j] (fp16, block diagonal, zero elsewhere; 64 columns)
-__global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restrict__ Bcat, f16* __restrict__ W2, int D, int r, int P,
-                                                          float scaling) {
+// ---- one launch packs the fp16 K-extension operands of ALL layers (the stacks are contiguous over layers):
+//   W2 [l][p*D + n, p*r + j] = scaling * B[l][(p*D + n)*r + j]   (block diagonal, zero elsewhere; 64 columns)
+//   W2d[l][k, j]             = A[l][j*K + k] for j < R else 0    (fp16 [K, 64]: second K-source of the qkv dgrad GEMM)
+__global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ A, const float* __restrict__ Bcat, f16* __restrict__ W2,
+                                                        f16* __restrict__ W2d, int D, int K, int r, int P, int layers, float scaling) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)P * D * 64) return;
-  const int64_t n = idx / 64;
-  const int j = (int)(idx - n * 64);
-  const int p = (int)(n / D);
-  float v = 0.f;
-  if (j >= p * r && j < (p + 1) * r) v = scaling * Bcat[n * r + (j - p * r)];
-  W2[idx] = (f16)v;
-}
-// ---- W2d[k, j] = A[j*K + k] for j < R else 0 (fp16 [K, 64]) : second K-source of the qkv dgrad GEMM
-__global__ __launch_bounds__(256) void lora_pack_at_kernel(const float* __restrict__ A, f16* __restrict__ W2d, int K, int R) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)K * 64) return;
-  const int64_t k = idx / 64;
-  const int j = (int)(idx - k * 64);
-  W2d[idx] = (f16)(j < R ? A[(int64_t)j * K + k] : 0.f);
+  const int64_t nb = (int64_t)layers * P * D * 64, na = (int64_t)layers * K * 64;
+  if (idx < nb) {
+    const int64_t n = idx / 64;  // row over layers * P * D
+    const int j = (int)(idx - n * 64);
+    const int p = (int)((n / D) % P);
+    float v = 0.f;
+    if (j >= p * r && j < (p + 1) * r) v = scaling * Bcat[n * r + (j - p * r)];
+    W2[idx] = (f16)v;
+  } else if (idx < nb + na) {
+    const int64_t i = idx - nb;
+    const int64_t lk = i / 64;  // layer * K + k
+    const int j = (int)(i - lk * 64);
+    const int64_t l = lk / K, k = lk - l * K;
+    const int R = P * r;
+    W2d[i] = (f16)(j < R ? A[(l * R + j) * K + k] : 0.f);
+  }
 }
 
-// ---- LoRA backward, three tiny reductions.  dY is the gradient of the fused qkv projection output [M, P*D].
-// (a) dt[m, p*r + j] = scaling * sum_n dY[m, p*D + n] * fp16(B[(p*D+n)*r + j])      (wave per row)
-__global__ __launch_bounds__(256) void lora_bwd_dt_kernel(const f16* __restrict__ dY, int64_t lddy, const float* __restrict__ Bcat,
-                                                          f16* __restrict__ dt, int64_t lddt, int64_t M, int D, int r, int P,
-                                                          float scaling) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  for (int p = 0; p < P; ++p)
-    for (int j = 0; j < r; ++j) {
-      float a = 0.f;
-      for (int n = lane; n < D; n += 64) a += (float)dY[row * lddy + p * D + n] * (float)(f16)Bcat[((int64_t)p * D + n) * r + j];
-      a = wave_sum(a) * scaling;
-      if (lane == 0) dt[row * lddt + p * r + j] = (f16)a;
+// ---- LoRA backward.  dY is the gradient of the fused qkv projection output [M, P*D]; per adapter p (q, k, v):
+//   (a) dt[m, p*r + j]  = scaling * sum_n dY[m, p*D + n] * fp16(B[(p*D+n)*r + j])
+//   (b) dB[(p*D+n)*r+j] += scaling * sum_m dY[m, p*D + n] * t[m, p*r + j]
+//   (c) dA[j*K + k]     += sum_m dt[m, j] * x[m, k]
+// One kernel per slab of LORA_RS rows does all three: (a) lands in LDS (and in dt for the dgrad GEMM), (b)/(c) are per-slab
+// partial sums written to a workspace; blockIdx.y = 0 takes the (b) units, 1 the (c) units so that M / LORA_RS * 2 blocks fill the
+// chip.  A second kernel adds the partials in slab order (deterministic).
+constexpr int LORA_RS = 8;
+constexpr int LORA_MAXR = 24;  // P * r
+template <int R4>  // r == 4 fast path (vector loads of B rows / t rows) or generic r <= 8
+__global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ x, int64_t ldx,
+                                                             const f16* __restrict__ t, int64_t ldt, const float* __restrict__ Bcat,
+                                                             f16* __restrict__ dt, int64_t lddt, float* __restrict__ partB,
+                                                             float* __restrict__ partA, int64_t M, int D, int K, int r, int P,
+                                                             float scaling) {
+  __shared__ float ts[LORA_RS][LORA_MAXR];
+  __shared__ float dts[LORA_RS][LORA_MAXR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = P * r;
+  const int64_t m0 = (int64_t)blockIdx.x * LORA_RS;
+  const int rows = (int)(M - m0 < LORA_RS ? M - m0 : LORA_RS);
+  if (tid < LORA_RS * LORA_MAXR) {
+    const int i = tid / LORA_MAXR, j = tid - i * LORA_MAXR;
+    ts[i][j] = (i < rows && j < R) ? (float)t[(m0 + i) * ldt + j] : 0.f;
+    dts[i][j] = 0.f;  // columns >= R stay zero for (c)'s 4-row units
+  }
+  __syncthreads();
+  // ---- (a): wave per row, the row of dY is read once (16-byte loads) against all r columns of B
+  for (int i = wave; i < LORA_RS; i += 4) {
+    for (int p = 0; p < P; ++p) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < rows)
+        for (int n = lane * 8; n < D; n += 512) {
+          const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + (int64_t)p * D + n);
+          const float* bp = Bcat + ((int64_t)p * D + n) * r;
+          if (R4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const f32x4 b = *(const f32x4*)(bp + 4 * e);
+              const float d = (float)dy[e];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[j] += d * (float)(f16)b[j];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float d = (float)dy[e];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < r) acc[j] += d * (float)(f16)bp[e * r + j];
+            }
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < r) {
+          const float v = wave_sum(acc[j]) * scaling;
+          if (lane == 0) {
+            const f16 h = (f16)v;
+            dts[i][p * r + j] = (float)h;  // (c) consumes the fp16 value the dgrad GEMM sees
+            if (i < rows && blockIdx.y == 0) dt[(m0 + i) * lddt + p * r + j] = h;
+          }
+        }
     }
-}
-// (b)/(c) are reductions over the M rows; M is split into slabs of LORA_RS rows across blockIdx.y so the chip is
-// filled, per-slab partials go to a workspace and a second kernel sums them in a fixed order (deterministic).
-constexpr int LORA_RS = 16;
-// (b) partB[s][n*r + j] = sum_{m in slab s} dY[m, n] * t[m, p*r+j]                    (thread per output column n)
-__global__ __launch_bounds__(256) void lora_bwd_db_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ t,
-                                                          int64_t ldt, float* __restrict__ part, int64_t M, int D, int r, int P) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over P*D
-  if (n >= (int64_t)P * D) return;
-  const int p = (int)(n / D);
-  const int64_t m0 = (int64_t)blockIdx.y * LORA_RS, m1 = m0 + LORA_RS < M ? m0 + LORA_RS : M;
-  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t m = m0; m < m1; ++m) {
-    const float d = (float)dY[m * lddy + n];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < r) a[j] += d * (float)t[m * ldt + p * r + j];
   }
-  float* o = part + (int64_t)blockIdx.y * P * D * r + n * r;
+  __syncthreads();
+  if (blockIdx.y == 0) {
+    // ---- (b): unit = 8 consecutive columns n of dY; acc[e][j] over the slab rows
+    const int units = P * D / 8;
+    float* o = partB + (int64_t)blockIdx.x * P * D * r;
+    for (int u = tid; u < units; u += 256) {
+      const int n = u * 8, p = n / D;
+      float acc[8][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (j < r) o[j] = a[j];
-}
-// (c) partA[s][j*K + k] = sum_{m in slab s} dt[m, j] * x[m, k]                          (thread per k, j < R <= 24)
-__global__ __launch_bounds__(256) void lora_bwd_da_kernel(const f16* __restrict__ dt, int64_t lddt, const f16* __restrict__ x,
-                                                          int64_t ldx, float* __restrict__ part, int64_t M, int K, int R) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  const int64_t m0 = (int64_t)blockIdx.y * LORA_RS, m1 = m0 + LORA_RS < M ? m0 + LORA_RS : M;
-  float a[24];
+      for (int e = 0; e < 8; ++e)
 #pragma unroll
-  for (int j = 0; j < 24; ++j) a[j] = 0.f;
-  for (int64_t m = m0; m < m1; ++m) {
-    const float xv = (float)x[m * ldx + k];
+        for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
+      for (int i = 0; i < rows; ++i) {
+        const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + n);
 #pragma unroll
-    for (int j = 0; j < 24; ++j)
-      if (j < R) a[j] += (float)dt[m * lddt + j] * xv;
+        for (int j = 0; j < 8; ++j)
+          if (j < (R4 ? 4 : r)) {
+            const float tv = ts[i][p * r + j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e][j] += (float)dy[e] * tv;
+          }
+      }
+      if (R4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[e][j];
+          *(f32x4*)(o + (int64_t)(n + e) * 4) = v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < r) o[(int64_t)(n + e) * r + j] = acc[e][j];
+      }
+    }
+  } else {
+    // ---- (c): unit = (4 adapter rows j, 8 consecutive k)
+    const int kg = K / 8, jgs = (R + 3) / 4;
+    float* o = partA + (int64_t)blockIdx.x * R * K;
+    for (int u = tid; u < kg * jgs; u += 256) {
+      const int jg = u / kg, k = (u - jg * kg) * 8;
+      float acc[4][8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+      for (int i = 0; i < rows; ++i) {
+        const f16x8 xv = *(const f16x8*)(x + (m0 + i) * ldx + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = dts[i][jg * 4 + j];  // columns >= R hold zeros (LORA_MAXR is a multiple of 4)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][e] += d * (float)xv[e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (jg * 4 + j < R) {
+          f32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = acc[j][e];
+            v1[e] = acc[j][4 + e];
+          }
+          float* dst = o + (int64_t)(jg * 4 + j) * K + k;
+          *(f32x4*)dst = v0;
+          *(f32x4*)(dst + 4) = v1;
+        }
+    }
   }
-  float* o = part + (int64_t)blockIdx.y * R * K;
-#pragma unroll
-  for (int j = 0; j < 24; ++j)
-    if (j < R) o[(int64_t)j * K + k] = a[j];
 }
-// out[i] += scale * sum_s part[s*n + i]
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int nslab,
-                                                          float scale) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a = 0.f;
-  for (int s = 0; s < nslab; ++s) a += part[(int64_t)s * n + i];
-  out[i] += scale * a;
+// dB[i] += scaleB * sum_s partB[s][i] (i < nB);  dA[i] += sum_s partA[s][i] (i < nA): one launch for both, 4 floats per thread
+__global__ __launch_bounds__(256) void lora_slab_reduce_kernel(const float* __restrict__ partB, const float* __restrict__ partA,
+                                                               float* __restrict__ dB, float* __restrict__ dA, int64_t nB, int64_t nA,
+                                                               int nslab, float scaleB) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const float* part;
+  float* out;
+  int64_t n;
+  float scale;
+  if (i < nB) part = partB, out = dB, n = nB, scale = scaleB;
+  else if (i - nB < nA) i -= nB, part = partA, out = dA, n = nA, scale = 1.f;
+  else return;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= nslab; s += 4) {  // 4 independent loads in flight, summed in slab order
+    const f32x4 v0 = *(const f32x4*)(part + (int64_t)s * n + i), v1 = *(const f32x4*)(part + (int64_t)(s + 1) * n + i),
+                v2 = *(const f32x4*)(part + (int64_t)(s + 2) * n + i), v3 = *(const f32x4*)(part + (int64_t)(s + 3) * n + i);
+    a += v0;
+    a += v1;
+    a += v2;
+    a += v3;
+  }
+  for (; s < nslab; ++s) a += *(const f32x4*)(part + (int64_t)s * n + i);
+  f32x4 o = *(f32x4*)(out + i);
+  o += a * scale;
+  *(f32x4*)(out + i) = o;
 }
 
 }  // namespace
@@ -252,13 +354,13 @@ extern "C" int tb_lora_down(const void* x, int64_t ldx, const float* A, void* t,
   return TB_OK;
 }
 
-extern "C" int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd, void* w2_dgrad, int D, int K, int r, int P, float scaling,
-                            tb_stream_t stream) {
+extern "C" int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd, void* w2_dgrad, int D, int K, int r, int P, int layers,
+                            float scaling, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!A || !Bcat || !w2_fwd || !w2_dgrad || P * r > 64) return TB_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(lora_pack_b_kernel, GRID1D((int64_t)P * D * 64), dim3(256), 0, s, Bcat, (f16*)w2_fwd, D, r, P, scaling);
-  hipLaunchKernelGGL(lora_pack_at_kernel, GRID1D((int64_t)K * 64), dim3(256), 0, s, A, (f16*)w2_dgrad, K, P * r);
+  if (!A || !Bcat || !w2_fwd || !w2_dgrad || P * r > 64 || layers <= 0) return TB_EINVAL;
+  const int64_t n = (int64_t)layers * ((int64_t)P * D + K) * 64;
+  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), dim3(256), 0, (hipStream_t)stream, A, Bcat, (f16*)w2_fwd, (f16*)w2_dgrad, D, K, r, P,
+                     layers, scaling);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
@@ -272,19 +374,23 @@ extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t 
                            void* dt, int64_t lddt, float* dA, float* dB, float* ws, int64_t M, int D, int K, int r, int P,
                            float scaling, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || !ws || r > 8 || P * r > 24) return TB_EINVAL;
+  if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || !ws || r > 8 || P * r > LORA_MAXR) return TB_EINVAL;
+  if (D % 8 || K % 8 || lddy % 8 || ldx % 8 || (P * D * r) % 4 || (P * r * K) % 4) return TB_EINVAL;  // 16-byte vector accesses
+  if (((uintptr_t)dY) % 16 || ((uintptr_t)x) % 16 || ((uintptr_t)dA) % 16 || ((uintptr_t)dB) % 16 || ((uintptr_t)ws) % 16 ||
+      (r == 4 && ((uintptr_t)Bcat) % 16))
+    return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nslab = (int)((M + LORA_RS - 1) / LORA_RS);
+  const int64_t nB = (int64_t)P * D * r, nA = (int64_t)P * r * K;
   float* partB = ws;
-  float* partA = ws + (int64_t)nslab * P * D * r;
-  hipLaunchKernelGGL(lora_bwd_dt_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const f16*)dY, lddy, Bcat, (f16*)dt, lddt, M,
-                     D, r, P, scaling);
-  hipLaunchKernelGGL(lora_bwd_db_kernel, dim3((unsigned)(((int64_t)P * D + 255) / 256), nslab), dim3(256), 0, s, (const f16*)dY, lddy,
-                     (const f16*)t, ldt, partB, M, D, r, P);
-  hipLaunchKernelGGL(lora_bwd_da_kernel, dim3((unsigned)((K + 255) / 256), nslab), dim3(256), 0, s, (const f16*)dt, lddt,
-                     (const f16*)x, ldx, partA, M, K, P * r);
-  hipLaunchKernelGGL(slab_reduce_kernel, GRID1D((int64_t)P * D * r), dim3(256), 0, s, partB, dB, (int64_t)P * D * r, nslab, scaling);
-  hipLaunchKernelGGL(slab_reduce_kernel, GRID1D((int64_t)P * r * K), dim3(256), 0, s, partA, dA, (int64_t)P * r * K, nslab, 1.f);
+  float* partA = ws + (int64_t)nslab * nB;
+  if (r == 4)
+    hipLaunchKernelGGL(lora_bwd_fused_kernel<1>, dim3(nslab, 2), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)x, ldx, (const f16*)t,
+                       ldt, Bcat, (f16*)dt, lddt, partB, partA, M, D, K, r, P, scaling);
+  else
+    hipLaunchKernelGGL(lora_bwd_fused_kernel<0>, dim3(nslab, 2), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)x, ldx, (const f16*)t,
+                       ldt, Bcat, (f16*)dt, lddt, partB, partA, M, D, K, r, P, scaling);
+  hipLaunchKernelGGL(lora_slab_reduce_kernel, GRID1D((nB + nA) / 4), dim3(256), 0, s, partB, partA, dB, dA, nB, nA, nslab, scaling);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -274,8 +274,9 @@ def lora_down(x, A, t):
     L.check(L.lib().tb_lora_down(L.ptr(x), x.stride(0), L.ptr(A), L.ptr(t), t.stride(0), M, K, A.shape[0], L.stream()), "tb_lora_down")
 
 
-def lora_pack(A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, scaling=1.0):
-    L.check(L.lib().tb_lora_pack(L.ptr(A), L.ptr(Bcat), L.ptr(w2_fwd), L.ptr(w2_dgrad), D, K, r, P, scaling, L.stream()), "tb_lora_pack")
+def lora_pack(A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, scaling=1.0, layers=1):
+    L.check(L.lib().tb_lora_pack(L.ptr(A), L.ptr(Bcat), L.ptr(w2_fwd), L.ptr(w2_dgrad), D, K, r, P, layers, scaling, L.stream()),
+            "tb_lora_pack")
 
 
 _lora_ws = {}

@@ -136,8 +136,8 @@ class HipTextEncoder:
         if not self.r:
             return
         D = self.geo.hidden_size
-        for i in range(self.geo.num_layers):
-            ops.lora_pack(self.lora_A[i], self.lora_B[i], self.w2_fwd[i], self.w2_dgrad[i], D, D, self.r, 3, self.scaling)
+        assert self.lora_A.is_contiguous() and self.lora_B.is_contiguous()
+        ops.lora_pack(self.lora_A, self.lora_B, self.w2_fwd, self.w2_dgrad, D, D, self.r, 3, self.scaling, layers=self.geo.num_layers)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, slot=0, pins=True):
