@@ -91,9 +91,15 @@ int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
  * final_layer_norm.  stats = [M, 2] (mean, rstd).  bwd: dx = LN'(dy) (+ add), dx/add in x's dtype. */
 int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
                      const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream);
+/* same, plus the rank-R LoRA down projection of the normalised row while it is in registers (peft lora_A on q/k/v,
+ * train_textboost.py:700-722): t[m, j] = sum_k y[m,k] * fp16(loraA[j*C + k]), j < R (what tb_lora_down computes from y) */
+int tb_layernorm_lora_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                          const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, void* t /* fp16 */,
+                          int64_t ldt, tb_stream_t stream);
+/* dx16 (optional, may be NULL): an fp16 copy of dx for the next dgrad GEMM (saves a conversion pass over the fp32 stream) */
 int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,
                      const float* gamma, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx,
-                     int64_t M, int C, tb_stream_t stream);
+                     void* dx16, int64_t lddx16, int64_t M, int C, tb_stream_t stream);
 
 /* ---- Flash attention, O = softmax(scale * Q K^T [+ causal]) V, and its backward -------------------
  * Replaces F.scaled_dot_product_attention in diffusers AttnProcessor2_0 (UNet attn1/attn2) and the eager

@@ -64,6 +64,17 @@ def test_layernorm_fwd_bwd(M, C, xdt):
     ops.layernorm_bwd(dy, x, gamma, stats, dx, add=add)
     ref.backward(dy.float())
     assert rel_err(dx, xr.grad + add.float()) < (2e-3 if xdt == torch.float16 else 1e-4)
+    # optional outputs: fp16 copy of dx, and the fused LoRA down projection of the normalised rows (== tb_lora_down on y)
+    dx2 = torch.empty_like(dx); dx16 = torch.zeros(M, C + 8, device="cuda", dtype=torch.float16)[:, :C]
+    ops.layernorm_bwd(dy, x, gamma, stats, dx2, add=add, dx16=dx16)
+    assert torch.equal(dx2, dx) and torch.equal(dx16, dx.half())
+    R = 12
+    A = torch.randn(R, C, device="cuda") / 4
+    y2 = torch.empty_like(y); t = torch.zeros(M, 64, device="cuda", dtype=torch.float16); t_ref = torch.zeros_like(t)
+    ops.layernorm_fwd(x, y2, gamma, beta, stats, eps=1e-5, lora_A=A, t=t)
+    ops.lora_down(y, A, t_ref)
+    assert torch.equal(y2, y) and t[:, R:].abs().max() == 0
+    assert rel_err(t[:, :R], y.float() @ A.half().float().T) < 2e-3 and rel_err(t[:, :R], t_ref[:, :R]) < 2e-3
 
 
 def ref_attention(q, k, v, H, causal):

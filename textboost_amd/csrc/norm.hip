@@ -397,7 +397,8 @@ __device__ __forceinline__ void store8<float>(float* p, const float* v) {
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, int64_t ldx, TO* __restrict__ Y, int64_t ldy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ stats, int64_t M, int C, float eps) {
+                                                     float* __restrict__ stats, int64_t M, int C, float eps,
+                                                     const float* __restrict__ loraA, int R, f16* __restrict__ tdown, int64_t ldt) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -439,6 +440,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * gamma[vi * 8 + e] + beta[vi * 8 + e];
       store8<TO>(Y + row * ldy + vi * 8, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = (float)(TO)o[e];  // what a consumer of Y reads
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+    }
+  }
+  if (loraA) {
+    // fused LoRA down projection (lora_A of peft lora.Linear on the normalised row): tdown[row, j] = sum_k y[row,k] * fp16(A[j,k]);
+    // the row is still in registers, the R <= 24 adapter rows are L2 resident
+    for (int j = 0; j < R; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < LN_MAXV; ++k) {
+        int vi = lane + 64 * k;
+        if (vi < nv) {
+          const f32x4 a0 = *(const f32x4*)(loraA + (int64_t)j * C + vi * 8), a1 = *(const f32x4*)(loraA + (int64_t)j * C + vi * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a += v[k][e] * (float)(f16)a0[e] + v[k][4 + e] * (float)(f16)a1[e];
+        }
+      }
+      a = wave_sum(a);
+      if (lane == 0) tdown[row * ldt + j] = (f16)a;
     }
   }
 }
@@ -448,7 +472,7 @@ template <typename T, typename TDY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dY, int64_t lddy, const T* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
                                                      const T* __restrict__ add, int64_t ldadd, T* __restrict__ dX, int64_t lddx,
-                                                     int64_t M, int C) {
+                                                     f16* __restrict__ dX16, int64_t lddx16, int64_t M, int C) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -487,6 +511,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dY,
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += rstd * (g[k][e] - s1 - xh[k][e] * s2);
       store8<T>(dX + row * lddx + vi * 8, o);
+      if (dX16) store8<f16>(dX16 + row * lddx16 + vi * 8, o);  // the fp16 operand of the next dgrad GEMM
     }
   }
 }
@@ -536,42 +561,56 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   return TB_OK;
 }
 
-extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
-                                const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
+static int ln_fwd_launch(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                         const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, f16* tdown, int64_t ldt,
+                         tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x || !y || !gamma || !beta || M <= 0) return TB_EINVAL;
   if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || ldy % 8) return TB_EINVAL;
+  if (loraA && (!tdown || R <= 0 || R > 64 || ((uintptr_t)loraA) % 16)) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 3) / 4));
   if (x_dtype == TB_F32 && y_dtype == TB_F16)
-    hipLaunchKernelGGL((ln_fwd_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+    hipLaunchKernelGGL((ln_fwd_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt);
   else if (x_dtype == TB_F32 && y_dtype == TB_F32)
-    hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, stats, M, C, eps);
+    hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt);
   else if (x_dtype == TB_F16 && y_dtype == TB_F16)
-    hipLaunchKernelGGL((ln_fwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps);
+    hipLaunchKernelGGL((ln_fwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt);
   else
     return TB_EINVAL;
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
 
+extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                                const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
+  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int tb_layernorm_lora_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                                     const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, void* t,
+                                     int64_t ldt, tb_stream_t stream) {
+  if (!loraA) return TB_EINVAL;
+  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, loraA, R, (f16*)t, ldt, stream);
+}
+
 extern "C" int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,
                                 const float* gamma, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx,
-                                int64_t M, int C, tb_stream_t stream) {
+                                void* dx16, int64_t lddx16, int64_t M, int C, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!dy || !x || !gamma || !stats || !dx || M <= 0) return TB_EINVAL;
-  if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8)) return TB_EINVAL;
+  if (C % 8 || C > 64 * 8 * LN_MAXV || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8) || (dx16 && lddx16 % 8)) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 3) / 4));
   if (x_dtype == TB_F32 && dy_dtype == TB_F16)
     hipLaunchKernelGGL((ln_bwd_kernel<float, f16>), grid, dim3(256), 0, s, (const f16*)dy, lddy, (const float*)x, ldx, gamma, stats,
-                       (const float*)add, ldadd, (float*)dx, lddx, M, C);
+                       (const float*)add, ldadd, (float*)dx, lddx, (f16*)dx16, lddx16, M, C);
   else if (x_dtype == TB_F32 && dy_dtype == TB_F32)
     hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)dy, lddy, (const float*)x, ldx, gamma,
-                       stats, (const float*)add, ldadd, (float*)dx, lddx, M, C);
+                       stats, (const float*)add, ldadd, (float*)dx, lddx, (f16*)dx16, lddx16, M, C);
   else if (x_dtype == TB_F16 && dy_dtype == TB_F16)
     hipLaunchKernelGGL((ln_bwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, stats,
-                       (const f16*)add, ldadd, (f16*)dx, lddx, M, C);
+                       (const f16*)add, ldadd, (f16*)dx, lddx, (f16*)dx16, lddx16, M, C);
   else
     return TB_EINVAL;
   TB_CHECK_LAUNCH();

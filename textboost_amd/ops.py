@@ -144,18 +144,24 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G=32, silu=False,
     return dx
 
 
-def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5):
+def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5, lora_A=None, t=None):
+    """lora_A fp32 [R, C] + t fp16 [M, >=R]: also write the LoRA down projection of the normalised rows into t[:, :R]."""
     M, Cc = y.shape
+    if lora_A is not None:
+        L.check(L.lib().tb_layernorm_lora_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), _dt(y), L.ptr(gamma), L.ptr(beta),
+                                              L.ptr(stats), M, Cc, eps, L.ptr(lora_A), lora_A.shape[0], L.ptr(t), t.stride(0), L.stream()),
+                "tb_layernorm_lora_fwd")
+        return y
     L.check(L.lib().tb_layernorm_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), _dt(y), L.ptr(gamma), L.ptr(beta),
                                      L.ptr(stats), M, Cc, eps, L.stream()), "tb_layernorm_fwd")
     return y
 
 
-def layernorm_bwd(dy, x, gamma, stats, dx, add=None):
+def layernorm_bwd(dy, x, gamma, stats, dx, add=None, dx16=None):
     M, Cc = dx.shape
     L.check(L.lib().tb_layernorm_bwd(L.ptr(dy), dy.stride(0), _dt(dy), L.ptr(x), x.stride(0), _dt(x), L.ptr(gamma), L.ptr(stats),
-                                     L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), M, Cc,
-                                     L.stream()), "tb_layernorm_bwd")
+                                     L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), L.ptr(dx16),
+                                     dx16.stride(0) if dx16 is not None else 0, M, Cc, L.stream()), "tb_layernorm_bwd")
     return dx
 
 

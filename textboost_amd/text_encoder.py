@@ -155,13 +155,13 @@ class HipTextEncoder:
             p = f"{s}l{i}."
             x1 = self.buf(p + "x1", M, D, f16)
             ls1 = self.buf(p + "ls1", M, 2, f32)
-            ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
             qkv = self.buf(p + "qkv", M, 3 * D, f16)
             if self.r:
-                t = self.buf(p + "t", M, 64, f16)
-                ops.lora_down(x1, self.lora_A[i], t)
+                t = self.buf(p + "t", M, 64, f16)  # columns >= 3r stay zero (K-extension operand of the qkv GEMM)
+                ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps, lora_A=self.lora_A[i], t=t)
                 ops.gemm(x1, W["qkv.w"], qkv, A2=t, W2=self.w2_fwd[i], bias=W["qkv.b"])
             else:
+                ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
                 ops.gemm(x1, W["qkv.w"], qkv, bias=W["qkv.b"])
             o = self.buf(p + "o", M, D, f16)
             lse = self.buf(p + "lse", B * H, T, f32)
@@ -208,7 +208,8 @@ class HipTextEncoder:
             ops.pin_bwd(d_out, ids, B, T, self.use_fixed_special_embedding, EOS_ID)
         h_last = self._bufs[f"{s}l{geo.num_layers - 1}.h3"]
         dh = self.buf("g.dh_a", M, D, f32)
-        ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh)
+        dh16 = self.buf("g.dh16", M, D, f16)  # fp16 copy of the running residual gradient, written by the LayerNorm backward
+        ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh, dx16=dh16)
         dh_other = self.buf("g.dh_b", M, D, f32)
         for i in reversed(range(geo.num_layers)):
             W = self.Wl[i]
@@ -216,15 +217,12 @@ class HipTextEncoder:
             h_in = self._bufs[f"{s}l{i - 1}.h3"] if i > 0 else self._bufs[s + "h0"]
             h2, pre, qkv, o, lse = (self._bufs[p + n] for n in ("h2", "pre", "qkv", "o", "lse"))
             x1 = self._bufs[p + "x1"]
-            dh16 = self.buf("g.dh16", M, D, f16)
-            ops.convert(dh, dh16)
             dpre = self.buf("g.dpre", M, I, f16)
             ops.gemm(dh16, W["fc2.wd"], dpre, act=self.act_bwd, C2=pre)
             dx2 = self.buf("g.dx", M, D, f16)
             ops.gemm(dpre, W["fc1.wd"], dx2)
             dh2 = dh_other
-            ops.layernorm_bwd(dx2, h2, W["ln2.g"], self._bufs[p + "ls2"], dh2, add=dh)
-            ops.convert(dh2, dh16)
+            ops.layernorm_bwd(dx2, h2, W["ln2.g"], self._bufs[p + "ls2"], dh2, add=dh, dx16=dh16)
             do = self.buf("g.do", M, D, f16)
             ops.gemm(dh16, W["out.wd"], do)
             dqkv = self.buf("g.dqkv", M, 3 * D, f16)
@@ -239,7 +237,7 @@ class HipTextEncoder:
                 ops.gemm(dqkv, W["qkv.wd"], dx1, A2=dt, W2=self.w2_dgrad[i])
             else:
                 ops.gemm(dqkv, W["qkv.wd"], dx1)
-            ops.layernorm_bwd(dx1, h_in, W["ln1.g"], self._bufs[p + "ls1"], dh, add=dh2)
+            ops.layernorm_bwd(dx1, h_in, W["ln1.g"], self._bufs[p + "ls1"], dh, add=dh2, dx16=dh16 if i > 0 else None)
             # dh (buffer a) now holds the gradient w.r.t. this layer's input; dh2 (buffer b) is free again
         if self.n_added:
             ops.embed_bwd(dh, ids, self.grad_added, self.first_added)
