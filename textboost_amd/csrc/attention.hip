@@ -13,6 +13,14 @@
 // reading the A operand (V^T, staged transposed in LDS) with the same permutation, so no cross-lane traffic is
 // needed between the two matmuls.  The backward kernels use the same idea (lane owns a query in the dQ kernel,
 // a key in the dK/dV kernel).
+//
+// The softmax side of these kernels is VALU-bound at the UNet's small head dims (rocprofv3 PMC, S = 4096, hd = 40: VALU busy 65 %,
+// MFMA busy 28 %), so everything that can ride on the matrix pipe does:
+//   * the lane-owned operand (Q, or K in the dK/dV kernel) is pre-multiplied by scale*log2(e) once, and the MFMA accumulator is
+//     initialised with -m (forward), -lse (backward) or -delta (the dP product) instead of zero, so S arrives as the exp2 argument
+//     and dP arrives as dP - delta: no per-score fma / subtract;
+//   * the forward row sum l is an extra all-ones row of V^T in the head-dim padding (hd < 32*DT): O^T row hd accumulates sum_k P;
+//   * the softmax scale of dS is applied once to the dQ / dK accumulators at write-out (as FlashAttention-2 does).
 #define TB_ATTN_FUSED_DELTA 1  // A/B on MI355X: delta = rowsum(dO*O) inside the dQ kernel, +1.0 % steps/s vs its own launch
 #include "common.h"
 #include "../../include/textboost_hip.h"
@@ -22,7 +30,7 @@ namespace {
 constexpr int KVT = 64;      // keys (or queries, in the dK/dV kernel) per LDS tile
 constexpr int TLD = KVT + 4; // row stride (halfs) of transposed tiles: 136 B -> conflict-free ds_read_b64 across d
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float NEG_BIG = -1e30f;
+__device__ __attribute__((aligned(16))) const f16 g_zero8[8] = {};  // out-of-range lanes load this line: no divergent branches
 // single v_exp_f32 (no denormal-range fixup: softmax probabilities below 2^-126 may flush to 0)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -58,14 +66,14 @@ __device__ __forceinline__ void tile_load(TileRegs<WD>& t, const f16* g, int64_t
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int row = row0 + kg * 4 + k;
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (idx < TileRegs<WD>::ITEMS && row < nrows && ch * 8 < hd) v = *(const f16x8*)(g + (int64_t)row * ld + ch * 8);
-      t.v[it][k] = v;
+      const bool ok = idx < TileRegs<WD>::ITEMS && row < nrows && ch * 8 < hd;
+      t.v[it][k] = *(const f16x8*)(ok ? g + (int64_t)row * ld + ch * 8 : g_zero8);
     }
   }
 }
-template <int WD, bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* tr) {
+// ONES: row `ones_row` (a multiple of 8 inside the zero padding hd..WD-1) of the transposed image is all ones
+template <int WD, bool ROWMAJOR, bool TRANSPOSED, bool ONES = false>
+__device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* tr, int ones_row = -1) {
   constexpr int CPR = TileRegs<WD>::CPR;
 #pragma unroll
   for (int it = 0; it < TileRegs<WD>::NI; ++it) {
@@ -82,6 +90,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* 
         f16x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = t.v[it][k][i];
+        if (ONES && i == 0 && ch * 8 == ones_row) o = f16x4{(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
         *(f16x4*)(tr + (ch * 8 + i) * TLD + kg * 4) = o;
       }
     }
@@ -116,23 +125,39 @@ __device__ __forceinline__ void load_row_frags(f16x8* f, const f16* g, int64_t l
 #pragma unroll
   for (int j = 0; j < KS; ++j) {
     const int col = 16 * j + 8 * hi;
-    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < nrows && col < hd) v = *(const f16x8*)(g + (int64_t)row * ld + col);
-    f[j] = v;
+    f[j] = *(const f16x8*)((row < nrows && col < hd) ? g + (int64_t)row * ld + col : g_zero8);
   }
 }
 
+#ifdef TB_ATTN_PRIO
+#define TB_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define TB_PRIO(x)
+#endif
 #define ZERO16(x)                \
   _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) (x)[r_] = 0.f;
+#define FILL16(x, v)             \
+  _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) (x)[r_] = (v);
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // v_max3_f32
+// lane-owned B-operand fragments times a scalar (scale * log2 e), rounded back to fp16
+template <int KS>
+__device__ __forceinline__ void scale_frags(f16x8* f, float c) {
+#pragma unroll
+  for (int j = 0; j < KS; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[j][e] = (f16)((float)f[j][e] * c);
+}
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int DT, int KS>
+template <int DT, int KS, bool ONES>
 __global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
   f16* Vt = Ks + RM<WD>::SIZE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR): the mask tests below become scalar branches
   const int b = blockIdx.z, h = blockIdx.y;
   const int qblk = blockIdx.x * 128;
   const int q = qblk + wave * 32 + l31;
@@ -141,40 +166,64 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_f
   const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * p.hd;
   f16x8 qf[KS];
   load_row_frags<KS>(qf, Qg, p.ldq, q, p.Sq, p.hd, hi);
+  scale_frags<KS>(qf, p.scale * LOG2E);  // scores come out of the MFMA in the log2 domain
   f32x16 o[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) ZERO16(o[d]);
-  float m = NEG_BIG, l = 0.f;
-  const float c = p.scale * LOG2E;
+  // running max m (log2 domain) enters the score MFMA as its accumulator input: s' = c * q.k - m is the exp2 argument
+  float m = 0.f, l = 0.f;
+  f32x16 negm;
+  ZERO16(negm);
   int kv_end = p.Skv;
   if (p.causal) kv_end = min(p.Skv, qblk + 128);  // keys beyond the block's last query are never visible
-  constexpr bool PF = DT <= 3;  // register prefetch of the next tile (skipped for wide heads: the registers are needed for O)
+  // K / V^T tiles are double-buffered in LDS (PF: DT <= 3): tile t+1 is written (from the registers its global loads landed in during
+  // tile t-1) while tile t is multiplied, so one barrier per tile suffices and the LDS stores overlap the MFMAs
+  constexpr bool PF = DT <= 3;  // wide heads keep the single-buffered, unprefetched schedule: the registers are needed for O
+  constexpr int TILE = RM<WD>::SIZE + TR<WD>::SIZE;
   TileRegs<WD> kreg, vreg;
   if (PF) {
     tile_load<WD>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
     tile_load<WD>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
-  }
-  for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
+    tile_store<WD, true, false>(kreg, Ks, nullptr);
+    tile_store<WD, false, true, ONES>(vreg, nullptr, Vt, p.hd);
+    if (KVT < kv_end) {
+      tile_load<WD>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
+      tile_load<WD>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
+    }
     __syncthreads();
-    if (!PF) {
+  }
+  int cur = 0;
+  for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
+    if (PF) {
+      Ks = reinterpret_cast<f16*>(smem_raw) + cur * TILE;
+      Vt = Ks + RM<WD>::SIZE;
+      if (kv0 + KVT < kv_end) {  // next tile -> the other buffer (every wave left it at the barrier that ended the previous iteration)
+        f16* Kn = reinterpret_cast<f16*>(smem_raw) + (cur ^ 1) * TILE;
+        tile_store<WD, true, false>(kreg, Kn, nullptr);
+        tile_store<WD, false, true, ONES>(vreg, nullptr, Kn + RM<WD>::SIZE, p.hd);
+        if (kv0 + 2 * KVT < kv_end) {
+          tile_load<WD>(kreg, Kg, p.ldk, kv0 + 2 * KVT, p.Skv, p.hd);
+          tile_load<WD>(vreg, Vg, p.ldv, kv0 + 2 * KVT, p.Skv, p.hd);
+        }
+      }
+    } else {
+      __syncthreads();
       tile_load<WD>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
       tile_load<WD>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
-    }
-    tile_store<WD, true, false>(kreg, Ks, nullptr);
-    tile_store<WD, false, true>(vreg, nullptr, Vt);
-    __syncthreads();
-    if (PF && kv0 + KVT < kv_end) {  // next tile's loads fly under this tile's MFMAs
-      tile_load<WD>(kreg, Kg, p.ldk, kv0 + KVT, p.Skv, p.hd);
-      tile_load<WD>(vreg, Vg, p.ldv, kv0 + KVT, p.Skv, p.hd);
+      tile_store<WD, true, false>(kreg, Ks, nullptr);
+      tile_store<WD, false, true, ONES>(vreg, nullptr, Vt, p.hd);
+      __syncthreads();
     }
     f32x16 s[2];
+    TB_PRIO(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      ZERO16(s[kt]);
+      s[kt] = negm;
 #pragma unroll
       for (int j = 0; j < KS; ++j)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s[kt], 0, 0, 0);
     }
+    TB_PRIO(0);
     // masking is needed only on the ragged last tile / the causal diagonal: wave-uniform test keeps it off the common path
     const bool need_mask = (kv0 + KVT > p.Skv) || (p.causal && kv0 + KVT - 1 > qblk + wave * 32);
     if (need_mask) {
@@ -187,30 +236,41 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_f
           s[kt][r] = ok ? s[kt][r] : -INFINITY;
         }
     }
-    float mx = NEG_BIG;  // running max in the log2 domain: max(s) * c  (c > 0)
+    float mx0 = s[0][0], mx1 = s[1][0];  // excess of this tile's scores over the running max
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-    const float m_new = fmaxf(m, mx);
-    if (__any(m_new > m)) {  // rescale only when some row's max moved (rare after the first tiles)
-      const float alpha = fast_exp2(m - m_new);
-      l *= alpha;
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    for (int r = 1; r < 15; r += 2) {
+      mx0 = max3f(mx0, s[0][r], s[0][r + 1]);
+      mx1 = max3f(mx1, s[1][r], s[1][r + 1]);
     }
-    m = m_new;
+    float mx = max3f(mx0, mx1, fmaxf(s[0][15], s[1][15]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const bool first = kv0 == 0;  // key 0 is visible to every query, so the first tile always has a finite maximum
+    if (first || __any(mx > 0.f)) {  // re-base only when some row's max moved (rare after the first tiles)
+      const float d = first ? mx : fmaxf(mx, 0.f);
+      if (!first) {
+        const float alpha = fast_exp2(-d);
+        l *= alpha;
+#pragma unroll
+        for (int dd = 0; dd < DT; ++dd)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+      m += d;
+      FILL16(negm, -m);
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(fmaf(s[kt][r], c, -m_new));
+        const float pv = fast_exp2(s[kt][r]);
         s[kt][r] = pv;
-        l += pv;
+        if (!ONES) l += pv;
       }
+    TB_PRIO(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -220,8 +280,24 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_f
         for (int d = 0; d < DT; ++d)
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Vt, d * 32 + l31, kt * 32 + 16 * jj, hi), pf, o[d], 0, 0, 0);
       }
+    TB_PRIO(0);
+    if (PF) {
+      __syncthreads();
+      cur ^= 1;
+    }
   }
-  l += __shfl_xor(l, 32, 64);
+  if (ONES) {
+    // the all-ones row hd of V^T made O^T row hd the row sum; it sits in register 4*g of the hi == 0 lane of tile hd / 32
+    float ls = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (d * 32 + g * 8 == p.hd) ls = o[d][4 * g];
+    l = __shfl(ls, l31, 64);
+  } else {
+    l += __shfl_xor(l, 32, 64);
+  }
   if (q < p.Sq) {
     const float inv = 1.f / l;
     f16* Og = (f16*)p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * p.hd;
@@ -271,7 +347,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
   f16* Vs = Ks + RM<WD>::SIZE;
   f16* Kt = Vs + RM<WD>::SIZE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR): the mask tests below become scalar branches
   const int b = blockIdx.z, h = blockIdx.y;
   const int qblk = blockIdx.x * 128;
   const int q = qblk + wave * 32 + l31;
@@ -282,6 +359,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
   f16x8 qf[KS], dof[KS];
   load_row_frags<KS>(qf, Qg, p.ldq, q, p.Sq, p.hd, hi);
   load_row_frags<KS>(dof, dOg, p.lddo, q, p.Sq, p.hd, hi);
+  scale_frags<KS>(qf, p.scale * LOG2E);  // as in the forward: scores arrive in the log2 domain
   const bool qok = q < p.Sq;
   const int64_t sidx = ((int64_t)b * p.H + h) * p.Sq + (qok ? q : 0);
   const float lse2 = p.LSE[sidx] * LOG2E;
@@ -305,7 +383,13 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
 #else
   const float delta = p.Delta[sidx];
 #endif
-  const float c = p.scale * LOG2E;
+  // FOLD: -lse and -delta enter the two products as accumulator inputs (S' = c q.k - lse is the exp2 argument, dP' = dO.v - delta);
+  // costs 32 registers, so the wide-head instantiations (already AGPR-bound at one wave per SIMD) subtract explicitly instead
+  constexpr bool FOLD = DT <= 2;
+  f32x16 neg_lse, neg_delta;
+  FILL16(neg_lse, FOLD ? -lse2 : 0.f);
+  FILL16(neg_delta, FOLD ? -delta : 0.f);
+  const float sub_l = FOLD ? 0.f : lse2, sub_d = FOLD ? 0.f : delta;
   f32x16 dq[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) ZERO16(dq[d]);
@@ -333,8 +417,13 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16 s, dp;
-      ZERO16(s);
-      ZERO16(dp);
+      if (FOLD) {
+        s = neg_lse;
+        dp = neg_delta;
+      } else {
+        ZERO16(s);
+        ZERO16(dp);
+      }
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s, 0, 0, 0);
@@ -346,12 +435,12 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + kt * 32 + mfma32_row(r, hi);
           const bool ok = qok && key < p.Skv && (!p.causal || key <= q);
-          const float pv = ok ? fast_exp2(fmaf(s[r], c, -lse2)) : 0.f;
-          s[r] = pv * p.scale * (dp[r] - delta);  // dS^T
+          const float pv = ok ? fast_exp2(FOLD ? s[r] : s[r] - sub_l) : 0.f;
+          s[r] = pv * (FOLD ? dp[r] : dp[r] - sub_d);  // dS^T / scale
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c, -lse2)) * p.scale * (dp[r] - delta);
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(FOLD ? s[r] : s[r] - sub_l) * (FOLD ? dp[r] : dp[r] - sub_d);
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -372,7 +461,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
         if (col < p.hd) {
           f16x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (f16)dq[d][4 * r4 + e];
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(dq[d][4 * r4 + e] * p.scale);
           *(f16x4*)(dQg + col) = v;
         }
       }
@@ -393,7 +482,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   f16* dOt = Qt + TR<WD>::SIZE;
   float* lse_s = reinterpret_cast<float*>(dOt + TR<WD>::SIZE);
   float* del_s = lse_s + KVT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR): the mask tests below become scalar branches
   const int b = blockIdx.z, h = blockIdx.y;
   const int kblk = (blockIdx.x / qsplit) * 128;
   const int qslice = blockIdx.x % qsplit;
@@ -408,7 +498,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   f16x8 kf[KS], vf[KS];
   load_row_frags<KS>(kf, Kg, p.ldk, key, p.Skv, p.hd, hi);
   load_row_frags<KS>(vf, Vg, p.ldv, key, p.Skv, p.hd, hi);
-  const float c = p.scale * LOG2E;
+  scale_frags<KS>(kf, p.scale * LOG2E);  // the lane-owned operand carries scale * log2(e) (K here, Q in the other two kernels)
   f32x16 dk[DT], dv[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
@@ -434,8 +524,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
     tile_store<WD, true, true>(doreg, dOs, dOt);
     if (threadIdx.x < KVT) {
       const int qq = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = qq < p.Sq ? LSEg[qq] * LOG2E : 0.f;
-      del_s[threadIdx.x] = qq < p.Sq ? DELg[qq] : 0.f;
+      lse_s[threadIdx.x] = qq < p.Sq ? -LSEg[qq] * LOG2E : 0.f;  // negated: they are the accumulator inputs of the two products
+      del_s[threadIdx.x] = qq < p.Sq ? -DELg[qq] : 0.f;
     }
     __syncthreads();
     if (PF && q0 + KVT < q_end) {
@@ -444,20 +534,31 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      f32x16 s, dp;
-      ZERO16(s);
-      ZERO16(dp);
+      // per-row -lse / -delta: rows of register quad g are 8g + 4hi + {0..3} -> one 16-byte LDS read per quad.  FOLD (see the dQ
+      // kernel): they are the accumulator inputs of the two products; otherwise they are added to the results below
+      constexpr bool FOLD = DT <= 2;
+      f32x16 s, dp, nl, nd;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 lq = *(const f32x4*)(lse_s + qt * 32 + 8 * g4 + 4 * hi);
+        const f32x4 dq4 = *(const f32x4*)(del_s + qt * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          nl[4 * g4 + e] = lq[e];
+          nd[4 * g4 + e] = dq4[e];
+        }
+      }
+      if (FOLD) {
+        s = nl;
+        dp = nd;
+      } else {
+        ZERO16(s);
+        ZERO16(dp);
+      }
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Qs, qt * 32 + l31, 2 * j + hi), kf[j], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(dOs, qt * 32 + l31, 2 * j + hi), vf[j], dp, 0, 0, 0);
-      }
-      // per-row lse / delta: rows of register quad g are 8g + 4hi + {0..3} -> one 16-byte LDS read per quad
-      f32x4 lq[4], dq4[4];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        lq[g4] = *(const f32x4*)(lse_s + qt * 32 + 8 * g4 + 4 * hi);
-        dq4[g4] = *(const f32x4*)(del_s + qt * 32 + 8 * g4 + 4 * hi);
       }
       const bool need_mask = (q0 + qt * 32 + 32 > p.Sq) || (kblk + wave * 32 + 32 > p.Skv) || (p.causal && kblk + wave * 32 + 31 > q0 + qt * 32);
       if (need_mask) {
@@ -465,16 +566,16 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
         for (int r = 0; r < 16; ++r) {
           const int qq = q0 + qt * 32 + mfma32_row(r, hi);
           const bool ok = kok && qq < p.Sq && (!p.causal || key <= qq);
-          const float pv = ok ? fast_exp2(fmaf(s[r], c, -lq[r >> 2][r & 3])) : 0.f;
-          s[r] = pv;                                                   // P
-          dp[r] = pv * p.scale * (dp[r] - dq4[r >> 2][r & 3]);         // dS
+          const float pv = ok ? fast_exp2(FOLD ? s[r] : s[r] + nl[r]) : 0.f;
+          s[r] = pv;                                       // P
+          dp[r] = pv * (FOLD ? dp[r] : dp[r] + nd[r]);     // dS / scale
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = fast_exp2(fmaf(s[r], c, -lq[r >> 2][r & 3]));
+          const float pv = fast_exp2(FOLD ? s[r] : s[r] + nl[r]);
           s[r] = pv;
-          dp[r] = pv * p.scale * (dp[r] - dq4[r >> 2][r & 3]);
+          dp[r] = pv * (FOLD ? dp[r] : dp[r] + nd[r]);
         }
       }
 #pragma unroll
@@ -503,7 +604,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
           f32x4 a, bb;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            a[e] = dk[d][4 * r4 + e];
+            a[e] = dk[d][4 * r4 + e] * p.scale;
             bb[e] = dv[d][4 * r4 + e];
           }
           *(f32x4*)(dK32 + col) = a;
@@ -522,7 +623,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
           f16x4 a, bb;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            a[e] = (f16)dk[d][4 * r4 + e];
+            a[e] = (f16)(dk[d][4 * r4 + e] * p.scale);
             bb[e] = (f16)dv[d][4 * r4 + e];
           }
           *(f16x4*)(dKg + col) = a;
@@ -551,9 +652,12 @@ __global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __r
 template <int DT, int KS>
 int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
-  size_t lds = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16);
+  size_t lds = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16) * (DT <= 3 ? 2 : 1);  // double-buffered K / V^T tiles
   dim3 grid((d.Sq + 127) / 128, d.H, d.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<DT, KS>), grid, dim3(256), lds, s, d);
+  if (d.hd < WD)  // head-dim padding exists: the row sum rides on the PV product (all-ones row hd of V^T)
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true>), grid, dim3(256), lds, s, d);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false>), grid, dim3(256), lds, s, d);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
