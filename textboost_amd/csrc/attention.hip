@@ -151,7 +151,7 @@ __device__ __forceinline__ void scale_frags(f16x8* f, float c) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int DT, int KS, bool ONES>
-__global__ __launch_bounds__(256, (DT <= 2 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {
+__global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {  // 3 blocks/CU only where 168 VGPRs hold without spills
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
