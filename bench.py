@@ -53,9 +53,11 @@ def roofline_leg(step):
                  "tflops": round(v[2] / v[1] / 1e12, 1) if v[2] else None,
                  "gbps": round(v[3] / v[1] / 1e9, 1) if v[3] else None} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     achieved = fl / t / 1e12
+    total_flop = sum(v[2] for v in agg.values())
     roof = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2),
             "alg_flop_per_launch": fl / n, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "recorded_matmul_tflop_per_step": round(total_flop / 1e12, 3)}  # sum of 2MNK / attention FLOP over the step's launches
     return roof, table
 
 
@@ -126,7 +128,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE.json metric: 8)")
-    ap.add_argument("--latent", type=int, default=64, help="latent side (512^2 images -> 64)")
+    ap.add_argument("--latent", type=int, default=None, help="latent side (default 64 = 512^2 images; 96 for --workload sd21)")
+    ap.add_argument("--workload", choices=["sd15", "sd21"], default="sd15",
+                    help="sd15 = the BASELINE.json metric (configs[1]); sd21 = SURVEY 8(d) config 4 shapes (SD2.x UNet, OpenCLIP-H text "
+                         "encoder, LoRA r=8, 96^2 latents) -- a secondary measurement, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -154,8 +159,13 @@ def main():
     from textboost_amd.workload import build_step
 
     torch.manual_seed(42)  # the reference seeds every rank identically (train_textboost.py:601); data is offset by rank
+    from textboost_amd import models
+    sd21 = args.workload == "sd21"
+    if args.latent is None:
+        args.latent = 96 if sd21 else 64
     step, added = build_step(batch=args.batch, latent=args.latent, data_seed=1000 + rank, world_size=world,
-                             device=torch.device("cuda", local))
+                             device=torch.device("cuda", local), unet_geo=models.SD21_UNET if sd21 else models.SD15_UNET,
+                             clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4)
     step.force_dist = force_dist
     if args.no_graph:
         for _ in range(2):
@@ -185,7 +195,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         roof, table = roofline_leg(step)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sd21:  # the CPU baseline is the headline workload's
         try:
             cpu = cpu_baseline_leg()
         except Exception as e:  # the baseline is a reported reference, never fatal to the GPU number
@@ -194,18 +204,27 @@ def main():
         dist.barrier()
     if rank == 0:
         sps = args.steps * 1.0 / dt
+        flop_per_image = FLOP_PER_IMAGE
+        metric = "train steps/sec (batch=8, 512^2, SD1.5, LoRA r=4)"
+        workload = ("BASELINE.json configs[1]: SD1.5 UNet (859.5M, frozen, fwd + dgrad bwd) + CLIP-L text encoder LoRA r=4 on "
+                    "q/k/v (fwd x2 + bwd x2) + fp16 KPL teacher fwd, per-GPU batch %d, %dx%d latents (512^2), 18 added token vectors, "
+                    "MSE + 0.1*KPL(cos), GradScaler + clip + AdamW + renorm on device; random-init weights; step as one HIP graph"
+                    % (args.batch, args.latent, args.latent))
+        if sd21:  # secondary measurement; algorithmic FLOP taken from the recorded launches of the eager leg
+            metric = "train steps/sec (batch=%d, SD2.1 shapes, %d^2 latents, LoRA r=8)" % (args.batch, args.latent)
+            workload = ("SURVEY 8(d) config 4: SD2.x UNet (865.9M, Linear proj_in/out, head dim 64) + OpenCLIP-H text encoder (23 layers, "
+                        "D=1024) LoRA r=8 + KPL teacher, per-GPU batch %d, %dx%d latents; random-init weights; one HIP graph"
+                        % (args.batch, args.latent, args.latent))
+            flop_per_image = (roof["recorded_matmul_tflop_per_step"] * 1e12 / args.batch) if roof else float("nan")
         out = {
-            "metric": "train steps/sec (batch=8, 512^2, SD1.5, LoRA r=4)", "value": round(sps, 4), "unit": "steps/s",
+            "metric": metric, "value": round(sps, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: SD1.5 UNet (859.5M, frozen, fwd + dgrad bwd) + CLIP-L text encoder LoRA r=4 on "
-                                   "q/k/v (fwd x2 + bwd x2) + fp16 KPL teacher fwd, per-GPU batch %d, %dx%d latents (512^2), 18 added token vectors, "
-                                   "MSE + 0.1*KPL(cos), GradScaler + clip + AdamW + renorm on device; random-init weights; step as one HIP graph"
-                                   % (args.batch, args.latent, args.latent),
+            "config": {"workload": workload,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "images_per_s": round(sps * args.batch * world, 2)},
-            "alg_tflops_per_gpu": round(sps * args.batch * FLOP_PER_IMAGE / 1e12, 2),
-            "frac_of_mfma_peak_whole_step": round(sps * args.batch * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "alg_tflops_per_gpu": round(sps * args.batch * flop_per_image / 1e12, 2),
+            "frac_of_mfma_peak_whole_step": round(sps * args.batch * flop_per_image / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "loss": sc["loss"], "loss_scale": sc["loss_scale"], "found_inf_last": sc["found_inf"], "opt_steps": sc["opt_steps"],
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -809,8 +809,22 @@ int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   return TB_OK;
 }
 
+int g_variant64 = -1;  // k-tile depth of the 64x64 tile (tb_gemm_set_variant(10 + v)): -1 = by grid size, 0 = BK64 x 2 stages, 4 = x 3, 5 = x 4
+
 template <int BM, int BN, int MODE>
 int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
+  if (BM == 64 && BN == 64) {
+    // The small tile runs latency-bound GEMMs (a k-tile of MFMA work is ~1/8 of an L2 round trip).  When the grid is at most two
+    // blocks per CU the LDS is free for a 4-stage ring (3 k-tiles in flight); larger grids keep 2 stages and 5 blocks per CU
+    // (scratch/tile64.py, one MI355X: 512x1280x1280 16.2 -> 14.1 us, 1232x768x768 12.3 -> 10.8; 2048x1280x1280 (640 blocks) 20.7 vs 27.9)
+    const int64_t nblk = ((d.M + 63) / 64) * ((d.N + 63) / 64) * S;
+    const int v = g_variant64 >= 0 ? g_variant64 : (nblk <= 512 ? 5 : 0);
+    switch (v) {
+      case 4: return launch_v<BM, BN, MODE, 64, 3>(d, s, S);
+      case 5: return launch_v<BM, BN, MODE, 64, 4>(d, s, S);
+      default: return launch_v<BM, BN, MODE, 64, 2>(d, s, S);
+    }
+  }
   switch (g_variant) {
     case 1: return launch_v<BM, BN, MODE, 32, 3>(d, s, S);
     case 2: return launch_v<BM, BN, MODE, 32, 2>(d, s, S);
@@ -893,7 +907,10 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
     // too few tiles to fill 256 CUs: split K across blocks (fp32 partials in ws, fixed-order reduction -> deterministic)
     const int64_t nk = d.K / 64;
     const int64_t npad = (d.N + 7) / 8 * 8;
-    int64_t want = blocks < g_split_blocks && nk >= g_split_minnk ? (g_split_target + blocks - 1) / blocks : 1;  // short K: a second pass costs more
+    // short K: a second pass costs more.  When the un-split 64x64 grid already has >= 2 blocks per CU only very long K pays
+    // (2048x1280: K=2560 30.6 us un-split vs 36.1 split, K=3840 41.0 vs 44.1, K=5120 62.3 vs 50.1)
+    const int64_t minnk = (!narrow && blocks * 4 >= 512 && g_split_minnk == 32) ? 80 : g_split_minnk;
+    int64_t want = blocks < g_split_blocks && nk >= minnk ? (g_split_target + blocks - 1) / blocks : 1;
     if (want > nk / g_split_min_tiles) want = nk / g_split_min_tiles;
     if (want > 16) want = 16;
     const int64_t fit = d.ws_bytes / (int64_t)(d.M * npad * sizeof(float));
@@ -926,6 +943,7 @@ extern "C" int tb_gemm_set_variant(int v) {
   else if (v >= 3000) g_order = v - 3000;
   else if (v >= 2000) g_ablate = v - 2000;
   else if (v >= 1000) g_split_target = v - 1000;  // 1000 disables split-K, 1512 = default target of 512 blocks
+  else if (v >= 9 && v < 20) g_variant64 = v - 10;  // 9 = automatic
   else g_variant = v;
   return old;
 }

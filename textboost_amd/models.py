@@ -17,6 +17,8 @@ from .unet import UNetGeometry
 SD15_UNET = UNetGeometry()
 SD21_UNET = UNetGeometry(num_heads=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True)
 SD15_CLIP = CLIPGeometry()
+# SD2.x text encoder: OpenCLIP ViT-H/14 text tower, 23 of its 24 layers (penultimate-layer output), erf-GELU MLP
+SD21_CLIP = CLIPGeometry(hidden_size=1024, intermediate_size=4096, num_layers=23, num_heads=16, act="gelu")
 
 
 def unet_shapes(geo: UNetGeometry) -> Dict[str, Tuple[int, ...]]:
