@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--workload", choices=["sd15", "sd21"], default="sd15",
                     help="sd15 = the BASELINE.json metric (configs[1]); sd21 = SURVEY 8(d) config 4 shapes (SD2.x UNet, OpenCLIP-H text "
                          "encoder, LoRA r=8, 96^2 latents) -- a secondary measurement, never the headline")
+    ap.add_argument("--vae", action="store_true",
+                    help="secondary measurement: the step starts from 8x-larger RGB pixels and runs the SD VAE encoder first "
+                         "(train_textboost.py:1036-1037; SURVEY 8(f).1) -- the BASELINE.json metric uses synthetic latents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -165,7 +168,7 @@ def main():
         args.latent = 96 if sd21 else 64
     step, added = build_step(batch=args.batch, latent=args.latent, data_seed=1000 + rank, world_size=world,
                              device=torch.device("cuda", local), unet_geo=models.SD21_UNET if sd21 else models.SD15_UNET,
-                             clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4)
+                             clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4, with_vae=args.vae)
     step.force_dist = force_dist
     if args.no_graph:
         for _ in range(2):
@@ -195,7 +198,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         roof, table = roofline_leg(step)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sd21:  # the CPU baseline is the headline workload's
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sd21 and not args.vae:  # the CPU baseline is the headline workload's
         try:
             cpu = cpu_baseline_leg()
         except Exception as e:  # the baseline is a reported reference, never fatal to the GPU number
@@ -210,6 +213,10 @@ def main():
                     "q/k/v (fwd x2 + bwd x2) + fp16 KPL teacher fwd, per-GPU batch %d, %dx%d latents (512^2), 18 added token vectors, "
                     "MSE + 0.1*KPL(cos), GradScaler + clip + AdamW + renorm on device; random-init weights; step as one HIP graph"
                     % (args.batch, args.latent, args.latent))
+        if args.vae:
+            metric = metric[:-1] + ", + VAE encoder on %d^2 pixels)" % (8 * args.latent)
+            workload += "; PLUS the SD VAE encoder (34.2M, fp16 MFMA / fp32 stats) on resident [B,3,%d,%d] fp32 pixels inside the graph" % (
+                8 * args.latent, 8 * args.latent)
         if sd21:  # secondary measurement; algorithmic FLOP taken from the recorded launches of the eager leg
             metric = "train steps/sec (batch=%d, SD2.1 shapes, %d^2 latents, LoRA r=8)" % (args.batch, args.latent)
             workload = ("SURVEY 8(d) config 4: SD2.x UNet (865.9M, Linear proj_in/out, head dim 64) + OpenCLIP-H text encoder (23 layers, "

@@ -45,10 +45,11 @@ typedef struct tb_gemm_desc {
   const void* W2; int64_t ldw2;  /* fp16 [N, K-K1] */
   int32_t a_mode;                /* TB_A_LINEAR | TB_A_CONV3X3 */
   /* conv gather geometry: output pixel (b,y,x) of an Hout x Wout map, tap (ky,kx):
-   *   plain      : src = (y*stride + sign*(ky-1), x*stride + sign*(kx-1))          in Hin x Win
+   *   plain      : src = (y*stride + sign*(ky-1) + shift, x*stride + sign*(kx-1) + shift)   in Hin x Win
+   *                (shift = 1, stride = 2: the VAE's Downsample2D, F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0))
    *   upsample   : u = (y + ky-1, x + kx-1) in 2Hin x 2Win, src = u >> 1  (nearest x2 folded into the gather)
    *   transposed : dgrad of a stride-2 conv: src = ((y+1-ky)/2, (x+1-kx)/2) where both are even & in range */
-  int32_t B, Hin, Win, Cin, Hout, Wout, stride, sign, upsample, transposed;
+  int32_t B, Hin, Win, Cin, Hout, Wout, stride, sign, upsample, transposed, shift;
   /* epilogue: v = alpha*acc + bias[n] + rowbias[(m / rows_per_group)*N + n] + R[m,n]; v = act(v) */
   float alpha;
   const float* bias;             /* fp32 [N] or NULL */
@@ -137,9 +138,18 @@ int tb_timestep_embed(const int64_t* timesteps, void* out, int B, int dim, tb_st
  * input-gradient (sign=-1).  w_packed fp32 [(tap*4 + c4)*Cout + co]. */
 int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
                      int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream);
+/* same with Cin = 3 or 4 input channels (w_packed fp32 [(tap*Cin + ci)*Cout + co]): the VAE encoder's conv_in on RGB pixels */
+int tb_convin_to_nhwc(const void* in, int in_dtype, int Cin, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
+                      int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream);
 /* UNet conv_out forward: NHWC fp16 [B*H*W, C] -> NCHW fp16 [B,4,H,W]; w_packed fp32 [4][9][C] */
 int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, const float* bias, void* out, int B, int H, int W, int C,
                 tb_stream_t stream);
+/* ---- VAE encoder pieces (vae.encode(x).latent_dist.sample() * scaling_factor, train_textboost.py:1036-1037) ----
+ * row softmax of fp32 scores -> fp16 probabilities (single-head 512-channel mid-block attention runs as GEMM, softmax, GEMM) */
+int tb_softmax_rows(const float* scores, int64_t lds, void* probs /* fp16 */, int64_t ldp, int64_t rows, int cols, tb_stream_t stream);
+/* moments fp32 NHWC [B*HW, ldm >= 2L] = (mean | logvar) -> latents fp32 NCHW [B, L, HW] = (mean + exp(0.5 clamp(logvar,-30,20)) eps) * scale */
+int tb_vae_sample(const float* moments, int64_t ldm, const float* eps, float* latents, int B, int HW, int L, float scale,
+                  tb_stream_t stream);
 /* F.mse_loss(pred.float(), target.float()).mean() (:1085-1090); dpred = loss_scale[0] * dloss/dpred (fp32) */
 int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
                 tb_stream_t stream);

@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("a_mode", C.c_int32),
         ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
         ("Wout", C.c_int32), ("stride", C.c_int32), ("sign", C.c_int32), ("upsample", C.c_int32), ("transposed", C.c_int32),
+        ("shift", C.c_int32),
         ("alpha", C.c_float),
         ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int64), ("ldrb", C.c_int64),
         ("R", C.c_void_p), ("ldr", C.c_int64), ("r_dtype", C.c_int32),
@@ -76,6 +77,9 @@ _SIGS = {
     "tb_add_noise": ([_VP, _VP, _VP, _VP, _VP, _VP, _I, _I64, _VP], C.c_int),
     "tb_timestep_embed": ([_VP, _VP, _I, _I, _VP], C.c_int),
     "tb_conv4_to_nhwc": ([_VP, _I, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_convin_to_nhwc": ([_VP, _I, _I, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_softmax_rows": ([_VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
+    "tb_vae_sample": ([_VP, _I64, _VP, _VP, _I, _I, _I, _F, _VP], C.c_int),
     "tb_conv_to4": ([_VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _VP], C.c_int),
     "tb_mse_loss": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP], C.c_int),
     "tb_kpl_cos": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),

@@ -33,7 +33,7 @@ __global__ void timestep_embed_kernel(const int64_t* __restrict__ t, f16* __rest
 
 // ---- 3x3 conv with 4 channels on the NCHW side (UNet conv_in forward; conv_out input-gradient), fp32 accumulate.
 // out[m, co] (NHWC fp16, row stride ldo) = bias[co] + sum_{tap, ci<4} in[b, ci, y+sign*(ky-1), x+sign*(kx-1)] * Wp[(tap*4+ci)*Cout + co]
-template <typename TIN>
+template <typename TIN, int CIN>
 __global__ __launch_bounds__(256) void conv4_to_nhwc_kernel(const TIN* __restrict__ in, const float* __restrict__ Wp,
                                                             const float* __restrict__ bias, f16* __restrict__ out, int64_t ldo,
                                                             int B, int H, int W, int Cout, int sign, float in_scale) {
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void conv4_to_nhwc_kernel(const TIN* __restric
     const int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
     if (sy < 0 || sx < 0 || sy >= H || sx >= W) continue;
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-      const float v = (float)in[(((int64_t)b * 4 + ci) * H + sy) * W + sx] * in_scale;
-      const float* w = Wp + (int64_t)(tap * 4 + ci) * Cout + cg * 8;
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float v = (float)in[(((int64_t)b * CIN + ci) * H + sy) * W + sx] * in_scale;
+      const float* w = Wp + (int64_t)(tap * CIN + ci) * Cout + cg * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += v * w[e];
     }
@@ -262,6 +262,58 @@ __global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ in,
   out[m * ldo + c] = (TO)((float)in[m * ldi + c] * scale);
 }
 
+// ---- row softmax of fp32 scores -> fp16 probabilities (the VAE mid-block attention: one head of 512 channels over 4096 pixels
+// does not fit the flash kernels' head-dim range, so it runs as GEMM -> this -> GEMM).  One block per row; upcast_softmax=True.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds, f16* __restrict__ P, int64_t ldp,
+                                                           int cols) {
+  __shared__ float red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* s = S + (int64_t)blockIdx.x * lds;
+  f16* p = P + (int64_t)blockIdx.x * ldp;
+  float mx = -INFINITY;
+  for (int c = t * 4; c < cols; c += 1024) {
+    const f32x4 v = *(const f32x4*)(s + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = t * 4; c < cols; c += 1024) {
+    const f32x4 v = *(const f32x4*)(s + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum += __expf(v[e] - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int c = t * 4; c < cols; c += 1024) {
+    const f32x4 v = *(const f32x4*)(s + c);
+    f16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (f16)(__expf(v[e] - mx) * inv);
+    *(f16x4*)(p + c) = o;
+  }
+}
+
+// ---- DiagonalGaussianDistribution.sample() * scaling_factor (train_textboost.py:1036-1037):
+// moments fp32 NHWC [B*HW, 2L] = (mean | logvar);  latents NCHW fp32 [B, L, HW] = (mean + exp(0.5 clamp(logvar, -30, 20)) * eps) * scale
+__global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ mom, int64_t ldm, const float* __restrict__ eps,
+                                                         float* __restrict__ out, int B, int HW, int Lc, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B * L * HW (NCHW order)
+  if (idx >= (int64_t)B * Lc * HW) return;
+  const int pix = (int)(idx % HW);
+  const int c = (int)((idx / HW) % Lc);
+  const int b = (int)(idx / ((int64_t)HW * Lc));
+  const float* m = mom + ((int64_t)b * HW + pix) * ldm;
+  const float lv = fminf(fmaxf(m[Lc + c], -30.f), 20.f);
+  out[idx] = (m[c] + __expf(0.5f * lv) * eps[idx]) * scale;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
@@ -285,19 +337,29 @@ extern "C" int tb_timestep_embed(const int64_t* timesteps, void* out, int B, int
   return TB_OK;
 }
 
-extern "C" int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
-                                int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream) {
+extern "C" int tb_convin_to_nhwc(const void* in, int in_dtype, int Cin, const float* w_packed, const float* bias, void* out, int64_t ldo,
+                                 int B, int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!in || !w_packed || !out || Cout % 8 || ldo % 8 || (sign != 1 && sign != -1)) return TB_EINVAL;
+  if (!in || !w_packed || !out || Cout % 8 || ldo % 8 || (sign != 1 && sign != -1) || (Cin != 3 && Cin != 4)) return TB_EINVAL;
   const int64_t n = (int64_t)B * H * W * (Cout / 8);
-  if (in_dtype == TB_F32)
-    hipLaunchKernelGGL(conv4_to_nhwc_kernel<float>, GRID1D(n), dim3(256), 0, (hipStream_t)stream, (const float*)in, w_packed, bias,
-                       (f16*)out, ldo, B, H, W, Cout, sign, in_scale);
-  else
-    hipLaunchKernelGGL(conv4_to_nhwc_kernel<f16>, GRID1D(n), dim3(256), 0, (hipStream_t)stream, (const f16*)in, w_packed, bias,
-                       (f16*)out, ldo, B, H, W, Cout, sign, in_scale);
+  hipStream_t s = (hipStream_t)stream;
+#define TB_CONVIN(T, CI) \
+  hipLaunchKernelGGL((conv4_to_nhwc_kernel<T, CI>), GRID1D(n), dim3(256), 0, s, (const T*)in, w_packed, bias, (f16*)out, ldo, B, H, W, Cout, sign, in_scale)
+  if (in_dtype == TB_F32) {
+    if (Cin == 4) TB_CONVIN(float, 4);
+    else TB_CONVIN(float, 3);
+  } else {
+    if (Cin == 4) TB_CONVIN(f16, 4);
+    else TB_CONVIN(f16, 3);
+  }
+#undef TB_CONVIN
   TB_CHECK_LAUNCH();
   return TB_OK;
+}
+
+extern "C" int tb_conv4_to_nhwc(const void* in, int in_dtype, const float* w_packed, const float* bias, void* out, int64_t ldo, int B,
+                                int H, int W, int Cout, int sign, float in_scale, tb_stream_t stream) {
+  return tb_convin_to_nhwc(in, in_dtype, 4, w_packed, bias, out, ldo, B, H, W, Cout, sign, in_scale, stream);
 }
 
 extern "C" int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, const float* bias, void* out, int B, int H, int W, int C,
@@ -398,6 +460,24 @@ extern "C" int tb_convert(const void* in, int64_t ldi, int in_dtype, void* out, 
     hipLaunchKernelGGL((convert_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, M, C, scale);
   else
     hipLaunchKernelGGL((convert_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)in, ldi, (f16*)out, ldo, M, C, scale);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_softmax_rows(const float* scores, int64_t lds, void* probs, int64_t ldp, int64_t rows, int cols, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!scores || !probs || rows <= 0 || cols <= 0 || cols % 4 || lds % 4 || ldp % 4) return TB_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, scores, lds, (f16*)probs, ldp, cols);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_vae_sample(const float* moments, int64_t ldm, const float* eps, float* latents, int B, int HW, int L, float scale,
+                             tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!moments || !eps || !latents || B <= 0 || HW <= 0 || L <= 0 || ldm < 2 * L) return TB_EINVAL;
+  hipLaunchKernelGGL(vae_sample_kernel, GRID1D((int64_t)B * L * HW), dim3(256), 0, (hipStream_t)stream, moments, ldm, eps, latents, B, HW,
+                     L, scale);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -530,8 +530,8 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
             sx = tx >> 1;
             ok = ok && sy < p.Hin && sx < p.Win;
           } else {
-            sy = py[i] * p.stride + p.sign * (ky - 1);
-            sx = px[i] * p.stride + p.sign * (kx - 1);
+            sy = py[i] * p.stride + p.sign * (ky - 1) + p.shift;
+            sx = px[i] * p.stride + p.sign * (kx - 1) + p.shift;
             ok = sy >= 0 && sx >= 0 && sy < p.Hin && sx < p.Win;
           }
           ok = ok && a_ok[i];
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
 
 // ------------------------------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input HALO tile (used when a 128-pixel output tile is a whole number of image
-// rows): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
+// rows, W = 16 / 32 / 64, or a 128-pixel segment of one row, W % 128 == 0 -- the VAE encoder's 128..512-wide maps): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
 // fragments from that halo at shifted row addresses; only the weight tiles stream per tap.  Compared with gemm_kernel's
 // per-tap gather this moves 4.4x fewer activation bytes through the L2->LDS path that bounds the kernel.
 template <int BN>
@@ -643,13 +643,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   constexpr int BM = 128, BK = 64;
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
   constexpr int BI = BN / 32;  // weight-tile load instructions per wave per tap
-  constexpr int MAXHI = 9;     // halo load instructions per wave (<= ceil(33 / 4))
+  constexpr int MAXHI = 13;    // halo load instructions per wave (<= ceil(49 / 4): 3 x 130 halo pixels of a 128-pixel row segment)
 #define SWZ(row) ((((row) >> 1) & 7))
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int W = 1 << wshift, H = p.Hout, R = BM >> wshift;
-  const int HC = W + 2, NH = (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
+  // tile = R rows of TW = min(W, 128) pixels: whole image rows for W <= 64, a 128-pixel segment of one row for W = 128, 256, ...
+  const int TW = 1 << wshift, W = p.Wout, H = p.Hout, R = BM >> wshift;
+  const int HC = TW + 2, NH = (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
   f16* Hs = smem;
   f16* Wst = smem + NH8 * BK;  // two weight stages of BN x 64 halfs
 
@@ -673,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int hw = H * W;
   const int b = (int)(m0 / hw);
-  const int y0 = (int)(m0 - (int64_t)b * hw) >> wshift;  // first image row of the tile
+  const int rem0 = (int)(m0 - (int64_t)b * hw);
+  const int y0 = rem0 / W, x0 = rem0 - y0 * W;  // first image row / column of the tile (x0 = 0 unless W > 128)
 
   const int cp = lane & 7, rl = lane >> 3;
   // ---- halo sources of this lane (fixed across channel chunks, + 64 halfs per chunk)
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
     const int j = wave + 4 * i;  // instruction index; rows j*8 .. j*8+7 of the halo image
     const int hr = j * 8 + rl;
     const int hy = hr / HC, hx = hr - hy * HC;
-    const int yy = y0 - 1 + hy, xx = hx - 1;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
     const bool ok = j < NI && hr < NH && yy >= 0 && yy < H && xx >= 0 && xx < W;
     h_ptr[i] = ok ? (const f16*)p.A + ((int64_t)b * hw + (int64_t)yy * W + xx) * p.lda + ((cp ^ SWZ(hr)) << 3) : zero;
     h_step[i] = ok ? BK : 0;
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int ml = wm * WTM + i * 32 + l31;
-    hrow0[i] = (ml >> wshift) * HC + (ml & (W - 1));
+    hrow0[i] = (ml >> wshift) * HC + (ml & (TW - 1));
   }
 
   for (int c = c_begin; c < c_end; ++c) {
@@ -844,8 +846,8 @@ int g_split_target = 384;  // split K until about this many blocks exist (A/B: 2
 template <int BN>
 int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
   const int tiles_m = (int)(d.M / 128), tiles_n = (int)((d.N + BN - 1) / BN);
-  const int W = 1 << wshift, R = 128 >> wshift;
-  const int nh8 = ((R + 2) * (W + 2) + 7) & ~7;
+  const int TW = 1 << wshift, R = 128 >> wshift;
+  const int nh8 = ((R + 2) * (TW + 2) + 7) & ~7;
   size_t lds = (size_t)nh8 * 128 + 2 * (size_t)BN * 128;
   if (lds < (size_t)128 * BN * sizeof(float)) lds = (size_t)128 * BN * sizeof(float);
   g_last_cfg[0] = 128, g_last_cfg[1] = BN, g_last_cfg[2] = 2, g_last_cfg[3] = 642, g_last_cfg[4] = S;
@@ -885,8 +887,8 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
   const bool by_rule = narrow && !odd64;  // such grids are never small enough for the 64x64 fallback below
 #endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
-  if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && d.Hin == d.Hout && d.Win == d.Wout &&
-      (d.Wout == 16 || d.Wout == 32 || d.Wout == 64) && ((int64_t)d.Hout * d.Wout) % 128 == 0) {
+  if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && !d.shift && d.Hin == d.Hout && d.Win == d.Wout &&
+      (d.Wout == 16 || d.Wout == 32 || d.Wout == 64 || d.Wout % 128 == 0) && ((int64_t)d.Hout * d.Wout) % 128 == 0) {
     // too few tiles for 256 CUs: split the 64-channel chunks over S blocks per tile (fp32 partials + the split-K reducer)
     int Sh = 1;
     const int kpt = d.Cin / 64;
@@ -898,7 +900,7 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
       if (want > 1) Sh = (int)want;
     }
     if (blocks * Sh >= 200) {
-      const int wshift = d.Wout == 64 ? 6 : (d.Wout == 32 ? 5 : 4);
+      const int wshift = d.Wout >= 128 ? 7 : (d.Wout == 64 ? 6 : (d.Wout == 32 ? 5 : 4));
       return (narrow || (g_conv_narrow & 1)) ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
     }
   }
@@ -969,7 +971,7 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;
     if (d.M != (int64_t)d.B * d.Hout * d.Wout) return TB_EINVAL;
     if (d.sign != 1 && d.sign != -1) return TB_EINVAL;
-    if (d.stride < 1) return TB_EINVAL;
+    if (d.stride < 1 || (d.shift && (d.upsample || d.transposed))) return TB_EINVAL;
   } else if (d.a_mode != TB_A_LINEAR) {
     return TB_EINVAL;
   }

@@ -213,6 +213,23 @@ def conv4_to_nhwc(x, w_packed, bias, out, B, H, W, Cout, sign=1, in_scale=1.0):
                                      in_scale, L.stream()), "tb_conv4_to_nhwc")
 
 
+def convin_to_nhwc(x, cin, w_packed, bias, out, B, H, W, Cout, sign=1, in_scale=1.0):
+    L.check(L.lib().tb_convin_to_nhwc(L.ptr(x), _dt(x), cin, L.ptr(w_packed), L.ptr(bias), L.ptr(out), out.stride(0), B, H, W, Cout,
+                                      sign, in_scale, L.stream()), "tb_convin_to_nhwc")
+
+
+def softmax_rows(scores, probs):
+    """fp32 [rows, cols] scores -> fp16 probabilities (row softmax)."""
+    rows, cols = scores.shape
+    L.check(L.lib().tb_softmax_rows(L.ptr(scores), scores.stride(0), L.ptr(probs), probs.stride(0), rows, cols, L.stream()),
+            "tb_softmax_rows")
+
+
+def vae_sample(moments, eps, latents, B, HW, Lc, scale):
+    L.check(L.lib().tb_vae_sample(L.ptr(moments), moments.stride(0), L.ptr(eps), L.ptr(latents), B, HW, Lc, scale, L.stream()),
+            "tb_vae_sample")
+
+
 def conv_to4(x, w_packed, bias, out, B, H, W, C):
     L.check(L.lib().tb_conv_to4(L.ptr(x), x.stride(0), L.ptr(w_packed), L.ptr(bias), L.ptr(out), B, H, W, C, L.stream()), "tb_conv_to4")
 

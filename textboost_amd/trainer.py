@@ -126,18 +126,32 @@ class TextBoostStep:
         self.graph = None
         self.external_noise = False
         self.side = torch.cuda.Stream(device=device) if self.kpl else None
+        self.vae = None  # attach_vae(): the step then starts from pixels (:1027-1037) instead of latents
+
+    def attach_vae(self, vae):
+        """Run `vae.encode(pixel_values).latent_dist.sample() * scaling_factor` (:1036-1037) at the top of every step, inside the
+        captured graph: `pixel_values` [B,3,8h,8w] fp32 becomes the step's static input and `x0` an internal buffer."""
+        B, C, h, w = self.x0.shape
+        assert vae.B == B and vae.H == 8 * h and vae.W == 8 * w and vae.geo.latent_channels == C
+        self.vae = vae
+        self.pixel_values = torch.zeros(B, vae.geo.in_channels, vae.H, vae.W, device=self.dev)
+        self.vae_eps = torch.zeros(B, C, h, w, device=self.dev)
 
     # ------------------------------------------------------------------ pieces
     def draw(self):
         """:1041-1048 -- noise ~ N(0,1), timesteps ~ U{0..T-1} from torch generators (never inside custom kernels)."""
         if self.external_noise:
             return
+        if self.vae is not None:  # DiagonalGaussianDistribution.sample() draws first (:1036), then the diffusion noise (:1041)
+            self.vae_eps.normal_(generator=self.gen)
         self.noise.normal_(generator=self.gen)
         self.timesteps.random_(0, self.hp.num_train_timesteps, generator=self.gen)
 
     def forward_backward(self):
         hp, te, B = self.hp, self.te, self.B
         st = self.state
+        if self.vae is not None:
+            self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))                  # :1027-1037
         ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
         te.pack_lora()
         BT = B * te.T

@@ -34,7 +34,7 @@ def synthetic_ids(B, added_ids, gen: torch.Generator, prior=False, null_prob=0.1
 
 def build_step(batch=8, latent=64, unet_geo: UNetGeometry = models.SD15_UNET, clip_geo: CLIPGeometry = models.SD15_CLIP,
                lora_rank=4, n_added=18, hyper: StepHyper | None = None, weight_seed=1234, data_seed=1000, device="cuda",
-               world_size=1):
+               world_size=1, with_vae=False):
     """Config 2 of BASELINE.json by default: SD1.5 UNet + CLIP-L, per-GPU batch 8, 512^2 (64^2 latents), LoRA r=4, KPL on,
     18 added token vectors (2 placeholder + 16 augmentation vectors)."""
     hyper = hyper or StepHyper()
@@ -59,6 +59,12 @@ def build_step(batch=8, latent=64, unet_geo: UNetGeometry = models.SD15_UNET, cl
     step = TextBoostStep(unet, te, teacher, hyper, (batch, 4, latent, latent), device=device, world_size=world_size)
     dg = torch.Generator().manual_seed(data_seed)
     step.x0.copy_(torch.randn(batch, 4, latent, latent, generator=dg))
+    if with_vae:  # the reference's full step: pixels in [-1, 1] -> VAE encoder -> latents (train_textboost.py:1027-1037)
+        from .vae import HipVAEEncoder, VAEGeometry, vae_encoder_shapes
+        vgeo = VAEGeometry()
+        vsd = models.random_state_dict(vae_encoder_shapes(vgeo), weight_seed + 4, device=device)
+        step.attach_vae(HipVAEEncoder(vgeo, vsd, batch, 8 * latent, 8 * latent, device=device))
+        step.pixel_values.copy_(torch.rand(batch, 3, 8 * latent, 8 * latent, generator=dg) * 2 - 1)
     step.input_ids.copy_(synthetic_ids(batch, added, dg))
     step.prior_ids.copy_(synthetic_ids(batch, added, dg, prior=True))
     return step, added

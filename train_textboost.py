@@ -6,8 +6,11 @@
 
 What runs here is the reference's hot path (train_textboost.py:1024-1150) on the HIP kernels of libtextboost_hip.so, behind
 the reference's flags (:49-450) and output layout (:1157-1209, :1236-1266).  Out of scope in this round:
-the VAE encoder, the PIL/augmentation data pipeline, validation sampling.  The trainer therefore consumes LATENTS:
+the PIL/augmentation data pipeline and validation sampling.  The trainer therefore consumes preprocessed tensors:
 
+  * `<instance_data_dir>/pixel_values.pt` -- a [N,3,R,R] fp32 tensor in [-1,1] (what `TextBoostDataset` yields, dataset.py:420-457):
+    the SD VAE encoder then runs on the device at the top of every step, exactly where the reference calls it (:1036-1037;
+    weights from `<pretrained_model_name_or_path>/vae/diffusion_pytorch_model.safetensors`, else seeded random init), or
   * `<instance_data_dir>/latents.pt`   -- a [N,4,h,w] fp32 tensor of `vae.encode(x).latent_dist.sample()*scaling_factor`
     (+ optional `input_ids.pt` [N,77] / `prior_input_ids.pt` [M,77] int64 from the reference's tokenizer), or
   * synthetic latents and token ids when no such file exists -- there is no network, tokenizer or checkpoint in
@@ -95,6 +98,10 @@ def main(args):
     latent = args.resolution // 8
     lat_path = os.path.join(args.instance_data_dir or "", "latents.pt")
     latents = torch.load(lat_path) if args.instance_data_dir and os.path.exists(lat_path) else None
+    px_path = os.path.join(args.instance_data_dir or "", "pixel_values.pt")
+    pixels = torch.load(px_path) if args.instance_data_dir and os.path.exists(px_path) else None
+    if pixels is not None:
+        latents, latent = None, pixels.shape[-1] // 8
     if latents is not None:
         latent = latents.shape[-1]
     unet = HipUNet(unet_geo, usd, B, latent, latent, text_len=clip_geo.max_pos, device=dev)
@@ -130,6 +137,14 @@ def main(args):
     if args.with_image_prior or args.unet_params_to_train != "none":
         raise NotImplementedError("--with_image_prior (broken in the reference, SURVEY 0.6) / --unet_params_to_train are outside this round's hot path")
     step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
+    if pixels is not None:  # :651-656, :938: the (frozen) VAE; the step then starts from pixel_values (:1027-1037)
+        from textboost_amd.vae import HipVAEEncoder, VAEGeometry, vae_encoder_shapes
+        vsd = load_local_state_dict(os.path.join(mdir, "vae", "diffusion_pytorch_model.safetensors")) if os.path.isdir(mdir) else None
+        if vsd is None:
+            logger.warning("no local VAE weights under %s: seeded random-init SD VAE encoder shapes are used", mdir)
+            vsd = models.random_state_dict(vae_encoder_shapes(VAEGeometry()), 1236, device=dev)
+        step.attach_vae(HipVAEEncoder(VAEGeometry(), vsd, B, 8 * latent, 8 * latent, device=dev))
+        del vsd
 
     # ---- data: latents (+ ids) from disk, else synthetic; rank r takes samples r, r+W, ... (every shard non-empty: SURVEY 0.6)
     dg = torch.Generator().manual_seed(1000 + rank)
@@ -139,14 +154,19 @@ def main(args):
     prior_ids = torch.load(pids_path) if os.path.exists(pids_path) else None
 
     def next_batch(it):
-        if latents is not None:
+        if pixels is not None:
+            idx = shard_indices(pixels.shape[0], B, it, rank, world)
+            step.pixel_values.copy_(pixels[idx])
+            if inst_ids is not None:
+                step.input_ids.copy_(inst_ids[[i % inst_ids.shape[0] for i in idx]])
+        elif latents is not None:
             idx = shard_indices(latents.shape[0], B, it, rank, world)
             step.x0.copy_(latents[idx])
             if inst_ids is not None:
                 step.input_ids.copy_(inst_ids[[i % inst_ids.shape[0] for i in idx]])
         else:
             step.x0.copy_(torch.randn(B, 4, latent, latent, generator=dg))
-        if latents is None or inst_ids is None:
+        if (latents is None and pixels is None) or inst_ids is None:
             step.input_ids.copy_(synthetic_ids(B, added_ids, dg))
         if prior_ids is not None:
             j = torch.randint(0, prior_ids.shape[0], (B,), generator=dg)
