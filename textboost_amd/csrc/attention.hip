@@ -56,18 +56,36 @@ struct TileRegs {
   static constexpr int NI = (ITEMS + 255) / 256;      // items per thread
   f16x8 v[NI][4];
 };
-template <int WD>
+typedef const __attribute__((address_space(1))) f16x8* gvec8_t;  // explicit global address space: a select against the zero line must
+                                                                  // not degrade the loads to flat_load (which also ticks lgkmcnt and
+                                                                  // would make every LDS wait drain the prefetch)
+// FAST adds a test-free path for tiles whose 64 rows all exist (costs registers for the second code path: enabled where measured
+// faster -- the narrow-head backward kernels, L0 self-attention backward 1184 -> 1104 us; off for the forward (spills at 3 waves/SIMD)
+// and for the AGPR-bound wide heads)
+template <int WD, bool FAST = false>
 __device__ __forceinline__ void tile_load(TileRegs<WD>& t, const f16* g, int64_t ld, int row0, int nrows, int hd) {
   constexpr int CPR = TileRegs<WD>::CPR;
+  const bool full = FAST && row0 + KVT <= nrows;  // wave-uniform: every row of the tile exists
 #pragma unroll
   for (int it = 0; it < TileRegs<WD>::NI; ++it) {
     const int idx = threadIdx.x + it * 256;
     const int kg = idx / CPR, ch = idx - kg * CPR;
+    const bool item = idx < TileRegs<WD>::ITEMS, colok = ch * 8 < hd;
+    if (full) {
+      // common path: no per-row tests.  Chunks in the head-dim padding (ch*8 >= hd) read the row's first chunk instead of zeros: they
+      // only ever meet zero-filled fragments of the lane-owned operand (S, dP) or land in output rows >= hd that are never stored
+      if (item) {
+        const f16* base = g + (int64_t)(row0 + kg * 4) * ld + (colok ? ch * 8 : 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = row0 + kg * 4 + k;
-      const bool ok = idx < TileRegs<WD>::ITEMS && row < nrows && ch * 8 < hd;
-      t.v[it][k] = *(const f16x8*)(ok ? g + (int64_t)row * ld + ch * 8 : g_zero8);
+        for (int k = 0; k < 4; ++k) t.v[it][k] = *(gvec8_t)(base + (int64_t)k * ld);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = row0 + kg * 4 + k;
+        const bool ok = item && row < nrows && colok;
+        t.v[it][k] = *(ok ? (gvec8_t)(g + (int64_t)row * ld + ch * 8) : (gvec8_t)g_zero8);
+      }
     }
   }
 }
@@ -125,7 +143,7 @@ __device__ __forceinline__ void load_row_frags(f16x8* f, const f16* g, int64_t l
 #pragma unroll
   for (int j = 0; j < KS; ++j) {
     const int col = 16 * j + 8 * hi;
-    f[j] = *(const f16x8*)((row < nrows && col < hd) ? g + (int64_t)row * ld + col : g_zero8);
+    f[j] = *((row < nrows && col < hd) ? (gvec8_t)(g + (int64_t)row * ld + col) : (gvec8_t)g_zero8);
   }
 }
 
@@ -150,8 +168,13 @@ __device__ __forceinline__ void scale_frags(f16x8* f, float c) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+#ifdef TB_FWD_OCC2
+#define TB_FWD_OCC3 0
+#else
+#define TB_FWD_OCC3 1
+#endif
 template <int DT, int KS, bool ONES>
-__global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {  // 3 blocks/CU only where 168 VGPRs hold without spills
+__global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {  // 3 blocks/CU only where 168 VGPRs hold without spills
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
@@ -398,21 +421,21 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
   constexpr bool PF = DT <= 2;
   TileRegs<WD> kreg, vreg;
   if (PF) {
-    tile_load<WD>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
-    tile_load<WD>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+    tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
   }
   for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
     __syncthreads();
     if (!PF) {
-      tile_load<WD>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
-      tile_load<WD>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
     }
     tile_store<WD, true, true>(kreg, Ks, Kt);
     tile_store<WD, true, false>(vreg, Vs, nullptr);
     __syncthreads();
     if (PF && kv0 + KVT < kv_end) {
-      tile_load<WD>(kreg, Kg, p.ldk, kv0 + KVT, p.Skv, p.hd);
-      tile_load<WD>(vreg, Vg, p.ldv, kv0 + KVT, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, kv0 + KVT, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, kv0 + KVT, p.Skv, p.hd);
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -511,14 +534,14 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   constexpr bool PF = DT <= 2;
   TileRegs<WD> qreg, doreg;
   if (PF && q_begin < q_end) {
-    tile_load<WD>(qreg, Qg, p.ldq, q_begin, p.Sq, p.hd);
-    tile_load<WD>(doreg, dOg, p.lddo, q_begin, p.Sq, p.hd);
+    tile_load<WD, (DT <= 2)>(qreg, Qg, p.ldq, q_begin, p.Sq, p.hd);
+    tile_load<WD, (DT <= 2)>(doreg, dOg, p.lddo, q_begin, p.Sq, p.hd);
   }
   for (int q0 = q_begin; q0 < q_end; q0 += KVT) {
     __syncthreads();
     if (!PF) {
-      tile_load<WD>(qreg, Qg, p.ldq, q0, p.Sq, p.hd);
-      tile_load<WD>(doreg, dOg, p.lddo, q0, p.Sq, p.hd);
+      tile_load<WD, (DT <= 2)>(qreg, Qg, p.ldq, q0, p.Sq, p.hd);
+      tile_load<WD, (DT <= 2)>(doreg, dOg, p.lddo, q0, p.Sq, p.hd);
     }
     tile_store<WD, true, true>(qreg, Qs, Qt);
     tile_store<WD, true, true>(doreg, dOs, dOt);
@@ -529,8 +552,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
     }
     __syncthreads();
     if (PF && q0 + KVT < q_end) {
-      tile_load<WD>(qreg, Qg, p.ldq, q0 + KVT, p.Sq, p.hd);
-      tile_load<WD>(doreg, dOg, p.lddo, q0 + KVT, p.Sq, p.hd);
+      tile_load<WD, (DT <= 2)>(qreg, Qg, p.ldq, q0 + KVT, p.Sq, p.hd);
+      tile_load<WD, (DT <= 2)>(doreg, dOg, p.lddo, q0 + KVT, p.Sq, p.hd);
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
