@@ -111,3 +111,74 @@ def test_metric_config_properties_at_batch_8():
     ids[0, 1:] = 49407
     h = te.forward(ids, slot=0).view(ids.shape[0], 77, -1)
     assert torch.equal(h[0], te.null_embedding) and torch.equal(h[3, 0], te.null_embedding[0])
+
+
+def test_sd21_unet_full_size_forward_backward_vs_oracle():
+    """SURVEY 8(d) config 4 shapes: SD2.x UNet (865.9 M; Linear proj_in/out, 5/10/20/20 heads of dim 64, cross dim 1024), B=1, 64^2."""
+    from oracle.unet_sd import UNet2DCondition, UNetConfig
+    from textboost_amd import models
+    from textboost_amd.unet import HipUNet
+    torch.manual_seed(0)
+    assert models.count_params(models.unet_shapes(models.SD21_UNET)) == 865_910_724
+    sd = models.random_state_dict(models.unet_shapes(models.SD21_UNET), 79, device="cpu")
+    sd = {k: v.half().float() for k, v in sd.items()}
+    with torch.device("meta"):
+        ref = UNet2DCondition(UNetConfig.sd21())
+    ref = ref.to_empty(device="cpu")
+    ref.load_state_dict(sd)
+    B = 1
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 4, 64, 64, generator=g).half().float()
+    t = torch.tensor([402])
+    ehs = torch.randn(B, 77, 1024, generator=g).half().float().requires_grad_(True)
+    pred_ref = ref(x, t, ehs)
+    dpred = torch.randn(B, 4, 64, 64, generator=g)
+    pred_ref.backward(dpred)
+    hip = HipUNet(models.SD21_UNET, {k: v.to(dev) for k, v in sd.items()}, B, 64, 64, device=dev)
+    pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, 1024).to(dev).contiguous())
+    e = rel_err(pred, pred_ref)
+    assert e < 2e-2, f"SD2.1 UNet forward rel-L2 {e}"
+    d_ehs = hip.backward(dpred.to(dev))
+    e = rel_err(d_ehs.view(B, 77, 1024), ehs.grad)
+    assert e < 5e-2, f"SD2.1 UNet d_ehs rel-L2 {e}"
+
+
+def test_openclip_h_full_size_forward_backward_vs_oracle():
+    """SD2.x text encoder shapes (23 layers, D=1024, 16 heads, erf-GELU MLP), LoRA r=8, B=1."""
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle import train_step as ts
+    from textboost_amd import models
+    from textboost_amd.text_encoder import HipTextEncoder
+    torch.manual_seed(0)
+    assert models.count_params(models.clip_shapes(models.SD21_CLIP)) == 340_387_840
+    csd = models.random_state_dict(models.clip_shapes(models.SD21_CLIP), 80, device="cpu")
+    ref = TextBoostEncoder(CLIPTextCfg.sd21(), r=8)
+    ref.load_hf_state_dict(csd)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.02)
+        null = ref.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    ref.set_null_embedding(null)
+    added = add_tokens(ref, [11, 22])
+    B = 1
+    hip = HipTextEncoder(models.SD21_CLIP, csd, B, mode="autocast", lora_rank=8, device=dev, seed=0)
+    hip.set_null_embedding(null)
+    hip.add_tokens([11, 22])
+    for i, layer in enumerate(ref.layers):
+        hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
+        hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
+    g = torch.Generator().manual_seed(3)
+    ids = ts.synthetic_ids(B, added, g)
+    out_ref = ref(ids)
+    R = torch.randn(B, 77, 1024, generator=g)
+    (out_ref * R).sum().backward()
+    hip.pack_lora()
+    out = hip.forward(ids.to(dev))
+    assert rel_err(out.view(B, 77, 1024), out_ref) < 5e-3
+    hip.zero_grad()
+    hip.backward(R.view(B * 77, 1024).to(dev).contiguous())
+    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
+    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
+    assert rel_err(hip.grad_A, gA) < 3e-2 and rel_err(hip.grad_B, gB) < 3e-2
+    assert rel_err(hip.grad_added, ref.token_embedding.weight.grad[added]) < 3e-2
