@@ -11,7 +11,6 @@ Scalars (loss, loss scale, grad norm, found_inf, step count) stay on the device 
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -162,26 +161,21 @@ class TextBoostStep:
         if self.kpl:
             fork = torch.cuda.Event()
             fork.record(main)
-        late = os.environ.get("TB_TEACHER_LATE", "1") == "1"
-        if late:
-            pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)       # :1063-1067
+        pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)           # :1063-1067
         if self.kpl:                                                               # :1096-1106
-            # the frozen fp16 teacher + KPL loss depend only on the student's hidden states: they run on a side stream while the
-            # UNet occupies the main one (a fork/join inside the HIP graph).  The side work is ISSUED after the UNet forward: the
-            # graph executor submits nodes in creation order, and side nodes created first would be queued ahead of the UNet's.
-            side = main if os.environ.get("TB_NO_SIDE", "0") == "1" else self.side
-            side.wait_event(fork)
-            with torch.cuda.stream(side), ops.workspace_slot(1):
+            # the frozen fp16 teacher + KPL loss depend only on the student's hidden states: they are issued on a side stream (a
+            # fork/join inside the HIP graph) after the UNet forward.  ROCm 7 serialises the branch at replay (same steps/s with and
+            # without the second stream), so today this only keeps the dependency structure honest.
+            self.side.wait_event(fork)
+            with torch.cuda.stream(self.side), ops.workspace_slot(1):
                 h0 = self.teacher.forward(self.prior_ids, slot=0)
                 kpl = ops.kpl_cos if hp.kpl_type == "cos" else ops.kpl_mse
                 kpl(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
-        if not late:
-            pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
         ops.mse_loss(pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
         self.unet.backward(self.dpred, d_ehs_out=self.d_ehs)                       # :1108 (UNet part, dgrad only)
-        if self.kpl and side is not main:
-            main.wait_stream(side)
+        if self.kpl:
+            main.wait_stream(self.side)
         self.flat_grad.zero_()
         te.backward(self.d_all, slot=0)
         if hp.mixing is not None:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
