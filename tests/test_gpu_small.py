@@ -295,3 +295,27 @@ def test_geglu_grad_epilogue_matches_separate_kernel():
     hh, gg = pr.chunk(2, dim=-1)
     (hh * F.gelu(gg)).backward(dgated)
     assert rel_err(dproj, pack_geglu(pr.grad.T.contiguous()).T) < 3e-3
+
+
+@pytest.mark.parametrize("r", [2, 4, 8])
+def test_lora_backward_ranks(r):
+    """tb_lora_bwd at the generic, rank-4 and rank-8 instantiations (the reference default r=4; SD2.1 config r=8) vs autograd."""
+    from textboost_amd import ops
+    torch.manual_seed(r)
+    M, K, Dm, P = 154, 256, 192, 3
+    x = torch.randn(M, K, device=dev).half()
+    A = torch.randn(P * r, K, device=dev) / r
+    Bc = torch.randn(P * Dm, r, device=dev) * 0.1
+    t = torch.zeros(M, 64, device=dev, dtype=torch.float16)
+    ops.lora_down(x, A, t)
+    dY = torch.randn(M, P * Dm, device=dev).half()
+    dt = torch.zeros(M, 64, device=dev, dtype=torch.float16)
+    dA = torch.zeros_like(A); dB = torch.zeros_like(Bc)
+    ops.lora_bwd(dY, x, t, Bc, dt, dA, dB, Dm, K, r, P, scaling=0.5)
+    xr = x.float()
+    Ar = A.clone().requires_grad_(True); Br = Bc.clone().requires_grad_(True)
+    lo = 0.5 * torch.cat([(xr @ Ar[p_ * r:(p_ + 1) * r].T) @ Br[p_ * Dm:(p_ + 1) * Dm].T for p_ in range(P)], dim=1)
+    lo.backward(dY.float())
+    assert rel_err(dA, Ar.grad) < 5e-3 and rel_err(dB, Br.grad) < 5e-3
+    ref_dt = 0.5 * torch.cat([dY.float()[:, p_ * Dm:(p_ + 1) * Dm] @ Bc[p_ * Dm:(p_ + 1) * Dm].half().float() for p_ in range(P)], dim=1)
+    assert rel_err(dt[:, :P * r], ref_dt) < 3e-3 and dt[:, P * r:].abs().max() == 0

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 // chip.  A second kernel adds the partials in slab order (deterministic).
 constexpr int LORA_RS = 8;
 constexpr int LORA_MAXR = 24;  // P * r
-template <int R4>  // r == 4 fast path (vector loads of B rows / t rows) or generic r <= 8
+template <int RR>  // RR = r when r is 4 or 8 (16-byte vector loads of the B rows, fully unrolled), 0 = generic r <= 8
 __global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ x, int64_t ldx,
                                                              const f16* __restrict__ t, int64_t ldt, const float* __restrict__ Bcat,
                                                              f16* __restrict__ dt, int64_t lddt, float* __restrict__ partB,
@@ -158,13 +158,16 @@ __global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restri
         for (int n = lane * 8; n < D; n += 512) {
           const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + (int64_t)p * D + n);
           const float* bp = Bcat + ((int64_t)p * D + n) * r;
-          if (R4) {
+          if (RR) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const f32x4 b = *(const f32x4*)(bp + 4 * e);
               const float d = (float)dy[e];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc[j] += d * (float)(f16)b[j];
+              for (int q = 0; q < RR / 4; ++q) {
+                const f32x4 b = *(const f32x4*)(bp + RR * e + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] += d * (float)(f16)b[j];
+              }
             }
           } else {
 #pragma unroll
@@ -204,20 +207,22 @@ __global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restri
         const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + n);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (j < (R4 ? 4 : r)) {
+          if (j < (RR ? RR : r)) {
             const float tv = ts[i][p * r + j];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e][j] += (float)dy[e] * tv;
           }
       }
-      if (R4) {
+      if (RR) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          f32x4 v;
+        for (int e = 0; e < 8; ++e)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[e][j];
-          *(f32x4*)(o + (int64_t)(n + e) * 4) = v;
-        }
+          for (int q = 0; q < RR / 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[e][4 * q + j];
+            *(f32x4*)(o + (int64_t)(n + e) * RR + 4 * q) = v;
+          }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -377,19 +382,20 @@ extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t 
   if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || !ws || r > 8 || P * r > LORA_MAXR) return TB_EINVAL;
   if (D % 8 || K % 8 || lddy % 8 || ldx % 8 || (P * D * r) % 4 || (P * r * K) % 4) return TB_EINVAL;  // 16-byte vector accesses
   if (((uintptr_t)dY) % 16 || ((uintptr_t)x) % 16 || ((uintptr_t)dA) % 16 || ((uintptr_t)dB) % 16 || ((uintptr_t)ws) % 16 ||
-      (r == 4 && ((uintptr_t)Bcat) % 16))
+      ((r == 4 || r == 8) && ((uintptr_t)Bcat) % 16))
     return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nslab = (int)((M + LORA_RS - 1) / LORA_RS);
   const int64_t nB = (int64_t)P * D * r, nA = (int64_t)P * r * K;
   float* partB = ws;
   float* partA = ws + (int64_t)nslab * nB;
-  if (r == 4)
-    hipLaunchKernelGGL(lora_bwd_fused_kernel<1>, dim3(nslab, 2), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)x, ldx, (const f16*)t,
-                       ldt, Bcat, (f16*)dt, lddt, partB, partA, M, D, K, r, P, scaling);
-  else
-    hipLaunchKernelGGL(lora_bwd_fused_kernel<0>, dim3(nslab, 2), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)x, ldx, (const f16*)t,
-                       ldt, Bcat, (f16*)dt, lddt, partB, partA, M, D, K, r, P, scaling);
+#define TB_LORA_BWD(RR)                                                                                                                   \
+  hipLaunchKernelGGL(lora_bwd_fused_kernel<RR>, dim3(nslab, 2), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)x, ldx, (const f16*)t, \
+                     ldt, Bcat, (f16*)dt, lddt, partB, partA, M, D, K, r, P, scaling)
+  if (r == 4) TB_LORA_BWD(4);
+  else if (r == 8) TB_LORA_BWD(8);
+  else TB_LORA_BWD(0);
+#undef TB_LORA_BWD
   hipLaunchKernelGGL(lora_slab_reduce_kernel, GRID1D((nB + nA) / 4), dim3(256), 0, s, partB, partA, dB, dA, nB, nA, nslab, scaling);
   TB_CHECK_LAUNCH();
   return TB_OK;
