@@ -150,6 +150,15 @@ int tb_softmax_rows(const float* scores, int64_t lds, void* probs /* fp16 */, in
 /* moments fp32 NHWC [B*HW, ldm >= 2L] = (mean | logvar) -> latents fp32 NCHW [B, L, HW] = (mean + exp(0.5 clamp(logvar,-30,20)) eps) * scale */
 int tb_vae_sample(const float* moments, int64_t ldm, const float* eps, float* latents, int B, int HW, int L, float scale,
                   tb_stream_t stream);
+/* ---- validation / inference sampling (log_validation train_textboost.py:453-531, inference.py:73-100) ----
+ * out[b,o,p] = scale * sum_c W[o,c] in[b,c,p] + bias[o] on NCHW fp32, C <= 8: AutoencoderKL.post_quant_conv with latents / scaling_factor */
+int tb_chan_mix(const float* in, const float* W, const float* bias, float* out, int B, int C, int HW, float scale, tb_stream_t stream);
+/* one DPMSolverMultistepScheduler(dpmsolver++, order 2) step with classifier-free guidance: eps2 = UNet output fp16 [2B, n] (uncond | cond);
+ * eps = e_u + g (e_c - e_u); m0 = (x - sigma_t eps) / alpha_t; x = ca x + cb m0 + cc m_prev; m_prev = m0; x2 = fp16 (x | x) for the next call */
+int tb_dpm_step(float* x, const void* eps2, float* m_prev, void* x2, int64_t n_per_b, int B, float guidance, float alpha_t, float sigma_t,
+                float ca, float cb, float cc, tb_stream_t stream);
+/* (decoded / 2 + 0.5).clamp(0, 1): NHWC fp32 [B*HW, ld >= C] -> NCHW fp32 [B, C, HW] */
+int tb_vae_image(const float* decoded, int64_t ld, float* image, int B, int HW, int C, tb_stream_t stream);
 /* F.mse_loss(pred.float(), target.float()).mean() (:1085-1090); dpred = loss_scale[0] * dloss/dpred (fp32) */
 int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
                 tb_stream_t stream);

@@ -80,6 +80,9 @@ _SIGS = {
     "tb_convin_to_nhwc": ([_VP, _I, _I, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP], C.c_int),
     "tb_softmax_rows": ([_VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_vae_sample": ([_VP, _I64, _VP, _VP, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_chan_mix": ([_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_dpm_step": ([_VP, _VP, _VP, _VP, _I64, _I, _F, _F, _F, _F, _F, _F, _VP], C.c_int),
+    "tb_vae_image": ([_VP, _I64, _VP, _I, _I, _I, _VP], C.c_int),
     "tb_conv_to4": ([_VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _VP], C.c_int),
     "tb_mse_loss": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP], C.c_int),
     "tb_kpl_cos": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),

@@ -314,6 +314,54 @@ __global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict
   out[idx] = (m[c] + __expf(0.5f * lv) * eps[idx]) * scale;
 }
 
+// ---- sampling path (train_textboost.py:453-531 log_validation, inference.py) ------------------------------------
+// 1x1 conv on a few channels of an NCHW fp32 tensor: out[b,o,p] = scale * sum_c W[o,c] in[b,c,p] + bias[o]   (the VAE's post_quant_conv,
+// with the pipeline's latents / scaling_factor folded into `scale`)
+__global__ __launch_bounds__(256) void chan_mix_kernel(const float* __restrict__ in, const float* __restrict__ Wm,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int C, int HW,
+                                                       float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B * HW
+  if (idx >= (int64_t)B * HW) return;
+  const int b = (int)(idx / HW), p = (int)(idx - (int64_t)b * HW);
+  float v[8];
+  for (int c = 0; c < C; ++c) v[c] = in[((int64_t)b * C + c) * HW + p];
+  for (int o = 0; o < C; ++o) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += Wm[o * C + c] * v[c];
+    out[((int64_t)b * C + o) * HW + p] = scale * a + (bias ? bias[o] : 0.f);
+  }
+}
+// One DPM-Solver++(2M) update with classifier-free guidance, elementwise over the latents x [B, n] (fp32):
+//   eps = e_u + g (e_c - e_u)            (e = UNet output fp16 [2B, n]: rows 0..B-1 unconditional, B..2B-1 conditional)
+//   m0  = (x - sigma_t eps) / alpha_t ;  x <- ca x + cb m0 + cc m_prev ;  m_prev <- m0 ;  x2 (fp16 [2B, n]) <- (x, x) for the next UNet call
+__global__ __launch_bounds__(256) void dpm_step_kernel(float* __restrict__ x, const f16* __restrict__ e, float* __restrict__ m_prev,
+                                                       f16* __restrict__ x2, int64_t n_per_b, int B, float g, float alpha_t,
+                                                       float sigma_t, float ca, float cb, float cc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tot = n_per_b * B;
+  if (i >= tot) return;
+  const float eu = (float)e[i], ec = (float)e[tot + i];
+  const float eps = eu + g * (ec - eu);
+  const float xv = x[i];
+  const float m0 = (xv - sigma_t * eps) / alpha_t;
+  const float xn = ca * xv + cb * m0 + cc * m_prev[i];
+  m_prev[i] = m0;
+  x[i] = xn;
+  x2[i] = (f16)xn;
+  x2[tot + i] = (f16)xn;
+}
+// image = (decoded / 2 + 0.5).clamp(0, 1): NHWC fp32 [B*HW, ld >= C] -> NCHW fp32 [B, C, HW]   (StableDiffusionPipeline post-processing)
+__global__ __launch_bounds__(256) void vae_image_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out, int B, int HW,
+                                                        int C) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B * C * HW (NCHW order: coalesced stores)
+  if (idx >= (int64_t)B * C * HW) return;
+  const int p = (int)(idx % HW);
+  const int c = (int)((idx / HW) % C);
+  const int b = (int)(idx / ((int64_t)HW * C));
+  const float v = in[((int64_t)b * HW + p) * ld + c] * 0.5f + 0.5f;
+  out[idx] = fminf(fmaxf(v, 0.f), 1.f);
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
@@ -478,6 +526,33 @@ extern "C" int tb_vae_sample(const float* moments, int64_t ldm, const float* eps
   if (!moments || !eps || !latents || B <= 0 || HW <= 0 || L <= 0 || ldm < 2 * L) return TB_EINVAL;
   hipLaunchKernelGGL(vae_sample_kernel, GRID1D((int64_t)B * L * HW), dim3(256), 0, (hipStream_t)stream, moments, ldm, eps, latents, B, HW,
                      L, scale);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_chan_mix(const float* in, const float* W, const float* bias, float* out, int B, int C, int HW, float scale,
+                           tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!in || !W || !out || B <= 0 || C <= 0 || C > 8 || HW <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(chan_mix_kernel, GRID1D((int64_t)B * HW), dim3(256), 0, (hipStream_t)stream, in, W, bias, out, B, C, HW, scale);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_dpm_step(float* x, const void* eps2, float* m_prev, void* x2, int64_t n_per_b, int B, float guidance, float alpha_t,
+                           float sigma_t, float ca, float cb, float cc, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!x || !eps2 || !m_prev || !x2 || n_per_b <= 0 || B <= 0 || alpha_t == 0.f) return TB_EINVAL;
+  hipLaunchKernelGGL(dpm_step_kernel, GRID1D(n_per_b * B), dim3(256), 0, (hipStream_t)stream, x, (const f16*)eps2, m_prev, (f16*)x2, n_per_b, B,
+                     guidance, alpha_t, sigma_t, ca, cb, cc);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_vae_image(const float* decoded, int64_t ld, float* image, int B, int HW, int C, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!decoded || !image || B <= 0 || HW <= 0 || C <= 0 || ld < C) return TB_EINVAL;
+  hipLaunchKernelGGL(vae_image_kernel, GRID1D((int64_t)B * C * HW), dim3(256), 0, (hipStream_t)stream, decoded, ld, image, B, HW, C);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -230,6 +230,19 @@ def vae_sample(moments, eps, latents, B, HW, Lc, scale):
             "tb_vae_sample")
 
 
+def chan_mix(x, W, bias, out, B, C, HW, scale=1.0):
+    L.check(L.lib().tb_chan_mix(L.ptr(x), L.ptr(W), L.ptr(bias), L.ptr(out), B, C, HW, scale, L.stream()), "tb_chan_mix")
+
+
+def dpm_step(x, eps2, m_prev, x2, n_per_b, B, guidance, alpha_t, sigma_t, ca, cb, cc):
+    L.check(L.lib().tb_dpm_step(L.ptr(x), L.ptr(eps2), L.ptr(m_prev), L.ptr(x2), n_per_b, B, guidance, alpha_t, sigma_t, ca, cb, cc,
+                                L.stream()), "tb_dpm_step")
+
+
+def vae_image(decoded, image, B, HW, C):
+    L.check(L.lib().tb_vae_image(L.ptr(decoded), decoded.stride(0), L.ptr(image), B, HW, C, L.stream()), "tb_vae_image")
+
+
 def conv_to4(x, w_packed, bias, out, B, H, W, C):
     L.check(L.lib().tb_conv_to4(L.ptr(x), x.stride(0), L.ptr(w_packed), L.ptr(bias), L.ptr(out), B, H, W, C, L.stream()), "tb_conv_to4")
 

@@ -1,0 +1,111 @@
+"""Validation / inference sampling on MI355X -- the device work of the reference's `log_validation` (train_textboost.py:453-531) and
+`inference.py:73-100`: diffusers `StableDiffusionPipeline.__call__` with `DPMSolverMultistepScheduler`, 25 steps, guidance 7.5.
+SURVEY.md 8(f) row 2.
+
+    ids (prompt, empty prompt) -> text encoder -> [classifier-free guidance: UNet on (x, x) with (uncond, cond)] x steps
+    -> DPM-Solver++(2M) update -> VAE decoder -> image in [0, 1]
+
+The UNet forward, the text encoder and the VAE decoder are the executors of this package; the per-step scalar coefficients of the solver
+are host arithmetic (`DPMSolverPP2M`, float64, computed once per schedule), the update itself is one elementwise kernel (`tb_dpm_step`).
+Nothing here synchronises with the host, so the whole loop can be captured in a HIP graph.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+class DPMSolverPP2M:
+    """diffusers DPMSolverMultistepScheduler as `from_config` builds it on SD's scheduler config: algorithm_type "dpmsolver++",
+    solver_order 2, solver_type "midpoint", epsilon prediction, timestep_spacing "linspace", final sigma zero (last step first order).
+    sigma = sqrt((1 - abar) / abar); alpha_t = 1 / sqrt(sigma^2 + 1); sigma_t = sigma alpha_t; lambda = log(alpha_t / sigma_t)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double()
+        self.T = num_train_timesteps
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n: int) -> List[int]:
+        ts = torch.linspace(0, self.T - 1, n + 1, dtype=torch.float64).round().flip(0)[:-1].long()
+        ac = self.alphas_cumprod[ts]
+        self.timesteps = ts.tolist()
+        self.sigmas = ((1 - ac) / ac).sqrt().tolist() + [0.0]
+        return self.timesteps
+
+    @staticmethod
+    def alpha_sigma(sigma: float) -> Tuple[float, float]:
+        a = 1.0 / math.sqrt(sigma * sigma + 1.0)
+        return a, sigma * a
+
+    def coefficients(self, i: int) -> Tuple[float, float, float]:
+        """x_next = ca x + cb m0 + cc m_prev  for step i  (m = data prediction (x - sigma_t eps) / alpha_t)."""
+        a0, st0 = self.alpha_sigma(self.sigmas[i])
+        a1, st1 = self.alpha_sigma(self.sigmas[i + 1])
+        if i == len(self.timesteps) - 1:      # sigma_next = 0: exp(-h) = 0, alpha_next = 1
+            return 0.0, a1, 0.0
+        lam0, lam1 = math.log(a0 / st0), math.log(a1 / st1)
+        h = lam1 - lam0
+        e = math.expm1(-h)
+        ca = st1 / st0
+        if i == 0:
+            return ca, -a1 * e, 0.0
+        ap, stp = self.alpha_sigma(self.sigmas[i - 1])
+        r0 = (lam0 - math.log(ap / stp)) / h
+        return ca, -a1 * e * (1.0 + 0.5 / r0), a1 * e * (0.5 / r0)
+
+
+class HipSampler:
+    """`sample(cond_ehs, uncond_ehs, latents=None) -> images [B,3,8h,8w] in [0,1]`.  `unet` must be built for batch 2B (guidance runs the
+    unconditional and conditional rows in one call, as the pipeline does), `vae_decoder` for batch B."""
+
+    def __init__(self, unet, vae_decoder, steps: int = 25, guidance: float = 7.5):
+        assert unet.B == 2 * vae_decoder.B and unet.H == vae_decoder.h and unet.W == vae_decoder.w
+        self.unet, self.vae, self.steps, self.g = unet, vae_decoder, steps, guidance
+        self.B = vae_decoder.B
+        self.sch = DPMSolverPP2M()
+        self.timesteps = self.sch.set_timesteps(steps)
+        dev = unet.dev
+        B, h, w = self.B, unet.H, unet.W
+        self.x = torch.zeros(B, 4, h, w, device=dev)
+        self.m_prev = torch.zeros(B, 4, h, w, device=dev)
+        self.x2 = torch.zeros(2 * B, 4, h, w, device=dev, dtype=torch.float16)
+        self.t_dev = [torch.full((2 * B,), t, dtype=torch.int64, device=dev) for t in self.timesteps]
+        self.generator: Optional[torch.Generator] = None
+
+    def denoise(self, cond_ehs, uncond_ehs, latents=None):
+        """cond / uncond: fp16 or fp32 [B*77, D] text-encoder outputs.  Returns the final latents fp32 [B,4,h,w]."""
+        B, sch = self.B, self.sch
+        if latents is None:
+            latents = torch.randn(self.x.shape, device=self.x.device, generator=self.generator)
+        self.x.copy_(latents * sch.init_noise_sigma)
+        self.m_prev.zero_()
+        self.x2[:B].copy_(self.x)
+        self.x2[B:].copy_(self.x)
+        ehs = torch.cat([uncond_ehs, cond_ehs]).to(torch.float16).contiguous()
+        n = self.x[0].numel()
+        for i in range(self.steps):
+            eps2 = self.unet.forward(self.x2, self.t_dev[i], ehs)
+            a_t, s_t = sch.alpha_sigma(sch.sigmas[i])
+            ca, cb, cc = sch.coefficients(i)
+            ops.dpm_step(self.x, eps2, self.m_prev, self.x2, n, B, self.g, a_t, s_t, ca, cb, cc)
+        return self.x
+
+    def sample(self, cond_ehs, uncond_ehs, latents=None):
+        return self.vae.decode(self.denoise(cond_ehs, uncond_ehs, latents))
+
+
+def make_image_grid(images: torch.Tensor, rows: int, cols: int):
+    """diffusers.utils.make_image_grid on a [rows*cols, 3, H, W] tensor in [0, 1] -> one PIL image (train_textboost.py:1224-1228)."""
+    from PIL import Image
+    n, c, H, W = images.shape
+    assert n == rows * cols and c == 3
+    arr = (images.clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+    grid = Image.new("RGB", (cols * W, rows * H))
+    for i in range(n):
+        grid.paste(Image.fromarray(arr[i]), box=((i % cols) * W, (i // cols) * H))
+    return grid

@@ -159,8 +159,8 @@ class HipVAEEncoder:
         ops.groupnorm_fwd(x, y, self.P[name + ".g"], self.P[name + ".b"], st, self.gn_ws, self.B, HW, C, self.geo.norm_num_groups,
                           self.geo.norm_eps, silu)
 
-    def _conv(self, x, name, out, Hin, Win, Hout, Wout, stride=1, shift=0, **epi):
-        geo = dict(B=self.B, Hin=Hin, Win=Win, Cin=x.shape[1], Hout=Hout, Wout=Wout, stride=stride, sign=1, upsample=0, transposed=0,
+    def _conv(self, x, name, out, Hin, Win, Hout, Wout, stride=1, shift=0, upsample=0, **epi):
+        geo = dict(B=self.B, Hin=Hin, Win=Win, Cin=x.shape[1], Hout=Hout, Wout=Wout, stride=stride, sign=1, upsample=upsample, transposed=0,
                    shift=shift)
         return ops.gemm(x, self.P[name + ".w"], out, conv=geo, bias=self.P[name + ".b"], **epi)
 
@@ -184,10 +184,9 @@ class HipVAEEncoder:
         self._conv(a2, p + ".conv2", out, H, W, H, W, R=res)
         return out
 
-    def _attention(self, x, H, W):
+    def _attention(self, x, H, W, a="encoder.mid_block.attentions.0"):
         B, HW = self.B, H * W
         M, C = x.shape
-        a = "encoder.mid_block.attentions.0"
         P = self.P
         hn = self.buf(f"a.{M}x{C}", M, C)
         self._gn(x, a + ".group_norm", hn, HW, False)
@@ -244,3 +243,137 @@ class HipVAEEncoder:
         lat = self.buf("latents", self.B * geo.latent_channels, h * w, torch.float32)
         ops.vae_sample(mom, noise.contiguous(), lat, self.B, h * w, geo.latent_channels, geo.scaling_factor)
         return lat.view(self.B, geo.latent_channels, h, w)
+
+
+class HipVAEDecoder(HipVAEEncoder):
+    """`decode(latents[B,4,h,w] fp32) -> image[B,3,8h,8w] fp32 in [0,1]`: the tail of StableDiffusionPipeline.__call__ used by the reference's
+    validation (`log_validation`, train_textboost.py:453-531) and inference.py -- `vae.decode(latents / scaling_factor).sample`, then
+    `(image / 2 + 0.5).clamp(0, 1)`.  diffusers keys `post_quant_conv.*`, `decoder.*`.  Same kernels and precision policy as the
+    encoder; Upsample2D (nearest x2 + 3x3 conv) is the conv gather with `upsample = 1` (no upsampled tensor is materialised)."""
+
+    def __init__(self, geo: VAEGeometry, state_dict: Dict[str, torch.Tensor], batch: int, latent_h: int, latent_w: int, device="cuda"):
+        assert all(c % 64 == 0 for c in geo.block_out_channels)
+        self.geo, self.B, self.h, self.w, self.dev = geo, batch, latent_h, latent_w, device
+        self.H, self.W = latent_h << (len(geo.block_out_channels) - 1), latent_w << (len(geo.block_out_channels) - 1)
+        self.dtype = torch.float32
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self._pack_decoder(state_dict)
+        self.gn_ws = torch.empty((2048 + 2 * batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
+
+    def _pack_decoder(self, sd):
+        dev, geo = self.dev, self.geo
+        P: Dict[str, torch.Tensor] = {}
+        self.P = P
+
+        def conv(name):
+            P[name + ".w"], _ = pack_conv3x3(sd[name + ".weight"], dev)
+            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+
+        def lin(name):
+            P[name + ".w"], _ = pack_linear(sd[name + ".weight"], dev)
+            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+
+        def norm(name):
+            P[name + ".g"] = _f32_via_f16(sd[name + ".weight"], dev)
+            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+
+        def resnet(p, cin, cout):
+            norm(p + ".norm1"); conv(p + ".conv1"); norm(p + ".norm2"); conv(p + ".conv2")
+            if cin != cout:
+                lin(p + ".conv_shortcut")
+
+        L4 = geo.latent_channels
+        ch = list(reversed(geo.block_out_channels))
+        P["pq.w"] = sd["post_quant_conv.weight"].detach().float().reshape(L4, L4).to(dev).contiguous()
+        P["pq.b"] = sd["post_quant_conv.bias"].detach().float().to(dev).contiguous()
+        w = _f32_via_f16(sd["decoder.conv_in.weight"], dev)  # [C0, 4, 3, 3] -> [(tap*4 + ci), C0]
+        P["conv_in.wp"] = w.permute(2, 3, 1, 0).reshape(9 * L4, ch[0]).contiguous()
+        P["conv_in.b"] = _f32_via_f16(sd["decoder.conv_in.bias"], dev)
+        resnet("decoder.mid_block.resnets.0", ch[0], ch[0])
+        a = "decoder.mid_block.attentions.0"
+        norm(a + ".group_norm")
+        P[a + ".qk.w"], _ = pack_linear(torch.cat([sd[a + ".to_q.weight"], sd[a + ".to_k.weight"]], dim=0), dev)
+        P[a + ".qk.b"] = _f32_via_f16(torch.cat([sd[a + ".to_q.bias"], sd[a + ".to_k.bias"]]), dev)
+        P[a + ".v.w"], _ = pack_linear(sd[a + ".to_v.weight"], dev)
+        P[a + ".v.b"] = _f32_via_f16(sd[a + ".to_v.bias"], dev)
+        lin(a + ".to_out.0")
+        resnet("decoder.mid_block.resnets.1", ch[0], ch[0])
+        prev = ch[0]
+        for i, c in enumerate(ch):
+            for j in range(geo.layers_per_block + 1):
+                resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+            if i < len(ch) - 1:
+                conv(f"decoder.up_blocks.{i}.upsamplers.0.conv")
+            prev = c
+        norm("decoder.conv_norm_out")
+        conv("decoder.conv_out")
+
+    def decode(self, latents):
+        geo, B, H, W = self.geo, self.B, self.h, self.w
+        L4 = geo.latent_channels
+        ch = list(reversed(geo.block_out_channels))
+        assert latents.shape == (B, L4, H, W) and latents.dtype == torch.float32
+        z = self.buf("z", B * L4, H * W, torch.float32)
+        ops.chan_mix(latents.contiguous(), self.P["pq.w"], self.P["pq.b"], z, B, L4, H * W, scale=1.0 / geo.scaling_factor)
+        x = self.buf(f"oX.{B * H * W}x{ch[0]}", B * H * W, ch[0])
+        ops.convin_to_nhwc(z, L4, self.P["conv_in.wp"], self.P["conv_in.b"], x, B, H, W, ch[0])
+        x = self._resnet("decoder.mid_block.resnets.0", x, H, W, "C")
+        x = self._attention(x, H, W, a="decoder.mid_block.attentions.0")
+        x = self._resnet("decoder.mid_block.resnets.1", x, H, W, "C")
+        tag = 0
+        for i, c in enumerate(ch):
+            for j in range(geo.layers_per_block + 1):
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, H, W, "AB"[tag & 1])
+                tag += 1
+            if i < len(ch) - 1:
+                Ho, Wo = 2 * H, 2 * W
+                y = self.buf(f"oU.{B * Ho * Wo}x{c}", B * Ho * Wo, c)
+                self._conv(x, f"decoder.up_blocks.{i}.upsamplers.0.conv", y, H, W, Ho, Wo, upsample=1)
+                x, H, W = y, Ho, Wo
+        a = self.buf(f"a.{x.shape[0]}x{x.shape[1]}", x.shape[0], x.shape[1])
+        self._gn(x, "decoder.conv_norm_out", a, H * W, True)
+        rgb = self.buf("rgb", B * H * W, 4, torch.float32)
+        self._conv(a, "decoder.conv_out", rgb[:, :geo.in_channels], H, W, H, W)
+        img = self.buf("image", B * geo.in_channels, H * W, torch.float32)
+        ops.vae_image(rgb, img, B, H * W, geo.in_channels)
+        return img.view(B, geo.in_channels, H, W)
+
+
+def vae_decoder_shapes(geo: VAEGeometry) -> Dict[str, Tuple[int, ...]]:
+    """diffusers AutoencoderKL state-dict keys of the decoder half (+ post_quant_conv) -> shapes."""
+    S: Dict[str, Tuple[int, ...]] = {}
+
+    def wb(name, *shape):
+        S[name + ".weight"] = tuple(shape)
+        S[name + ".bias"] = (shape[0],)
+
+    def norm(name, c):
+        S[name + ".weight"] = (c,)
+        S[name + ".bias"] = (c,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin); wb(p + ".conv1", cout, cin, 3, 3)
+        norm(p + ".norm2", cout); wb(p + ".conv2", cout, cout, 3, 3)
+        if cin != cout:
+            wb(p + ".conv_shortcut", cout, cin, 1, 1)
+
+    L4 = geo.latent_channels
+    ch = list(reversed(geo.block_out_channels))
+    wb("post_quant_conv", L4, L4, 1, 1)
+    wb("decoder.conv_in", ch[0], L4, 3, 3)
+    resnet("decoder.mid_block.resnets.0", ch[0], ch[0])
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", ch[0])
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        wb(f"{a}.{n}", ch[0], ch[0])
+    resnet("decoder.mid_block.resnets.1", ch[0], ch[0])
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(geo.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+        if i < len(ch) - 1:
+            wb(f"decoder.up_blocks.{i}.upsamplers.0.conv", c, c, 3, 3)
+        prev = c
+    norm("decoder.conv_norm_out", ch[-1])
+    wb("decoder.conv_out", geo.in_channels, ch[-1], 3, 3)
+    return S

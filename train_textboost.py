@@ -6,7 +6,8 @@
 
 What runs here is the reference's hot path (train_textboost.py:1024-1150) on the HIP kernels of libtextboost_hip.so, behind
 the reference's flags (:49-450) and output layout (:1157-1209, :1236-1266).  Out of scope in this round:
-the PIL/augmentation data pipeline and validation sampling.  The trainer therefore consumes preprocessed tensors:
+the PIL/augmentation data pipeline and the tokenizer.  The trainer therefore consumes preprocessed tensors (and, for
+`--validation_prompts`, `<instance_data_dir>/validation_input_ids.pt` [P,77] -- the prompts tokenised by the reference's tokenizer):
 
   * `<instance_data_dir>/pixel_values.pt` -- a [N,3,R,R] fp32 tensor in [-1,1] (what `TextBoostDataset` yields, dataset.py:420-457):
     the SD VAE encoder then runs on the device at the top of every step, exactly where the reference calls it (:1036-1037;
@@ -105,6 +106,23 @@ def main(args):
     if latents is not None:
         latent = latents.shape[-1]
     unet = HipUNet(unet_geo, usd, B, latent, latent, text_len=clip_geo.max_pos, device=dev)
+    # ---- validation sampling (:453-531, :1212-1228): prompts must arrive tokenised (no tokenizer offline)
+    val_ids_path = os.path.join(args.instance_data_dir or "", "validation_input_ids.pt")
+    val_ids = torch.load(val_ids_path) if args.validation_prompts and os.path.exists(val_ids_path) else None
+    sampler = None
+    if args.validation_prompts and val_ids is None:
+        logger.warning("--validation_prompts given but %s is missing (prompts cannot be tokenised offline): validation is skipped", val_ids_path)
+    if val_ids is not None and is_main:
+        from textboost_amd.sampler import HipSampler
+        from textboost_amd.vae import HipVAEDecoder, VAEGeometry, vae_decoder_shapes
+        nv = val_ids.shape[0] * args.num_validation_images
+        dsd = load_local_state_dict(os.path.join(mdir, "vae", "diffusion_pytorch_model.safetensors")) if os.path.isdir(mdir) else None
+        if dsd is None:
+            logger.warning("no local VAE weights under %s: seeded random-init SD VAE decoder shapes are used for validation images", mdir)
+            dsd = models.random_state_dict(vae_decoder_shapes(VAEGeometry()), 1237, device=dev)
+        sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),
+                             HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5)
+        del dsd
     del usd
     teacher = HipTextEncoder(clip_geo, csd, B, mode="half", device=dev) if args.kpl_weight > 0 else None
     frozen = HipTextEncoder(clip_geo, csd, 1, mode="autocast", device=dev)
@@ -189,6 +207,24 @@ def main(args):
                     list(aug_token_dict), world, B)
         print("Mean norm:", step.mean_norm)
 
+    def run_validation(done):
+        """log_validation (:453-531): 25 DPM-Solver++ steps, guidance 7.5, num_validation_images per prompt -> validation_{step}.jpg"""
+        import copy
+        from textboost_amd.sampler import make_image_grid
+        te_val = copy.copy(te)       # same parameters (incl. the LoRA operands packed by the last step), private activation buffers
+        te_val._bufs = {}
+        ids = val_ids.to(dev).repeat_interleave(args.num_validation_images, dim=0)
+        empty = torch.full_like(ids, EOS)
+        empty[:, 0] = BOS
+        cond = te_val.forward(ids).clone()
+        uncond = te_val.forward(empty).clone()
+        if args.seed is not None:
+            sampler.generator = torch.Generator(device=dev).manual_seed(args.seed)
+        images = sampler.sample(cond, uncond)
+        grid = make_image_grid(images, val_ids.shape[0], args.num_validation_images)
+        grid.save(os.path.join(args.output_dir, f"validation_{done}.jpg"))
+        logger.info("Running validation... wrote validation_%d.jpg (%d images)", done, images.shape[0])
+
     next_batch(0)
     step.capture(warmup=0)
     t0 = time.perf_counter()
@@ -201,6 +237,8 @@ def main(args):
             logger.info("step %d loss %.6f mse %.6f kpl %.6f scale %.0f grad_norm %.4f", done, sc["loss"], sc["loss_mse"],
                         sc["loss_kpl"], sc["loss_scale"], sc["grad_norm"])
             print(f"step {done}: loss {sc['loss']:.5f} lr {args.learning_rate}", flush=True)
+        if sampler is not None and done % args.validation_steps == 0:  # :1212-1228
+            run_validation(done)
         if is_main and done % args.checkpointing_steps == 0:  # :1157-1209
             ckpt.rotate_checkpoints(args.output_dir, args.checkpoints_total_limit)
             cdir = os.path.join(args.output_dir, f"checkpoint-{done}")
