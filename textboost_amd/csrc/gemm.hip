@@ -489,6 +489,28 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
     w_ptr[i] = (const f16*)p.W + nn * p.ldw + sw;
     w2_ptr[i] = p.W2 ? (const f16*)p.W2 + nn * p.ldw2 + sw : nullptr;
   }
+#ifndef TB_GEMM_OLD_ADDR
+  // Fast addressing (operands below 4 GiB, checked by the host): every lane keeps a 32-bit byte offset from the operand base and the
+  // k advance lives in the uniform base, so a k-tile's loads cost no vector ALU work at all (plain VALU does not overlap the MFMAs of
+  // the co-resident waves).  Rows past M / N are clamped to the last row instead of the zero line: they only
+  // feed output rows / columns that are never stored.  (Conv A operands keep per-tap pointers: their padding taps must read zeros.)
+  uint32_t a_off[AI], a2_off[AI], w_off[BI], w2_off[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = wave * (BM / 4) + i * RPI + rl;
+    const int64_t mm = min((int64_t)(m0 + row), p.M - 1);
+    a_off[i] = (uint32_t)((mm * p.lda + a_sw[i]) * 2);
+    a2_off[i] = (uint32_t)((mm * p.lda2 + a_sw[i]) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = wave * (BN / 4) + i * RPI + rl;
+    const int64_t nn = min((int64_t)(n0 + row), p.N - 1);
+    const int sw = (cp ^ SWZ(row)) * 8;
+    w_off[i] = (uint32_t)((nn * p.ldw + sw) * 2);
+    w2_off[i] = (uint32_t)((nn * p.ldw2 + sw) * 2);
+  }
+#endif
 
   const int nk_all = (int)(p.K / BK);
   const int nk1 = (int)(p.K1 / BK);
@@ -502,13 +524,25 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
     f16* As = smem + buf * STAGE + (wave * (BM / 4)) * BK;
     f16* Bs = smem + buf * STAGE + A_TILE + (wave * (BN / 4)) * BK;
     if (MODE == TB_A_LINEAR) {
-      const bool second = kt >= nk1;
+      const bool second = kt >= nk1;  // wave-uniform: which K-source this k-tile comes from
       const int koff = (second ? kt - nk1 : kt) * BK;
+#ifdef TB_GEMM_OLD_ADDR
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const f16* src = a_ok[i] ? (second ? a2_ptr[i] : a_ptr[i]) + koff : zero;
         glds16(src, As + i * RPI * BK);
       }
+#else
+      if (second) {
+        const char* base = (const char*)p.A2 + (int64_t)koff * 2;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) glds16((const f16*)(base + a2_off[i]), As + i * RPI * BK);
+      } else {
+        const char* base = (const char*)p.A + (int64_t)koff * 2;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) glds16((const f16*)(base + a_off[i]), As + i * RPI * BK);
+      }
+#endif
     } else {
       const int tap = kt / kpt;
       const int cc = kt - tap * kpt;
@@ -546,11 +580,23 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
     {
       const bool second = kt >= nk1;
       const int koff = (second ? kt - nk1 : kt) * BK;
+#ifdef TB_GEMM_OLD_ADDR
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         const f16* src = w_ok[i] ? (second ? w2_ptr[i] : w_ptr[i]) + koff : zero;
         glds16(src, Bs + i * RPI * BK);
       }
+#else
+      if (second) {
+        const char* base = (const char*)p.W2 + (int64_t)koff * 2;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) glds16((const f16*)(base + w2_off[i]), Bs + i * RPI * BK);
+      } else {
+        const char* base = (const char*)p.W + (int64_t)koff * 2;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) glds16((const f16*)(base + w_off[i]), Bs + i * RPI * BK);
+      }
+#endif
     }
   };
 
@@ -567,6 +613,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
   auto compute = [&](int buf) {
     const f16* Ab = smem + buf * STAGE + (wm * WTM) * BK;
     const f16* Bb = smem + buf * STAGE + A_TILE + (wn * WTN) * BK;
+#ifdef TB_GEMM_OLD_ADDR
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       f16x8 af[TM], bf[TN];
@@ -589,6 +636,33 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+#else
+    // all fragment reads of the k-tile are issued before its first MFMA (one exposed LDS latency per k-tile instead of one per 16-wide
+    // k-step; s_setprio inside the loop had been a scheduling barrier that kept the compiler from doing this itself)
+    constexpr int NKK = BK / 16;
+    f16x8 af[NKK][TM], bf[NKK][TN];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int ch = kk * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = i * 32 + l31;
+        af[kk][i] = *(const f16x8*)(Ab + row * BK + ((ch ^ SWZ(row)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = j * 32 + l31;
+        bf[kk][j] = *(const f16x8*)(Bb + row * BK + ((ch ^ SWZ(row)) << 3));
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)  // transposed accumulator: rows = n (from W), cols = m (from A)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+#endif
   };
   if constexpr (NST == 2) {
     stage(0, 0);
@@ -962,6 +1036,14 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if ((d.A2 == nullptr) != (d.W2 == nullptr)) return TB_EINVAL;
   if (d.lda % 8 || d.ldw % 8 || (d.A2 && (d.lda2 % 8 || d.ldw2 % 8))) return TB_EINVAL;  // 16-byte vector loads
   if (((uintptr_t)d.A) % 16 || ((uintptr_t)d.W) % 16 || ((uintptr_t)d.A2) % 16 || ((uintptr_t)d.W2) % 16) return TB_EINVAL;
+  {  // 32-bit per-lane byte offsets inside the kernels: every operand row range must lie below 4 GiB from its base
+    const int64_t lim = (int64_t)1 << 32;
+    const int64_t a_rows = d.a_mode == TB_A_LINEAR ? d.M : 0;
+    if (a_rows && ((a_rows - 1) * d.lda + d.K1) * 2 >= lim) return TB_EINVAL;
+    if (d.A2 && ((d.M - 1) * d.lda2 + (d.K - d.K1)) * 2 >= lim) return TB_EINVAL;
+    if (((d.N - 1) * d.ldw + d.K1) * 2 >= lim) return TB_EINVAL;
+    if (d.W2 && ((d.N - 1) * d.ldw2 + (d.K - d.K1)) * 2 >= lim) return TB_EINVAL;
+  }
   if (d.rowbias && d.rows_per_group <= 0) return TB_EINVAL;
   if (d.rowbias && d.ldrb < d.N) d.ldrb = d.N;
   if ((d.act == TB_ACT_QUICK_GELU_GRAD || d.act == TB_ACT_GELU_GRAD || d.act == TB_ACT_GEGLU_GRAD) && !d.C2) return TB_EINVAL;
