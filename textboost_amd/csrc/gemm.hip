@@ -397,7 +397,7 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
 
 // BKT: halfs per k-tile (64 -> 128-byte LDS rows, 32 -> 64-byte rows); NST: LDS stages (2, or 3 with counted vmcnt)
 template <int BM, int BN, int MODE, int BKT, int NST>
-__global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int S, float* __restrict__ ws, int64_t npad, int abl,
+__global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 2))) void gemm_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int S, float* __restrict__ ws, int64_t npad, int abl,
                                                                               int m_fastest) {
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   f16* smem = reinterpret_cast<f16*>(smem_raw);
@@ -686,7 +686,9 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : 2)) void gemm_kernel(const tb
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int ahead = min(nk - kt - 1, NST - 2);  // tiles issued after kt that may still be in flight
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+      if (NST >= 6 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
+      else if (NST >= 5 && ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+      else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -906,6 +908,8 @@ int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
     case 2: return launch_v<BM, BN, MODE, 32, 2>(d, s, S);
     case 3: return launch_v<BM, BN, MODE, 32, 4>(d, s, S);
     case 4: return launch_v<BM, BN, MODE, 64, 3>(d, s, S);
+    case 5: return launch_v<BM, BN, MODE, 64, 4>(d, s, S);
+    case 6: return BN == 64 ? launch_v<BM, BN, MODE, 64, 6>(d, s, S) : launch_v<BM, BN, MODE, 64, 4>(d, s, S);  // one block per CU, deep ring
     default: return launch_v<BM, BN, MODE, 64, 2>(d, s, S);
   }
 }
