@@ -150,39 +150,54 @@ __global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restri
     dts[i][j] = 0.f;  // columns >= R stay zero for (c)'s 4-row units
   }
   __syncthreads();
-  // ---- (a): wave per row, the row of dY is read once (16-byte loads) against all r columns of B
-  for (int i = wave; i < LORA_RS; i += 4) {
-    for (int p = 0; p < P; ++p) {
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (i < rows)
-        for (int n = lane * 8; n < D; n += 512) {
+  // ---- (a): each wave owns LORA_RS / 4 rows; a chunk of B (8 columns x r) is loaded once into registers and used for all of them
+  constexpr int RPW = LORA_RS / 4;
+  for (int p = 0; p < P; ++p) {
+    float acc[RPW][8];
+#pragma unroll
+    for (int ii = 0; ii < RPW; ++ii)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[ii][j] = 0.f;
+    for (int n = lane * 8; n < D; n += 512) {
+      const float* bp = Bcat + ((int64_t)p * D + n) * r;
+      float bw[8][8];  // [e][j], fp16-rounded as the forward used them
+      if (RR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int q = 0; q < RR / 4; ++q) {
+            const f32x4 b = *(const f32x4*)(bp + RR * e + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[e][4 * q + j] = (float)(f16)b[j];
+          }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bw[e][j] = j < r ? (float)(f16)bp[e * r + j] : 0.f;
+      }
+#pragma unroll
+      for (int ii = 0; ii < RPW; ++ii) {
+        const int i = wave + 4 * ii;
+        if (i < rows) {
           const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + (int64_t)p * D + n);
-          const float* bp = Bcat + ((int64_t)p * D + n) * r;
-          if (RR) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float d = (float)dy[e];
+          for (int e = 0; e < 8; ++e) {
+            const float d = (float)dy[e];
 #pragma unroll
-              for (int q = 0; q < RR / 4; ++q) {
-                const f32x4 b = *(const f32x4*)(bp + RR * e + 4 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[4 * q + j] += d * (float)(f16)b[j];
-              }
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float d = (float)dy[e];
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (j < r) acc[j] += d * (float)(f16)bp[e * r + j];
-            }
+            for (int j = 0; j < 8; ++j)
+              if (j < (RR ? RR : 8)) acc[ii][j] += d * bw[e][j];
           }
         }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < RPW; ++ii) {
+      const int i = wave + 4 * ii;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (j < r) {
-          const float v = wave_sum(acc[j]) * scaling;
+          const float v = wave_sum(acc[ii][j]) * scaling;
           if (lane == 0) {
             const f16 h = (f16)v;
             dts[i][p * r + j] = (float)h;  // (c) consumes the fp16 value the dgrad GEMM sees
