@@ -59,31 +59,35 @@ struct TileRegs {
 typedef const __attribute__((address_space(1))) f16x8* gvec8_t;  // explicit global address space: a select against the zero line must
                                                                   // not degrade the loads to flat_load (which also ticks lgkmcnt and
                                                                   // would make every LDS wait drain the prefetch)
-// FAST adds a test-free path for tiles whose 64 rows all exist (costs registers for the second code path: enabled where measured
-// faster -- the narrow-head backward kernels, L0 self-attention backward 1184 -> 1104 us; off for the forward (spills at 3 waves/SIMD)
-// and for the AGPR-bound wide heads)
-template <int WD, bool FAST = false>
+// FAST (narrow heads, DT <= 2): rows past the end of the matrix are CLAMPED to its last row and chunks in the head-dim padding
+// (ch*8 >= hd) read the row's first chunk; nothing is zero-filled.  Safe because every consumer neutralises them -- scores of keys >= Skv /
+// queries >= Sq are masked to p = 0 (p * V_clamped = 0 with finite V), and padding columns only meet zero-filled fragments of the
+// lane-owned operand (S, dP) or land in output rows >= hd that are never stored.  It buys: no per-row tests, no select, one address form
+// (loop-invariant per-lane offset + wave-uniform row term).  The wide-head instantiations (AGPR-bound, one wave per SIMD) measured
+// 5-7 % slower with it and keep the zero-line select (L1 self-attention backward 165 vs 177 us).
+template <int WD, bool FAST>
 __device__ __forceinline__ void tile_load(TileRegs<WD>& t, const f16* g, int64_t ld, int row0, int nrows, int hd) {
   constexpr int CPR = TileRegs<WD>::CPR;
-  const bool full = FAST && row0 + KVT <= nrows;  // wave-uniform: every row of the tile exists
+  const bool full = row0 + KVT <= nrows;  // wave-uniform: every row of the tile exists
+  const int rmax = nrows - 1 - row0;      // last existing row, tile-local (>= 0: callers never start a tile past the end)
 #pragma unroll
   for (int it = 0; it < TileRegs<WD>::NI; ++it) {
     const int idx = threadIdx.x + it * 256;
     const int kg = idx / CPR, ch = idx - kg * CPR;
-    const bool item = idx < TileRegs<WD>::ITEMS, colok = ch * 8 < hd;
-    if (full) {
-      // common path: no per-row tests.  Chunks in the head-dim padding (ch*8 >= hd) read the row's first chunk instead of zeros: they
-      // only ever meet zero-filled fragments of the lane-owned operand (S, dP) or land in output rows >= hd that are never stored
-      if (item) {
-        const f16* base = g + (int64_t)(row0 + kg * 4) * ld + (colok ? ch * 8 : 0);
+    if (FAST) {
+      if (idx < TileRegs<WD>::ITEMS) {
+        const f16* base = g + (int64_t)row0 * ld + (ch * 8 < hd ? ch * 8 : 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t.v[it][k] = *(gvec8_t)(base + (int64_t)k * ld);
+        for (int k = 0; k < 4; ++k) {
+          const int lr = kg * 4 + k;
+          t.v[it][k] = *(gvec8_t)(base + (int64_t)(full ? lr : min(lr, rmax)) * ld);
+        }
       }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = row0 + kg * 4 + k;
-        const bool ok = item && row < nrows && colok;
+        const bool ok = idx < TileRegs<WD>::ITEMS && row < nrows && ch * 8 < hd;
         t.v[it][k] = *(ok ? (gvec8_t)(g + (int64_t)row * ld + ch * 8) : (gvec8_t)g_zero8);
       }
     }
@@ -205,13 +209,13 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
   constexpr int TILE = RM<WD>::SIZE + TR<WD>::SIZE;
   TileRegs<WD> kreg, vreg;
   if (PF) {
-    tile_load<WD>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
-    tile_load<WD>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+    tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
     tile_store<WD, true, false>(kreg, Ks, nullptr);
     tile_store<WD, false, true, ONES>(vreg, nullptr, Vt, p.hd);
     if (KVT < kv_end) {
-      tile_load<WD>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
-      tile_load<WD>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
     }
     __syncthreads();
   }
@@ -225,14 +229,14 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
         tile_store<WD, true, false>(kreg, Kn, nullptr);
         tile_store<WD, false, true, ONES>(vreg, nullptr, Kn + RM<WD>::SIZE, p.hd);
         if (kv0 + 2 * KVT < kv_end) {
-          tile_load<WD>(kreg, Kg, p.ldk, kv0 + 2 * KVT, p.Skv, p.hd);
-          tile_load<WD>(vreg, Vg, p.ldv, kv0 + 2 * KVT, p.Skv, p.hd);
+          tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, kv0 + 2 * KVT, p.Skv, p.hd);
+          tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, kv0 + 2 * KVT, p.Skv, p.hd);
         }
       }
     } else {
       __syncthreads();
-      tile_load<WD>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
-      tile_load<WD>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
       tile_store<WD, true, false>(kreg, Ks, nullptr);
       tile_store<WD, false, true, ONES>(vreg, nullptr, Vt, p.hd);
       __syncthreads();
