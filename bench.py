@@ -54,10 +54,29 @@ def roofline_leg(step):
                  "gbps": round(v[3] / v[1] / 1e9, 1) if v[3] else None} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     achieved = fl / t / 1e12
     total_flop = sum(v[2] for v in agg.values())
+    by = agg[name][3]  # algorithmic bytes of the same launches (operands read once, output written once)
+    HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+    hbm_bound = by > 0 and (by / (HBM_PEAK_GBS * 1e9)) > (fl / (MFMA_PEAK_TFLOPS * 1e12))  # which roof takes longer for this work
     roof = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2),
             "alg_flop_per_launch": fl / n, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "recorded_matmul_tflop_per_step": round(total_flop / 1e12, 3)}  # sum of 2MNK / attention FLOP over the step's launches
+    if by > 0:
+        roof["alg_bytes_per_launch"] = round(by / n)
+        roof["mfma_frac"] = roof["frac"]
+        roof["hbm_frac"] = round(by / t / 1e9 / HBM_PEAK_GBS, 4)
+    if hbm_bound:  # the launches' arithmetic intensity is below the machine balance (312 FLOP/B): quote the memory roof
+        roof.update({"bound": "hbm", "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["hbm_frac"]})
+    # HBM traffic per launch of that kernel: PMC passes cannot run inside this process (separate rocprofv3 --pmc runs, FETCH_SIZE and
+    # WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md); the committed summary of those passes (scratch/pmc_bench.sh ->
+    # scratch/pmc_traffic.py) is quoted when it has the same kernel symbol
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if name in pmc:
+            roof["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
+    except (OSError, ValueError, KeyError):
+        pass
     return roof, table
 
 
