@@ -131,13 +131,14 @@ def test_text_encoder_forward_backward_match_oracle():
     assert rel_err(t_out.view(B, 77, D), t_ref) < 1e-2
 
 
-def build_step(B=2, hw=16, D=64, use_scaler=True, sd2=False, kpl_type="cos", mixing=None):
+def build_step(B=2, hw=16, D=64, use_scaler=True, sd2=False, kpl_type="cos", mixing=None, prediction_type="epsilon"):
     from oracle import train_step as ts
     from textboost_amd.trainer import StepHyper, TextBoostStep
     ref_unet, hip_unet, _ = make_unet(B, hw, D, seed=3, sd2=sd2)
     student, teacher, hip_te, hip_teacher, added, null = make_encoders(B, D, seed=4, act="gelu" if sd2 else "quick_gelu")
-    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig(kpl_type=kpl_type, mixing=mixing))
-    hp = StepHyper(use_grad_scaler=use_scaler, init_scale=65536.0 if use_scaler else 1.0, kpl_type=kpl_type, mixing=mixing)
+    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig(kpl_type=kpl_type, mixing=mixing, prediction_type=prediction_type))
+    hp = StepHyper(use_grad_scaler=use_scaler, init_scale=65536.0 if use_scaler else 1.0, kpl_type=kpl_type, mixing=mixing,
+                   prediction_type=prediction_type)
     step = TextBoostStep(hip_unet, hip_te, hip_teacher, hp, (B, 4, hw, hw), device=dev)
     step.external_noise = True
     return st_ref, step, added
@@ -301,3 +302,21 @@ def test_sd2_style_models_kpl_mse_and_mixing_match_oracle():
     gBv = step.te.grad_B.view(len(te_ref.layers), 3, D, 4)
     assert gBv[:, :, 1::2].abs().max().item() == 0.0 and gBv[:, :, 0::2].abs().max().item() > 0.0   # :1119-1126, object
     assert rel_err(step.te.grad_added * inv, out["g_emb_added"]) < 5e-2
+
+
+def test_v_prediction_target_matches_oracle():
+    """SD2.1-768 style `prediction_type="v_prediction"` (:1070-1075): target = noise_scheduler.get_velocity(x0, noise, t)."""
+    from oracle import train_step as ts
+    B, hw, D = 2, 16, 64
+    st_ref, step, added = build_step(B, hw, D, sd2=True, prediction_type="v_prediction")
+    g = torch.Generator().manual_seed(10)
+    ids = ts.synthetic_ids(B, added, g); pids = ts.synthetic_ids(B, added, g, prior=True)
+    x0 = torch.randn(B, 4, hw, hw, generator=g); noise = torch.randn(B, 4, hw, hw, generator=g)
+    t = torch.tensor([37, 911])
+    out = st_ref.step(x0, noise, t, ids, pids)
+    step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t); step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+    step.step_eager()
+    sc = step.scalars()
+    torch.testing.assert_close(step.velocity.cpu(), ts.get_velocity(x0, noise, t, st_ref.acp), rtol=1e-5, atol=1e-6)
+    assert sc["found_inf"] == 0.0 and abs(sc["loss_mse"] - out["mse"]) < 2e-2 * abs(out["mse"]) + 1e-4, (sc, out["mse"])
+    assert rel_err(step.te.grad_added / 65536.0, out["g_emb_added"]) < 5e-2
