@@ -148,7 +148,15 @@ def main(args):
                 aug_token_dict[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
     added_ids = list(added_tokens.values()) + list(aug_token_dict.values())
 
-    hp = StepHyper(lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
+    # noise_scheduler = DDPMScheduler.from_pretrained(..., subfolder="scheduler") (:644): prediction type from its config (SD2.1-768: v)
+    pred_type = "epsilon"
+    sched_cfg = os.path.join(mdir, "scheduler", "scheduler_config.json")
+    if os.path.exists(sched_cfg):
+        pred_type = json.load(open(sched_cfg)).get("prediction_type", "epsilon")
+        if pred_type not in ("epsilon", "v_prediction"):
+            raise ValueError(f"Unknown prediction type {pred_type}")  # :1075
+    hp = StepHyper(prediction_type=pred_type,
+                   lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
                    beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
                    max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight, kpl_type="cos" if args.kpl_type == "cos" else "mse",
                    mixing=(args.augment_ops if args.augment_ops == "object" else "style") if args.mixing else None)
