@@ -202,7 +202,10 @@ int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const 
 /* ---- optimizer tail: all scalars stay on the device in `state` (fp32[TB_ST_COUNT]) ------------------- */
 enum { TB_ST_LOSS_SCALE = 0, TB_ST_GROWTH_TRACKER = 1, TB_ST_STEP = 2, TB_ST_FOUND_INF = 3, TB_ST_COEF_LORA = 4,
        TB_ST_COEF_EMB = 5, TB_ST_BC1 = 6, TB_ST_BC2 = 7, TB_ST_GRAD_NORM = 8, TB_ST_SUMSQ_LORA = 9, TB_ST_SUMSQ_EMB = 10,
-       TB_ST_LOSS_MSE = 11, TB_ST_LOSS_KPL = 12, TB_ST_COUNT = 16 };
+       TB_ST_LOSS_MSE = 11, TB_ST_LOSS_KPL = 12,
+       TB_ST_LR_MULT = 13, /* lr_scheduler (diffusers get_scheduler, :911-916): holds lambda(step) - 1, written by the host, so a zeroed
+                              state means the constant schedule; every group's lr = base lr * (1 + state[13]) */
+       TB_ST_COUNT = 16 };
 int tb_sumsq(const float* x, int64_t n, float* out, float* ws64 /* 64 floats scratch */, tb_stream_t stream);
 /* GradScaler unscale/inf-check/update + clip_grad_norm_ coefficient + Adam bias corrections (:1108, :1128-1134) */
 int tb_scaler_update(float* state, float max_norm, float beta1, float beta2, float growth_factor, float backoff_factor,

@@ -319,3 +319,25 @@ def test_lora_backward_ranks(r):
     assert rel_err(dA, Ar.grad) < 5e-3 and rel_err(dB, Br.grad) < 5e-3
     ref_dt = 0.5 * torch.cat([dY.float()[:, p_ * Dm:(p_ + 1) * Dm] @ Bc[p_ * Dm:(p_ + 1) * Dm].half().float() for p_ in range(P)], dim=1)
     assert rel_err(dt[:, :P * r], ref_dt) < 3e-3 and dt[:, P * r:].abs().max() == 0
+
+
+def test_lr_multiplier_slot_scales_every_group():
+    """state[TB_ST_LR_MULT] = lambda - 1 (lr_scheduler, :911-916/:1135): AdamW and the decay-only rows see lr * lambda."""
+    from textboost_amd import _lib as L, ops
+    torch.manual_seed(0)
+    n = 4096
+    p0 = torch.randn(n, device=dev); g = torch.randn(n, device=dev)
+    outs = []
+    for lr, lam in ((1e-3, 0.25), (0.25e-3, 1.0)):
+        p = p0.clone(); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+        st = torch.zeros(L.ST_COUNT, device=dev); st[L.ST_LOSS_SCALE] = 1.0
+        ops.sumsq(g, st[L.ST_SUMSQ_LORA:L.ST_SUMSQ_LORA + 1])
+        ops.scaler_update(st, max_norm=1e9, growth_interval=2000)
+        st[L.ST_LR_MULT] = lam - 1.0
+        ops.adamw(p, g, m, v, lr, st, L.ST_COEF_LORA)
+        w = p0.clone().view(4, -1).contiguous()
+        ops.weight_decay(w.view(-1), 1 - lr * 1e-2, st)
+        outs.append((p, w))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-8)
+    assert not torch.equal(outs[0][0], p0)

@@ -58,3 +58,20 @@ def test_product_code_never_imports_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert "oracle" not in src.replace("ORACLE", ""), f
+
+
+def test_lr_lambda_matches_transformers_schedules():
+    """diffusers.optimization.get_scheduler (train_textboost.py:911-916) is the schedule family of transformers.optimization: pin the
+    host-side multipliers against the installed transformers implementation for every name the reference's --lr_scheduler accepts."""
+    import torch
+    from transformers.optimization import get_scheduler
+    from textboost_amd.trainer import lr_lambda
+    W, T, lr0 = 7, 40, 5e-5
+    for name in ["constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial"]:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=lr0)
+        sch = get_scheduler(name, optimizer=opt, num_warmup_steps=W, num_training_steps=T)
+        lam = lr_lambda(name, W, T, lr_init=lr0)
+        for step in range(T + 3):
+            assert abs(sch.get_last_lr()[0] - lr0 * lam(step)) <= 1e-12 + 1e-9 * lr0, (name, step, sch.get_last_lr()[0], lr0 * lam(step))
+            opt.step(); sch.step()

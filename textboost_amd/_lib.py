@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libtextboost_hip" + os.environ.get("TB_LIB_SUFFIX
 TB_F16, TB_F32 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD, ACT_GELU, ACT_GELU_GRAD, ACT_GEGLU_GRAD = 0, 1, 2, 3, 4, 5, 6, 7
 (ST_LOSS_SCALE, ST_GROWTH_TRACKER, ST_STEP, ST_FOUND_INF, ST_COEF_LORA, ST_COEF_EMB, ST_BC1, ST_BC2, ST_GRAD_NORM,
- ST_SUMSQ_LORA, ST_SUMSQ_EMB, ST_LOSS_MSE, ST_LOSS_KPL) = range(13)
+ ST_SUMSQ_LORA, ST_SUMSQ_EMB, ST_LOSS_MSE, ST_LOSS_KPL, ST_LR_MULT) = range(14)
 ST_COUNT = 16
 A_LINEAR, A_CONV3X3 = 0, 1
 

@@ -86,7 +86,8 @@ def save_trainer_state(step_obj, ckpt_dir: str):
     torch.save({"m_lora": step_obj.m_lora.cpu(), "v_lora": step_obj.v_lora.cpu(), "m_emb": step_obj.m_emb.cpu(),
                 "v_emb": step_obj.v_emb.cpu(), "state": step_obj.state.cpu(),
                 "orig_rows_decay_steps": float(step_obj.state[2].item())}, os.path.join(ckpt_dir, "optimizer.bin"))
-    torch.save({"last_epoch": float(step_obj.state[2].item()), "type": "constant"}, os.path.join(ckpt_dir, "scheduler.bin"))
+    torch.save({"last_epoch": float(step_obj.state[2].item()), "lr_multiplier": 1.0 + float(step_obj.state[13].item())},
+               os.path.join(ckpt_dir, "scheduler.bin"))  # lambda(step) of --lr_scheduler is recomputed from the step index on resume
     torch.save({"scale": float(step_obj.state[0].item()), "growth_tracker": float(step_obj.state[1].item()), "growth_factor": 2.0,
                 "backoff_factor": 0.5, "growth_interval": step_obj.hp.growth_interval}, os.path.join(ckpt_dir, "scaler.pt"))
     with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "wb") as f:

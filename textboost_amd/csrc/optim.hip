@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   if (st[TB_ST_FOUND_INF] != 0.f) return;
   const float gi = g[i] * st[coef_slot];
   const float bc1 = st[TB_ST_BC1], bc2 = st[TB_ST_BC2];
+  lr *= 1.f + st[TB_ST_LR_MULT];  // LambdaLR: every group's lr is its base lr times lambda(step) (slot holds lambda - 1)
   float pi = p[i] * (1.f - lr * wd);
   const float mi = beta1 * m[i] + (1.f - beta1) * gi;
   const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void decay_kernel(float* __restrict__ p, int64
   if (i >= n4) return;
   if (st[TB_ST_FOUND_INF] != 0.f) return;
   f32x4 x = ((f32x4*)p)[i];
-  x *= factor;
+  x *= 1.f - (1.f - factor) * (1.f + st[TB_ST_LR_MULT]);  // factor = 1 - lr * wd at the base lr
   ((f32x4*)p)[i] = x;
 }
 

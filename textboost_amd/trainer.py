@@ -58,6 +58,54 @@ def average_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = Fa
     return flat_grad
 
 
+def lr_lambda(name: str, num_warmup_steps: int, num_training_steps: int, lr_init: float = 1.0, num_cycles=None, power: float = 1.0,
+              lr_end: float = 1e-7):
+    """The multiplier lambda(step) of diffusers.optimization.get_scheduler(name, ...) (train_textboost.py:911-916; the same schedule
+    family as transformers.optimization).  step = number of `lr_scheduler.step()` calls so far (0 for the first optimizer step)."""
+    import math
+    W, T = num_warmup_steps, num_training_steps
+
+    def warm(step):
+        return float(step) / float(max(1, W))
+
+    if name == "constant":
+        return lambda step: 1.0
+    if name == "constant_with_warmup":
+        return lambda step: warm(step) if step < W else 1.0
+    if name == "linear":
+        return lambda step: warm(step) if step < W else max(0.0, float(T - step) / float(max(1, T - W)))
+    if name == "cosine":
+        nc = 0.5 if num_cycles is None else num_cycles
+
+        def f(step):
+            if step < W:
+                return warm(step)
+            pr = float(step - W) / float(max(1, T - W))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(nc) * 2.0 * pr)))
+        return f
+    if name == "cosine_with_restarts":
+        nc = 1 if num_cycles is None else num_cycles
+
+        def f(step):
+            if step < W:
+                return warm(step)
+            pr = float(step - W) / float(max(1, T - W))
+            if pr >= 1.0:
+                return 0.0
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(nc) * pr) % 1.0))))
+        return f
+    if name == "polynomial":
+        def f(step):
+            if step < W:
+                return warm(step)
+            if step > T:
+                return lr_end / lr_init
+            decay = (lr_init - lr_end) * (1 - (step - W) / (T - W)) ** power + lr_end
+            return decay / lr_init
+        return f
+    raise ValueError(f"unknown lr_scheduler {name}")
+
+
 def shard_indices(n_samples: int, batch: int, it: int, rank: int, world: int):
     """data-parallel sample assignment: global sample (it*W + rank)*B + b, wrapped over the dataset, so every rank's shard is
     non-empty even with ONE training image (the reference's Wrapper hangs for rank >= 1 there)."""
@@ -181,6 +229,11 @@ class TextBoostStep:
         if hp.mixing is not None:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
             gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
             gB[:, :, (1 if hp.mixing == "object" else 0)::2, :].zero_()
+
+    def set_lr_multiplier(self, mult: float):
+        """LambdaLR semantics of diffusers `get_scheduler` (:911-916, `lr_scheduler.step()` :1135): every param group's lr of the NEXT
+        optimizer step is its base lr times `mult`.  A one-element device write outside the captured graph (no sync)."""
+        self.state[L.ST_LR_MULT:L.ST_LR_MULT + 1].fill_(float(mult) - 1.0)  # the slot holds lambda - 1 (zeroed state = constant)
 
     def all_reduce(self):
         """DDP gradient averaging (:919-926): ONE RCCL all-reduce of the flat trainable-gradient buffer

@@ -233,11 +233,15 @@ def main(args):
         grid.save(os.path.join(args.output_dir, f"validation_{done}.jpg"))
         logger.info("Running validation... wrote validation_%d.jpg (%d images)", done, images.shape[0])
 
+    from textboost_amd.trainer import lr_lambda
+    lam = lr_lambda(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps, lr_init=hp.lr)  # :911-916
     next_batch(0)
     step.capture(warmup=0)
     t0 = time.perf_counter()
     for it in range(first_step, args.max_train_steps):
         next_batch(it)
+        if args.lr_scheduler != "constant":
+            step.set_lr_multiplier(lam(it))
         step.replay()
         done = it + 1
         if is_main and (done % 50 == 0 or done == args.max_train_steps):  # scalars are read off the hot loop
