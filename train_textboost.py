@@ -162,6 +162,18 @@ def main(args):
                    mixing=(args.augment_ops if args.augment_ops == "object" else "style") if args.mixing else None)
     if args.with_image_prior or args.unet_params_to_train != "none":
         raise NotImplementedError("--with_image_prior (broken in the reference, SURVEY 0.6) / --unet_params_to_train are outside this round's hot path")
+    # options that change the step's arithmetic and are not built fail loudly instead of silently training something else
+    if args.mixed_precision != "fp16":
+        raise NotImplementedError("only --mixed_precision fp16 is built (the reference driver's setting, run_textboost_db.py:150): fp16 UNet / "
+                                  "teacher, autocast text encoder with fp32 masters, dynamic loss scaling; got %r" % (args.mixed_precision,))
+    if args.gradient_accumulation_steps != 1:
+        raise NotImplementedError("--gradient_accumulation_steps > 1 is not built (one optimizer step per batch, as the reference's driver runs)")
+    if args.text_encoder_use_attention_mask:
+        raise NotImplementedError("--text_encoder_use_attention_mask is not built (off in the reference defaults, utils.py:14-17)")
+    if args.lora_rank <= 0:
+        raise NotImplementedError("--lora_rank 0 (embedding-only training) is not built")
+    if args.validation_prompts and args.validation_scheduler != "DPMSolverMultistepScheduler":
+        raise NotImplementedError("validation sampling implements DPMSolverMultistepScheduler only")
     step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
     if pixels is not None:  # :651-656, :938: the (frozen) VAE; the step then starts from pixel_values (:1027-1037)
         from textboost_amd.vae import HipVAEEncoder, VAEGeometry, vae_encoder_shapes
