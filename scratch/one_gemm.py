@@ -7,6 +7,11 @@ if which == "lin":
     M, N, K = 32768, 2560, 320
     A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half(); out = torch.empty(M, N, device=dev, dtype=torch.float16)
     fn = lambda: ops.gemm(A, W, out)
+elif which == "proj":  # the dominant launch class of the step: attention / feed-forward projection with residual
+    M, N, K = 8192, 640, 640
+    A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half(); out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    R = torch.randn(M, N, device=dev).half(); bias = torch.randn(N, device=dev)
+    fn = lambda: ops.gemm(A, W, out, bias=bias, R=R)
 elif which == "lin2":
     M, N, K = 8192, 5120, 640
     A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half(); out = torch.empty(M, N, device=dev, dtype=torch.float16)
