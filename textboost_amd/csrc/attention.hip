@@ -55,7 +55,21 @@ struct TileRegs {
   static constexpr int ITEMS = (KVT / 4) * CPR;       // work items per tile
   static constexpr int NI = (ITEMS + 255) / 256;      // items per thread
   f16x8 v[NI][4];
+  uint32_t off[NI];  // loop-invariant byte offset of this thread's first row / chunk from the tile's first row (tile_init)
 };
+// per-thread source offset of a tile: kg*4 * ld + chunk column, in bytes.  With it a full tile's loads are
+// `global_load_dwordx4 v, v_off, s[base]` with the tile's row term (and the k-th row of the item) in the uniform base: no vector ALU
+// work per load.
+template <int WD>
+__device__ __forceinline__ void tile_init(TileRegs<WD>& t, int64_t ld, int hd) {
+  constexpr int CPR = TileRegs<WD>::CPR;
+#pragma unroll
+  for (int it = 0; it < TileRegs<WD>::NI; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int kg = idx / CPR, ch = idx - kg * CPR;
+    t.off[it] = (uint32_t)((kg * 4 * ld + (ch * 8 < hd ? ch * 8 : 0)) * 2);
+  }
+}
 typedef const __attribute__((address_space(1))) f16x8* gvec8_t;  // explicit global address space: a select against the zero line must
                                                                   // not degrade the loads to flat_load (which also ticks lgkmcnt and
                                                                   // would make every LDS wait drain the prefetch)
@@ -76,11 +90,14 @@ __device__ __forceinline__ void tile_load(TileRegs<WD>& t, const f16* g, int64_t
     const int kg = idx / CPR, ch = idx - kg * CPR;
     if (FAST) {
       if (idx < TileRegs<WD>::ITEMS) {
-        const f16* base = g + (int64_t)row0 * ld + (ch * 8 < hd ? ch * 8 : 0);
+        if (full) {  // wave-uniform branch: uniform base + precomputed 32-bit offsets
+          const char* base = (const char*)(g + (int64_t)row0 * ld);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int lr = kg * 4 + k;
-          t.v[it][k] = *(gvec8_t)(base + (int64_t)(full ? lr : min(lr, rmax)) * ld);
+          for (int k = 0; k < 4; ++k) t.v[it][k] = *(gvec8_t)(base + (int64_t)k * ld * 2 + t.off[it]);
+        } else {     // ragged last tile: clamp the rows
+          const f16* base = g + (int64_t)row0 * ld + (ch * 8 < hd ? ch * 8 : 0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t.v[it][k] = *(gvec8_t)(base + (int64_t)min(kg * 4 + k, rmax) * ld);
         }
       }
     } else {
@@ -208,6 +225,8 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
   constexpr bool PF = DT <= 3;  // wide heads keep the single-buffered, unprefetched schedule: the registers are needed for O
   constexpr int TILE = RM<WD>::SIZE + TR<WD>::SIZE;
   TileRegs<WD> kreg, vreg;
+  tile_init<WD>(kreg, p.ldk, p.hd);
+  tile_init<WD>(vreg, p.ldv, p.hd);
   if (PF) {
     tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
     tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
@@ -424,6 +443,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
   if (p.causal) kv_end = min(p.Skv, qblk + 128);
   constexpr bool PF = DT <= 2;
   TileRegs<WD> kreg, vreg;
+  tile_init<WD>(kreg, p.ldk, p.hd);
+  tile_init<WD>(vreg, p.ldv, p.hd);
   if (PF) {
     tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
     tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
@@ -537,6 +558,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   if (p.causal) q_begin = max(q_begin, (kblk / KVT) * KVT);  // queries before the block's first key see none of its keys
   constexpr bool PF = DT <= 2;
   TileRegs<WD> qreg, doreg;
+  tile_init<WD>(qreg, p.ldq, p.hd);
+  tile_init<WD>(doreg, p.lddo, p.hd);
   if (PF && q_begin < q_end) {
     tile_load<WD, (DT <= 2)>(qreg, Qg, p.ldq, q_begin, p.Sq, p.hd);
     tile_load<WD, (DT <= 2)>(doreg, dOg, p.lddo, q_begin, p.Sq, p.hd);
