@@ -161,7 +161,7 @@ int tb_dpm_step(float* x, const void* eps2, float* m_prev, void* x2, int64_t n_p
 int tb_vae_image(const float* decoded, int64_t ld, float* image, int B, int HW, int C, tb_stream_t stream);
 /* F.mse_loss(pred.float(), target.float()).mean() (:1085-1090); dpred = loss_scale[0] * dloss/dpred (fp32) */
 int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
-                tb_stream_t stream);
+                float* ws /* >= 128 floats of scratch for the two-stage reduction, or NULL: one block */, tb_stream_t stream);
 /* knowledge-preservation loss, cos variant (:1099-1106): loss_out = mean_rows(1 - cos(h, h0));
  * dh = weight * loss_scale[0] * dloss/dh.  partial = M floats scratch. */
 int tb_kpl_cos(const float* h, int64_t ldh, const void* h0, int64_t ldh0, int h0_dtype, float* dh, int64_t lddh,

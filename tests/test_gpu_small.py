@@ -73,6 +73,14 @@ def test_mse_and_kpl_losses():
     ref = F.mse_loss(pr, target); ref.backward()
     torch.testing.assert_close(loss[0], ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(dpred, pr.grad * 1024, rtol=1e-5, atol=1e-6)
+    # the metric's size (8 x 4 x 64 x 64 = 131072 elements) takes the two-stage multi-block reduction
+    pred = torch.randn(8, 4, 64, 64, device=dev).half(); target = torch.randn(8, 4, 64, 64, device=dev)
+    dpred = torch.empty_like(target)
+    ops.mse_loss(pred, target, dpred, loss, ls)
+    pr = pred.float().requires_grad_(True)
+    ref = F.mse_loss(pr, target); ref.backward()
+    torch.testing.assert_close(loss[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dpred, pr.grad * 1024, rtol=1e-5, atol=1e-7)
     M, D = 154, 768
     h = torch.randn(M, D, device=dev); h0 = (h + 0.3 * torch.randn(M, D, device=dev)).half()
     dh = torch.empty_like(h); part = torch.empty(M, device=dev)

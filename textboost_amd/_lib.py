@@ -84,7 +84,7 @@ _SIGS = {
     "tb_dpm_step": ([_VP, _VP, _VP, _VP, _I64, _I, _F, _F, _F, _F, _F, _F, _VP], C.c_int),
     "tb_vae_image": ([_VP, _I64, _VP, _I, _I, _I, _VP], C.c_int),
     "tb_conv_to4": ([_VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _VP], C.c_int),
-    "tb_mse_loss": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP], C.c_int),
+    "tb_mse_loss": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP], C.c_int),
     "tb_kpl_cos": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),
     "tb_kpl_mse": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),
     "tb_geglu_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),

@@ -122,6 +122,23 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const f16* __restrict__ 
   }
 }
 
+// multi-block first stage of the same loss: block b writes its sum of squared differences to part[b]; tb_mse_loss then runs sum_kernel
+// (deterministic two-stage reduction; the single 1024-thread block above needs ~64 us for the metric's 131k elements, this ~8 us)
+__global__ __launch_bounds__(256) void mse_partial_kernel(const f16* __restrict__ pred, const float* __restrict__ target,
+                                                          float* __restrict__ dpred, float* __restrict__ part,
+                                                          const float* __restrict__ loss_scale, int64_t N) {
+  __shared__ float red[4];
+  const float gcoef = 2.f / (float)N * (loss_scale ? loss_scale[0] : 1.f);
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    const float d = (float)pred[i] - target[i];
+    a += d * d;
+    if (dpred) dpred[i] = gcoef * d;
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
 // ---- :1099-1106 knowledge-preservation loss, cos variant: mean_rows(1 - cos(h, h0)); grad wrt h (fp32).
 // One wave per row; partial[row] = 1 - cos;  dh = -(weight*loss_scale/M) * (h0/(|h||h0|) - cos * h/|h|^2)
 template <typename T0>
@@ -422,11 +439,18 @@ extern "C" int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, c
 }
 
 extern "C" int tb_mse_loss(const void* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
-                           tb_stream_t stream) {
+                           float* ws, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!pred || !target || !loss_out || N <= 0) return TB_EINVAL;
-  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const f16*)pred, target, dpred, loss_out,
-                     loss_scale, N);
+  hipStream_t s = (hipStream_t)stream;
+  if (ws && N >= 16384) {  // two-stage: up to 128 blocks of partial sums (ws >= 128 floats), then one block adds them in order
+    int nb = (int)((N + 1023) / 1024);
+    if (nb > 128) nb = 128;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, (const f16*)pred, target, dpred, ws, loss_scale, N);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, ws, loss_out, (int64_t)nb, 1.f / (float)N);
+  } else {
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, s, (const f16*)pred, target, dpred, loss_out, loss_scale, N);
+  }
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -250,8 +250,14 @@ def conv_to4(x, w_packed, bias, out, B, H, W, C):
     L.check(L.lib().tb_conv_to4(L.ptr(x), x.stride(0), L.ptr(w_packed), L.ptr(bias), L.ptr(out), B, H, W, C, L.stream()), "tb_conv_to4")
 
 
+_mse_ws = {}
+
+
 def mse_loss(pred, target, dpred, loss_out, loss_scale):
-    L.check(L.lib().tb_mse_loss(L.ptr(pred), L.ptr(target), L.ptr(dpred), L.ptr(loss_out), L.ptr(loss_scale), pred.numel(),
+    ws = _mse_ws.get(pred.device)
+    if ws is None:
+        ws = _mse_ws[pred.device] = torch.empty(128, device=pred.device)
+    L.check(L.lib().tb_mse_loss(L.ptr(pred), L.ptr(target), L.ptr(dpred), L.ptr(loss_out), L.ptr(loss_scale), pred.numel(), L.ptr(ws),
                                 L.stream()), "tb_mse_loss")
 
 
