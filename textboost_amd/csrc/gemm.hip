@@ -266,7 +266,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
 // needs: with 32-wide k-tiles the operand stages then bound the block's LDS and a third / fourth block fits on the CU.
 template <int BM, int BN, int TM, int TN, int PASSES>
 __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, int64_t m0, int64_t n0,
-                                              int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad) {
+                                              int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad, int mshift = 30,
+                                              int mstride = 0) {
+  // tile row r (0..BM-1) is output row  m0 + (r >> mshift) * mstride + (r & (2^mshift - 1)):  contiguous rows for the GEMMs (defaults),
+  // a 2^mshift-pixel-wide block of image rows (mstride = image width) for the LDS-halo conv
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int PR = BM / PASSES;  // rows staged per pass
   static_assert(PASSES == 1 || PASSES == 2, "one or two passes");
@@ -295,13 +298,17 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
           }
     }
     __syncthreads();
-    const int64_t mp = m0 + pass * PR;  // first global row of this pass
+    const int rp = pass * PR;  // first tile row of this pass
+    auto m_of = [&](int row) -> int64_t {
+      const int r = rp + row;
+      return m0 + (int64_t)(r >> mshift) * mstride + (r & ((1 << mshift) - 1));
+    };
     if (p.act == TB_ACT_GEGLU) {
       // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
       constexpr int UPR = BN / 16;  // units per row
       for (int u = t; u < PR * UPR; u += 256) {
         const int row = u / UPR, og = u - row * UPR;
-        const int64_t m = mp + row;
+        const int64_t m = m_of(row);
         if (m >= p.M) continue;
         const int hcol = (og >> 2) * 64 + (og & 3) * 8;  // tile-local packed column of h; g is +32
         float vh[8], vg[8];
@@ -355,7 +362,7 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
 #pragma unroll
           for (int it = 0; it < NU; ++it) {
             const int row = row0 + it * RS;
-            const int64_t m = mp + row;
+            const int64_t m = m_of(row);
             if (m >= p.M) continue;
             float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
 #pragma unroll
@@ -369,7 +376,7 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
           f16x8 aux[NU];
 #pragma unroll
           for (int it = 0; it < NU; ++it) {  // all residual / aux loads first: their (cold) latency overlaps
-            const int64_t m = mp + row0 + it * RS;
+            const int64_t m = m_of(row0 + it * RS);
             const int64_t mm = m < p.M ? m : p.M - 1;
             epi_load_r8(p, ef, mm, n, r8[it]);
             aux[it] = epi_load_aux8(p, ef, mm, n);
@@ -377,7 +384,7 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
 #pragma unroll
           for (int it = 0; it < NU; ++it) {
             const int row = row0 + it * RS;
-            const int64_t m = mp + row;
+            const int64_t m = m_of(row);
             if (m >= p.M) continue;
             float v[8];
 #pragma unroll
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
 
 // ------------------------------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input HALO tile (used when a 128-pixel output tile is a whole number of image
-// rows, W = 16 / 32 / 64, or a 128-pixel segment of one row, W % 128 == 0 -- the VAE encoder's 128..512-wide maps): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
+// rows, W = 16 / 32 / 64, or a 2 x 64 block of wider maps, W % 64 == 0 -- the VAE's 128..512-wide maps): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
 // fragments from that halo at shifted row addresses; only the weight tiles stream per tap.  Compared with gemm_kernel's
 // per-tap gather this moves 4.4x fewer activation bytes through the L2->LDS path that bounds the kernel.
 template <int BN>
@@ -719,12 +726,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   constexpr int BM = 128, BK = 64;
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
   constexpr int BI = BN / 32;  // weight-tile load instructions per wave per tap
-  constexpr int MAXHI = 13;    // halo load instructions per wave (<= ceil(49 / 4): 3 x 130 halo pixels of a 128-pixel row segment)
+  constexpr int MAXHI = 9;     // halo load instructions per wave (<= ceil(33 / 4): 4 x 66 halo pixels)
 #define SWZ(row) ((((row) >> 1) & 7))
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // tile = R rows of TW = min(W, 128) pixels: whole image rows for W <= 64, a 128-pixel segment of one row for W = 128, 256, ...
+  // tile = R image rows x TW = min(W, 64) columns (R * TW = 128 output pixels): whole rows for W <= 64, a 2 x 64 block for wider maps
+  // (the same 4 x 66 halo and 3 blocks per CU as the 64-wide case; a 1 x 128 row segment would need 3 x 130 halo pixels and 66 KB)
   const int TW = 1 << wshift, W = p.Wout, H = p.Hout, R = BM >> wshift;
   const int HC = TW + 2, NH = (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
   f16* Hs = smem;
@@ -747,11 +755,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
     tm = first_m + in_g % gm;
     tn = in_g / gm;
   }
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t n0 = (int64_t)tn * BN;
   const int hw = H * W;
-  const int b = (int)(m0 / hw);
-  const int rem0 = (int)(m0 - (int64_t)b * hw);
-  const int y0 = rem0 / W, x0 = rem0 - y0 * W;  // first image row / column of the tile (x0 = 0 unless W > 128)
+  const int tiles_x = W >> wshift, tiles_img = (H / R) * tiles_x;  // tiles per image row-block / per image
+  const int b = tm / tiles_img;
+  const int trem = tm - b * tiles_img;
+  const int y0 = (trem / tiles_x) * R, x0 = (trem % tiles_x) << wshift;  // first image row / column of the tile
+  const int64_t m0 = (int64_t)b * hw + (int64_t)y0 * W + x0;             // output row of the tile's first pixel
 
   const int cp = lane & 7, rl = lane >> 3;
   // ---- halo sources of this lane (fixed across channel chunks, + 64 halfs per chunk)
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
     }
   }
 #undef SWZ
-  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
+  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, wshift, W);
 }
 
 
@@ -966,7 +976,8 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
 #endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
   if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && !d.shift && d.Hin == d.Hout && d.Win == d.Wout &&
-      (d.Wout == 16 || d.Wout == 32 || d.Wout == 64 || d.Wout % 128 == 0) && ((int64_t)d.Hout * d.Wout) % 128 == 0) {
+      (d.Wout == 16 || d.Wout == 32 || (d.Wout % 64 == 0 && d.Hout % 2 == 0)) && ((int64_t)d.Hout * d.Wout) % 128 == 0 &&
+      d.Hout % (128 / (d.Wout < 64 ? d.Wout : 64)) == 0) {
     // too few tiles for 256 CUs: split the 64-channel chunks over S blocks per tile (fp32 partials + the split-K reducer)
     int Sh = 1;
     const int kpt = d.Cin / 64;
@@ -978,7 +989,7 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
       if (want > 1) Sh = (int)want;
     }
     if (blocks * Sh >= 200) {
-      const int wshift = d.Wout >= 128 ? 7 : (d.Wout == 64 ? 6 : (d.Wout == 32 ? 5 : 4));
+      const int wshift = d.Wout >= 64 ? 6 : (d.Wout == 32 ? 5 : 4);
       return (narrow || (g_conv_narrow & 1)) ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
     }
   }
