@@ -166,7 +166,8 @@ def test_gemm_rejects_bad_args():
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(8, 64, 128, 64, 64), (8, 128, 320, 64, 64), (8, 64, 640, 32, 32), (8, 64, 2048, 16, 16),
-                                            (2, 192, 1280, 64, 64), (2, 64, 128, 48, 128), (1, 128, 64, 24, 256), (1, 64, 128, 8, 512)])
+                                            (2, 192, 1280, 64, 64), (2, 64, 128, 48, 128), (1, 128, 64, 24, 256), (1, 64, 128, 8, 512), (4, 64, 128, 96, 96),
+                                            (8, 128, 64, 48, 48), (16, 64, 64, 32, 24)])
 def test_conv3x3_halo_kernel_fwd_and_dgrad(B, Cin, Cout, H, W):
     """shapes that take the LDS-halo path (whole image rows per 128-pixel tile, or 128-pixel segments of rows 128 / 256 / 512 wide
     as in the VAE encoder; >= 200 tiles), checked against F.conv2d and against the per-tap gather kernel (halo path switched off)."""

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
 
 // ------------------------------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input HALO tile (used when a 128-pixel output tile is a whole number of image
-// rows, W = 16 / 32 / 64, or a 2 x 64 block of wider maps, W % 64 == 0 -- the VAE's 128..512-wide maps): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
+// rows or, for wider / non-power-of-two maps, a (128/TW) x TW block with TW the largest power of two <= 64 dividing W): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
 // fragments from that halo at shifted row addresses; only the weight tiles stream per tap.  Compared with gemm_kernel's
 // per-tap gather this moves 4.4x fewer activation bytes through the L2->LDS path that bounds the kernel.
 template <int BN>
@@ -955,6 +955,17 @@ int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
   return TB_OK;
 }
 
+// log2 of the halo kernel's tile width for a W x H map, or 0 when it does not apply: the tile is (128 / TW) rows x TW columns with TW the
+// largest power of two (8..64) dividing W, and tiles must not straddle images (64 -> 2 x 64, 96 -> 4 x 32, 48 -> 8 x 16, 16 -> 8 x 16)
+inline int halo_wshift(int W, int H) {
+  int sh = 0;
+  while (sh < 6 && !(W & (1 << sh))) ++sh;
+  if (W & ((1 << sh) - 1)) return 0;
+  if (sh < 3) return 0;
+  const int R = 128 >> sh;
+  return (H % R == 0) ? sh : 0;
+}
+
 template <int MODE>
 int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
   // BN = 64 tiles N that is an odd multiple of 64 (320, 960, ...) exactly.  It is also the faster tile whenever the 128x128 grid
@@ -976,8 +987,7 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
 #endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
   if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && !d.shift && d.Hin == d.Hout && d.Win == d.Wout &&
-      (d.Wout == 16 || d.Wout == 32 || (d.Wout % 64 == 0 && d.Hout % 2 == 0)) && ((int64_t)d.Hout * d.Wout) % 128 == 0 &&
-      d.Hout % (128 / (d.Wout < 64 ? d.Wout : 64)) == 0) {
+      halo_wshift(d.Wout, d.Hout) > 0) {
     // too few tiles for 256 CUs: split the 64-channel chunks over S blocks per tile (fp32 partials + the split-K reducer)
     int Sh = 1;
     const int kpt = d.Cin / 64;
@@ -989,7 +999,7 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
       if (want > 1) Sh = (int)want;
     }
     if (blocks * Sh >= 200) {
-      const int wshift = d.Wout >= 64 ? 6 : (d.Wout == 32 ? 5 : 4);
+      const int wshift = halo_wshift(d.Wout, d.Hout);
       return (narrow || (g_conv_narrow & 1)) ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
     }
   }
