@@ -218,6 +218,35 @@ int tb_weight_decay(float* p, int64_t n, float factor, const float* state, tb_st
 int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, float* norms, tb_stream_t stream);
 int tb_row_norms(const float* w, int64_t rows, int D, float* norms, tb_stream_t stream);
 
+/* ---- image augmentation + feeder --------------------------------------------------------------------------------
+ * Replaces the Pillow / torchvision calls of textboost/augment/paired_augmentation.py:20-277 and textboost/dataset.py:324-381 (Resize(LANCZOS),
+ * crop, ToImage / ToDtype / Normalize).  Device images are RGBX u8, one uint32 per pixel, [H][stride] pixels.  Bit-exact with Pillow.
+ * The three table builders run on the HOST (plain host pointers, O(W + H) work); everything else takes device pointers + a stream. */
+#define TB_IMG_LANCZOS 1 /* PIL.Image.Resampling ids */
+#define TB_IMG_BICUBIC 3
+/* Resample.c precompute_coeffs + normalize_coeffs_8bpc for a full-width box: returns ksize (odd), or a negative error */
+int tb_resample_ksize(int in_size, int out_size, int filter);
+int tb_resample_coeffs(int in_size, int out_size, int filter, int32_t* bounds /* host [out_size * 2]: (first, count) */,
+                       int32_t* kk /* host [out_size * ksize], 22-bit fixed point */);
+/* Geometry.c ImagingScaleAffine column / row tables for an axis-aligned inverse matrix a[6] (a[1] == a[3] == 0); -1 = zero fill */
+int tb_affine_nearest_tables(const double* a, int in_w, int in_h, int out_w, int out_h, int32_t* xt /* host [out_w] */,
+                             int32_t* yt /* host [out_h] */);
+/* one pass of Image.resize: vertical = 0 resamples the width sw -> out_size (dst is [sh][out_size]), 1 the height sh -> out_size */
+int tb_img_resample(const uint32_t* src, int64_t sstride, int sw, int sh, uint32_t* dst, int64_t dstride, int out_size,
+                    const int32_t* bounds /* device */, const int32_t* kk /* device */, int ksize, int vertical, tb_stream_t stream);
+/* dst[y][x] = xt[x] >= 0 && yt[y] >= 0 ? src[yt[y]][xt[x]] : 0 (crop, pad, flip, collage tiling, NEAREST affine); gray = convert("L") luma */
+int tb_img_gather(const uint32_t* src, int64_t sstride, uint32_t* dst, int64_t dstride, int dw, int dh, const int32_t* xt /* device [dw] */,
+                  const int32_t* yt /* device [dh] */, int gray, tb_stream_t stream);
+/* Image.transform(AFFINE, a, BICUBIC) of the image edge-padded by (pad_x, pad_y), window [oy, oy + dh) x [ox, ox + dw) of its output (zeros
+ * outside it): adjust_scale's pad + affine + center_crop in one launch */
+int tb_img_affine_bicubic(const uint32_t* src, int64_t sstride, int sw, int sh, int pad_x, int pad_y, uint32_t* dst, int64_t dstride, int dw,
+                          int dh, int ox, int oy, const double* a /* host [6] */, tb_stream_t stream);
+/* crop [y0, y0 + R) x [x0, x0 + R) + ToImage + ToDtype(float32, scale=True) + Normalize(0.5, 0.5) -> fp32 [3, R, R] */
+int tb_img_to_pixels(const uint32_t* src, int64_t sstride, int sw, int sh, int x0, int y0, float* dst, int R, tb_stream_t stream);
+/* RGB u8 [n][3] -> RGBX, and back ([h][w][3]) */
+int tb_img_pack_rgb(const uint8_t* rgb, uint32_t* dst, int64_t n_pixels, tb_stream_t stream);
+int tb_img_unpack_rgb(const uint32_t* src, int64_t sstride, int w, int h, uint8_t* rgb, tb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

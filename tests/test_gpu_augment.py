@@ -1,0 +1,209 @@
+"""Device-side augmentation + feeder on the GPU, through the C-ABI, BIT-EXACT against the numpy oracle, against Pillow's
+committed outputs and against the committed seeded runs of the reference's own PairedAugmentation (tests/golden/gen_augment_golden.py)."""
+import json
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rnd(seed, h, w):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def up(a):
+    from textboost_amd import augment as D
+    return D.to_device_image(a)
+
+
+def down(t):
+    from textboost_amd import augment as D
+    return D.to_host_rgb(t)
+
+
+def test_pack_unpack_roundtrip_and_strided_view():
+    a = rnd(0, 37, 53)
+    t = up(a)
+    assert t.dtype == torch.int32 and tuple(t.shape) == (37, 53)
+    assert np.array_equal(down(t), a)
+    assert np.array_equal(down(t[5:30, 7:40]), a[5:30, 7:40])
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(37, 53, 16, 16), (64, 64, 64, 32), (100, 80, 33, 47), (30, 30, 77, 91), (257, 129, 64, 64), (9, 7, 3, 2),
+                                         (5, 5, 40, 40), (1, 1, 4, 4), (200, 300, 64, 96), (70, 1000, 70, 65), (640, 3, 17, 3)])
+def test_resize_matches_oracle(h, w, oh, ow):
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    a = rnd(h * 1000 + w, h, w)
+    for fo, fd in ((A.BICUBIC, D.BICUBIC), (A.LANCZOS, D.LANCZOS)):
+        assert np.array_equal(down(D.resize(up(a), (ow, oh), fd)), A.resize(a, (ow, oh), fo)), (fo,)
+
+
+def test_resize_matches_pillow_fixture():
+    from textboost_amd import augment as D
+    prim = np.load(os.path.join(G, "augment_pil_primitives.npz"))
+    for i, (h, w, oh, ow) in enumerate(prim["resize_cases"]):
+        t = up(prim[f"resize_in_{i}"])
+        assert np.array_equal(down(D.resize(t, (int(ow), int(oh)), D.BICUBIC)), prim[f"resize_bicubic_{i}"]), i
+        assert np.array_equal(down(D.resize(t, (int(ow), int(oh)), D.LANCZOS)), prim[f"resize_lanczos_{i}"]), i
+
+
+def test_resize_of_a_strided_crop_and_same_size_copy():
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    a = rnd(3, 90, 120)
+    t = up(a)
+    got = D.resize(t[10:70, 20:100], (64, 48), D.BICUBIC)
+    assert np.array_equal(down(got), A.resize(a[10:70, 20:100], (64, 48), A.BICUBIC))
+    same = D.resize(t, (120, 90), D.LANCZOS)
+    assert same.data_ptr() != t.data_ptr() and np.array_equal(down(same), a)
+
+
+def test_full_size_lanczos_like_the_dataset():
+    """A camera-sized instance image through `v2.Resize(512, LANCZOS)` (dataset.py:324): 1536 x 2048 -> 512 x 682, both passes > 2.6x down."""
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    r = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:1536, 0:2048]
+    a = np.clip(np.stack([xx // 8, yy // 6, (xx + yy) // 14], -1) + r.integers(-30, 31, (1536, 2048, 3)), 0, 255).astype(np.uint8)
+    got = down(D.resize_short_edge(up(a), 512))
+    assert got.shape == (512, 682, 3)
+    assert np.array_equal(got, A.tv_resize_short_edge(a, 512))
+
+
+def test_affine_matches_pillow_fixture():
+    from textboost_amd import augment as D
+    from textboost_amd import ops
+    prim = np.load(os.path.join(G, "augment_pil_primitives.npz"))
+    for i, (h, w) in enumerate(prim["affine_cases"]):
+        h, w = int(h), int(w)
+        t, m = up(prim[f"affine_in_{i}"]), [float(v) for v in prim[f"affine_matrix_{i}"]]
+        got = ops.img_affine_bicubic(t, m, 0, 0, 0, 0, w, h)
+        assert np.array_equal(down(got), prim[f"affine_bicubic_{i}"]), i
+        xt, yt = ops.affine_nearest_tables(m, w, h, w, h)
+        got = ops.img_gather(t, xt.cuda(), yt.cuda())
+        assert np.array_equal(down(got), prim[f"affine_nearest_{i}"]), i
+
+
+@pytest.mark.parametrize("h,w", [(40, 40), (33, 50), (64, 48), (131, 77)])
+def test_fused_pad_affine_crop_matches_the_three_step_oracle(h, w):
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    a = rnd(h + w, h, w)
+    for seed in range(6):
+        np.random.seed(seed)
+        want, p1 = A.adjust_scale(a, "x", True)
+        np.random.seed(seed)
+        got, p2 = D.adjust_scale(up(a), "x", True)
+        assert p1 == p2 and np.array_equal(down(got), want), (h, w, seed)
+
+
+def test_gather_ops_match_oracle():
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    for (h, w) in [(40, 40), (33, 50), (64, 48)]:
+        a = rnd(7 * h + w, h, w)
+        for name in ("horizontal_flip", "horizontal_translate", "square_photo_collage", "crop"):
+            fo = A.crop_op if name == "crop" else getattr(A, name)
+            for seed in range(5):
+                np.random.seed(seed), random.seed(seed)
+                want, p1 = fo(a, "a photo", False)
+                np.random.seed(seed), random.seed(seed)
+                got, p2 = getattr(D, name)(up(a), "a photo", False)
+                assert p1 == p2, (name, seed)
+                assert np.array_equal(down(got), want), (name, h, w, seed)
+        want, _ = A.grayscale_op(a, "p")
+        got, _ = D.grayscale(up(a), "p")
+        assert np.array_equal(down(got), want)
+
+
+def test_paired_augmentation_matches_the_reference_runs():
+    """Same seeds as the recorded runs of the real paired_augmentation.py -> same prompts, same pixels, for all 40 cases."""
+    from textboost_amd import augment as D
+    meta = json.load(open(os.path.join(G, "augment_reference_calls.json")))
+    imgs = np.load(os.path.join(G, "augment_reference_images.npz"))
+    for r in meta["records"]:
+        pipe = D.PairedAugmentation(**r["config"])
+        np.random.seed(r["np_seed"])
+        random.seed(r["py_seed"])
+        out, prompt, mask = pipe(up(imgs[f"in_{r['case']}"]), meta["prompt_in"])
+        assert mask is None and prompt == r["prompt"], r["case"]
+        assert np.array_equal(down(out), imgs[f"out_{r['case']}"]), (r["case"], r["calls"])
+
+
+class FakeTokenizer:
+    """Deterministic stand-in (no tokenizer files exist offline): ids from a hash of the words, padded to 77 like CLIPTokenizer."""
+    model_max_length = 77
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, prompt, truncation=True, padding="max_length", max_length=77, return_tensors="pt"):
+        self.calls += 1
+        ids = [49406] + [sum(map(ord, w)) % 49405 for w in prompt.split()][:max_length - 2]
+        ids = ids + [49407] * (max_length - len(ids))
+        return types.SimpleNamespace(input_ids=torch.tensor([ids], dtype=torch.int64))
+
+
+def test_feeder_batch_matches_oracle_items():
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    imgs = [rnd(21, 150, 110), rnd(22, 96, 140)]
+    templates = ["a photo of {}", "a rendering of {}", "{} on a table"]
+    size = 64
+    tok = FakeTokenizer()
+    feeder = D.DeviceFeeder([(up(a), "<sks> dog") for a in imgs], tok, templates, size=size, center_crop=False,
+                            augment_pipe=D.PairedAugmentation(hflip="inversion", inversion=True, p=0.8, color_prob=0.3))
+    idx = [0, 1, 0, 1, 1, 0, 0, 1]
+    random.seed(5), np.random.seed(5), torch.manual_seed(5)
+    batch = feeder.batch(idx)
+    random.seed(5), np.random.seed(5), torch.manual_seed(5)
+    pipe = A.PairedAugmentation(hflip="inversion", inversion=True, p=0.8, color_prob=0.3)
+    want = [A.dataset_item(imgs[i % 2], "<sks> dog", templates, size, False, pipe) for i in idx]
+    assert batch["pixel_values"].shape == (8, 3, size, size) and batch["pixel_values"].dtype == torch.float32 and batch["pixel_values"].is_cuda
+    assert batch["input_ids"].shape == (8, 77) and batch["input_ids"].dtype == torch.int64
+    for b, (pv, prompt) in enumerate(want):
+        assert batch["prompts"][b] == prompt
+        assert np.array_equal(batch["pixel_values"][b].cpu().numpy(), pv), b
+        assert torch.equal(batch["input_ids"][b:b + 1], FakeTokenizer()(prompt).input_ids)
+    # the prompt cache: a second pass over the same draws never reaches the tokenizer
+    calls = tok.calls
+    random.seed(5), np.random.seed(5), torch.manual_seed(5)
+    again = feeder.batch(idx)
+    assert tok.calls == calls and feeder.tokenize.hits >= 8
+    assert torch.equal(again["pixel_values"], batch["pixel_values"]) and torch.equal(again["input_ids"], batch["input_ids"])
+
+
+def test_feeder_center_crop_and_vae_input_range():
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    a = rnd(31, 100, 260)
+    feeder = D.DeviceFeeder([(up(a), "<v>")], FakeTokenizer(), ["{}"], size=48, center_crop=True, augment_pipe=None)
+    random.seed(0)
+    b = feeder.batch([0])
+    random.seed(0)
+    pv, _ = A.dataset_item(a, "<v>", ["{}"], 48, True, None)
+    assert np.array_equal(b["pixel_values"][0].cpu().numpy(), pv)
+    assert b["pixel_values"].min() >= -1 and b["pixel_values"].max() <= 1
+
+
+def test_error_behaviour():
+    from textboost_amd import _lib as L
+    from textboost_amd import augment as D
+    from textboost_amd import ops
+    t = up(rnd(1, 16, 16))
+    with pytest.raises(TypeError):
+        D.PairedAugmentation()(np.zeros((4, 4, 3), np.uint8), "p")
+    with pytest.raises(ValueError):
+        D.to_device_image(np.zeros((4, 4), np.uint8))
+    assert L.lib().tb_resample_ksize(0, 4, D.LANCZOS) == -22 and L.lib().tb_resample_ksize(8, 4, 2) == -22
+    with pytest.raises(RuntimeError):
+        ops.img_to_pixels(t, 10, 10, torch.empty(3, 8, 8, device="cuda"))  # window leaves the image
+    with pytest.raises(RuntimeError):
+        ops.img_affine_bicubic(t, [1.0, 0.5, 0.0, 0.0, 1.0, 0.0], 0, 0, 0, 0, 16, 16)  # rotation / shear is not on this path

@@ -117,3 +117,20 @@ def test_center_crop_pads_when_smaller():
     a = np.full((10, 6, 3), 9, np.uint8)
     out = A.tv_center_crop(a, (6, 10))  # the reference's swapped (w, h) on a non-square image
     assert out.shape == (6, 10, 3) and out[:, :2].max() == 0 and out[:, 2:8].min() == 9 and out[:, 8:].max() == 0
+
+
+def test_c_abi_host_table_builders_match_oracle():
+    """tb_resample_coeffs / tb_affine_nearest_tables are HOST entry points (libm sin, sequential accumulation): checkable without a GPU."""
+    from textboost_amd import ops
+    for n, o in [(53, 16), (64, 32), (30, 91), (257, 64), (7, 2), (5, 40), (2048, 512), (1365, 512), (512, 513), (1, 4)]:
+        for f in (A.LANCZOS, A.BICUBIC):
+            ks, b, kk = ops.resample_coeffs(n, o, f)
+            ks2, b2, kk2 = A.precompute_coeffs(n, 0.0, float(n), o, f)
+            assert ks == ks2 and ks % 2 == 1 and np.array_equal(b.numpy(), b2) and np.array_equal(kk.numpy(), kk2), (n, o, f)
+    for s, t, w, h in [(0.34, 0, 40, 40), (0.77, 0, 50, 33), (1.4, 0, 48, 64), (1.0, -7, 40, 40), (1.0, 13, 50, 33), (0.9, 3.5, 64, 48)]:
+        m = A.inverse_affine_matrix([w * 0.5, h * 0.5], 0.0, [float(t), 0.0], s, [0.0, 0.0])
+        xt, yt = ops.affine_nearest_tables(m, w, h, w, h)
+        xt2, yt2 = A.scale_affine_tables(m, w, h, w, h)
+        assert np.array_equal(xt.numpy(), xt2) and np.array_equal(yt.numpy(), yt2)
+    with pytest.raises(RuntimeError):
+        ops.affine_nearest_tables([1.0, 0.1, 0.0, 0.0, 1.0, 0.0], 8, 8, 8, 8)

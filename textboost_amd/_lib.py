@@ -105,7 +105,17 @@ _SIGS = {
     "tb_weight_decay": ([_VP, _I64, _F, _VP, _VP], C.c_int),
     "tb_renorm_rows": ([_VP, _I, _I, _F, _VP, _VP], C.c_int),
     "tb_row_norms": ([_VP, _I64, _I, _VP, _VP], C.c_int),
+    "tb_resample_ksize": ([_I, _I, _I], C.c_int),
+    "tb_resample_coeffs": ([_I, _I, _I, _VP, _VP], C.c_int),
+    "tb_affine_nearest_tables": ([C.POINTER(C.c_double), _I, _I, _I, _I, _VP, _VP], C.c_int),
+    "tb_img_resample": ([_VP, _I64, _I, _I, _VP, _I64, _I, _VP, _VP, _I, _I, _VP], C.c_int),
+    "tb_img_gather": ([_VP, _I64, _VP, _I64, _I, _I, _VP, _VP, _I, _VP], C.c_int),
+    "tb_img_affine_bicubic": ([_VP, _I64, _I, _I, _I, _I, _VP, _I64, _I, _I, _I, _I, C.POINTER(C.c_double), _VP], C.c_int),
+    "tb_img_to_pixels": ([_VP, _I64, _I, _I, _I, _I, _VP, _I, _VP], C.c_int),
+    "tb_img_pack_rgb": ([_VP, _VP, _I64, _VP], C.c_int),
+    "tb_img_unpack_rgb": ([_VP, _I64, _I, _I, _VP, _VP], C.c_int),
 }
+IMG_LANCZOS, IMG_BICUBIC = 1, 3
 
 
 def lib():

@@ -370,3 +370,74 @@ def renorm_rows(rows, mean_norm, norms=None):
 
 def row_norms(w, norms):
     L.check(L.lib().tb_row_norms(L.ptr(w), w.shape[0], w.shape[1], L.ptr(norms), L.stream()), "tb_row_norms")
+
+
+# ------------------------------------------------------------------------------------------- image augmentation
+# Device images are int32 tensors [H, W] holding RGBX bytes (R in the low byte).
+def resample_coeffs(in_size, out_size, filt):
+    """Host: Pillow's coefficient table for one axis -> (ksize, bounds int32 [out, 2], kk int32 [out, ksize]) as CPU tensors."""
+    ksize = L.lib().tb_resample_ksize(in_size, out_size, filt)
+    if ksize <= 0:
+        raise RuntimeError(f"tb_resample_ksize failed with code {ksize}")
+    bounds = torch.empty(out_size, 2, dtype=torch.int32)
+    kk = torch.empty(out_size, ksize, dtype=torch.int32)
+    rc = L.lib().tb_resample_coeffs(in_size, out_size, filt, L.ptr(bounds), L.ptr(kk))
+    if rc != ksize:
+        raise RuntimeError(f"tb_resample_coeffs failed with code {rc}")
+    return ksize, bounds, kk
+
+
+def affine_nearest_tables(matrix, in_w, in_h, out_w, out_h):
+    """Host: ImagingScaleAffine's column / row source indices (-1 = fill) as CPU int32 tensors."""
+    import ctypes as C
+    a = (C.c_double * 6)(*[float(v) for v in matrix])
+    xt = torch.empty(out_w, dtype=torch.int32)
+    yt = torch.empty(out_h, dtype=torch.int32)
+    L.check(L.lib().tb_affine_nearest_tables(a, in_w, in_h, out_w, out_h, L.ptr(xt), L.ptr(yt)), "tb_affine_nearest_tables")
+    return xt, yt
+
+
+def img_resample(src, out_size, bounds, kk, vertical):
+    sh, sw = src.shape
+    out = torch.empty((out_size, sw) if vertical else (sh, out_size), dtype=torch.int32, device=src.device)
+    L.check(L.lib().tb_img_resample(L.ptr(src), src.stride(0), sw, sh, L.ptr(out), out.stride(0), out_size, L.ptr(bounds), L.ptr(kk),
+                                    kk.shape[1], int(vertical), L.stream()), "tb_img_resample")
+    return out
+
+
+def img_gather(src, xt, yt, gray=False):
+    out = torch.empty((yt.numel(), xt.numel()), dtype=torch.int32, device=src.device)
+    L.check(L.lib().tb_img_gather(L.ptr(src), src.stride(0), L.ptr(out), out.stride(0), xt.numel(), yt.numel(), L.ptr(xt), L.ptr(yt),
+                                  int(gray), L.stream()), "tb_img_gather")
+    return out
+
+
+def img_affine_bicubic(src, matrix, pad_x, pad_y, ox, oy, dw, dh):
+    import ctypes as C
+    sh, sw = src.shape
+    a = (C.c_double * 6)(*[float(v) for v in matrix])
+    out = torch.empty((dh, dw), dtype=torch.int32, device=src.device)
+    L.check(L.lib().tb_img_affine_bicubic(L.ptr(src), src.stride(0), sw, sh, pad_x, pad_y, L.ptr(out), out.stride(0), dw, dh, ox, oy, a,
+                                          L.stream()), "tb_img_affine_bicubic")
+    return out
+
+
+def img_to_pixels(src, x0, y0, dst):
+    """dst: fp32 [3, R, R] (one slot of pixel_values)."""
+    sh, sw = src.shape
+    L.check(L.lib().tb_img_to_pixels(L.ptr(src), src.stride(0), sw, sh, x0, y0, L.ptr(dst), dst.shape[-1], L.stream()), "tb_img_to_pixels")
+
+
+def img_pack_rgb(rgb):
+    """uint8 [H, W, 3] on the device -> RGBX int32 [H, W]."""
+    h, w, _ = rgb.shape
+    out = torch.empty((h, w), dtype=torch.int32, device=rgb.device)
+    L.check(L.lib().tb_img_pack_rgb(L.ptr(rgb), L.ptr(out), h * w, L.stream()), "tb_img_pack_rgb")
+    return out
+
+
+def img_unpack_rgb(img):
+    h, w = img.shape
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=img.device)
+    L.check(L.lib().tb_img_unpack_rgb(L.ptr(img), img.stride(0), w, h, L.ptr(out), L.stream()), "tb_img_unpack_rgb")
+    return out
