@@ -207,3 +207,37 @@ def test_error_behaviour():
         ops.img_to_pixels(t, 10, 10, torch.empty(3, 8, 8, device="cuda"))  # window leaves the image
     with pytest.raises(RuntimeError):
         ops.img_affine_bicubic(t, [1.0, 0.5, 0.0, 0.0, 1.0, 0.0], 0, 0, 0, 0, 16, 16)  # rotation / shear is not on this path
+
+
+def test_cli_trains_from_image_files_through_the_device_feeder(tmp_path, monkeypatch):
+    """train_textboost.py on the reference's own inputs -- image files + a tokenizer: images decoded once, the per-sample dataset work
+    (template draw, PairedAugmentation, Lanczos resize, crop, normalise, tokenise) on the device, feeding the device VAE encoder."""
+    import sys
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+    from tests.test_host_logic import _WordTokenizer
+    data = tmp_path / "dog"
+    data.mkdir()
+    r = np.random.default_rng(0)
+    for i, (h, w) in enumerate([(300, 260), (200, 340)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.clip(np.stack([xx * 255 // w, yy * 255 // h, (xx + yy) % 256], -1) + r.integers(-20, 21, (h, w, 3)), 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(str(data / f"{i:02d}.png"))
+    tok = _WordTokenizer()
+    monkeypatch.setattr(T, "load_tokenizer", lambda mdir: tok)
+    out = str(tmp_path / "run")
+    args = T.parse_args(["--pretrained_model_name_or_path", "/nonexistent/sd15", "--instance_data_dir", str(data), "--output_dir", out,
+                         "--train_batch_size", "2", "--resolution", "128", "--max_train_steps", "4", "--placeholder_token", "<dog>",
+                         "--initializer_token", "dog", "--lora_rank", "4", "--mixed_precision", "fp16", "--seed", "3", "--augment", "paug",
+                         "--augment_inversion", "--augment_p", "0.9", "--template", "textboost"])
+    T.main(args)
+    log = open(os.path.join(out, "training.log")).read()
+    assert "device feeder: 2 resident instance image(s)" in log and "VAE" in log
+    d = torch.load(os.path.join(out, "dog.bin"))
+    assert torch.isfinite(d["<dog>"]).all()
+    # the augmentation tokens were registered through the tokenizer (word-level stand-in: 11 vectors) and saved next to the placeholder
+    assert os.path.exists(os.path.join(out, "hflip.bin")) and os.path.exists(os.path.join(out, "zoom-in_0.bin"))
+    assert "<dog>" in tok.vocab and "<left>" in tok.vocab

@@ -75,3 +75,88 @@ def test_lr_lambda_matches_transformers_schedules():
         for step in range(T + 3):
             assert abs(sch.get_last_lr()[0] - lr0 * lam(step)) <= 1e-12 + 1e-9 * lr0, (name, step, sch.get_last_lr()[0], lr0 * lam(step))
             opt.step(); sch.step()
+
+
+# ------------------------------------------------------------------------------ instance-image data path host logic
+class _WordTokenizer:
+    """Duck-typed stand-in for CLIPTokenizer (no tokenizer files exist offline): one id per whitespace word, grows with add_tokens."""
+    model_max_length = 77
+
+    def __init__(self):
+        self.vocab = {}
+        self.base = 49408
+
+    def _id(self, w):
+        if w in self.vocab:
+            return self.vocab[w]
+        return sum(map(ord, w)) % 49000
+
+    def encode(self, text, add_special_tokens=False):
+        return [self._id(w) for w in text.split()]
+
+    def add_tokens(self, names):
+        n = 0
+        for t in names:
+            if t not in self.vocab:
+                self.vocab[t] = self.base + len(self.vocab)
+                n += 1
+        return n
+
+    def convert_tokens_to_ids(self, names):
+        return [self.vocab[t] for t in names]
+
+    def __call__(self, prompt, truncation=True, padding="max_length", max_length=77, return_tensors="pt"):
+        import types
+        ids = ([49406] + self.encode(prompt))[:max_length - 1]
+        ids = ids + [49407] * (max_length - len(ids))
+        return types.SimpleNamespace(input_ids=torch.tensor([ids], dtype=torch.int64))
+
+
+class _Table:
+    """the part of HipTextEncoder.add_tokens the registration uses"""
+
+    def __init__(self, V=49408):
+        self.V, self.copied = V, []
+
+    def add_tokens(self, init_ids):
+        new = list(range(self.V, self.V + len(init_ids)))
+        self.V += len(init_ids)
+        self.copied += list(init_ids)
+        return new
+
+
+def test_index_stream_is_the_reference_wrapper_order(golden_dir):
+    from textboost_amd.data import IndexStream
+    g = torch.load(os.path.join(golden_dir, "wrapper_order.pt"))
+    assert IndexStream(5, 42).take(10) == g["n5_seed42_rep2"]
+    assert IndexStream(1, 42).take(4) == g["n1_seed42_rep4"]
+    # two ranks, five samples: padded with the head of the epoch, strided; one image: every rank still gets it (drop_last=False)
+    a, b = IndexStream(5, 42, 0, 2), IndexStream(5, 42, 1, 2)
+    e0 = [4, 2, 3, 1, 0]
+    assert a.take(3) == (e0 + e0[:1])[0::2] and b.take(3) == (e0 + e0[:1])[1::2]
+    assert IndexStream(1, 0, 1, 2).take(3) == [0, 0, 0]
+
+
+def test_templates_token_registration_and_image_listing(tmp_path):
+    from textboost_amd import data as D
+    assert D.load_templates("textboost") == ["{}", "a {}", "one {}", "the {}", "photo of a {}"]
+    assert len(D.load_templates("imagenet_small")) == 27 and len(D.load_templates("imagenet_style_small")) == 19
+    assert D.load_templates("a photo of {} dog") == ["a photo of {} dog"]
+    assert D.multi_vector_names("<dog>", 1) == ["<dog>"] and D.multi_vector_names("<dog>", 3) == ["<dog_0>", "<dog_1>", "<dog_2>"]
+    assert D.multi_vector_names("sks", 2) == ["sks", "sks_1"]
+    tok, table = _WordTokenizer(), _Table()
+    names, ids = D.add_token(table, tok, "<sks>", "dog")
+    assert names == ["<sks>"] and ids == [49408] and table.copied == tok.encode("dog")
+    aug_ids, aug = D.add_augmentation_tokens(table, tok, "object")
+    assert list(aug) == ["<grayscale>", "<zoom-in_0>", "<zoom-in_1>", "<zoom-out_0>", "<zoom-out_1>", "<collage_0>", "<collage_1>", "<crop>",
+                         "<hflip>", "<left>", "<right>"]  # word-level stand-in: 2 pieces for the two-word initialisers
+    assert aug_ids == list(range(49409, 49409 + 11)) and table.V == 49408 + 12
+    with pytest.raises(ValueError):
+        D.add_token(table, tok, "<sks>", "dog")  # already registered (utils.py:145-149)
+    (tmp_path / "b.png").write_bytes(b"x")
+    (tmp_path / "a.jpg").write_bytes(b"x")
+    (tmp_path / "c.jpg").write_bytes(b"x")
+    assert [os.path.basename(p) for p in D.get_images_path(str(tmp_path), 2)] == ["a.jpg", "b.png"]
+    assert D.has_instance_images(str(tmp_path)) and not D.has_instance_images(str(tmp_path / "nope"))
+    with pytest.raises(ValueError):
+        D.get_images_path(str(tmp_path / "nope"))

@@ -37,7 +37,7 @@ def _dev_table(a: np.ndarray, device) -> torch.Tensor:
 
 def to_device_image(rgb) -> torch.Tensor:
     """uint8 [H, W, 3] (numpy / CPU or CUDA tensor; e.g. `np.asarray(PIL.Image.open(p).convert("RGB"))`) -> resident RGBX image."""
-    t = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb)
+    t = torch.from_numpy(np.array(rgb, copy=True)) if isinstance(rgb, np.ndarray) else torch.as_tensor(rgb)
     if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
         raise ValueError("expected a uint8 [H, W, 3] RGB image")
     return ops.img_pack_rgb(t.cuda().contiguous())

@@ -5,10 +5,14 @@
     python -m torch.distributed.run --nproc-per-node=N train_textboost.py ...                       (README.md:82 of the reference)
 
 What runs here is the reference's hot path (train_textboost.py:1024-1150) on the HIP kernels of libtextboost_hip.so, behind
-the reference's flags (:49-450) and output layout (:1157-1209, :1236-1266).  Out of scope in this round:
-the PIL/augmentation data pipeline and the tokenizer.  The trainer therefore consumes preprocessed tensors (and, for
-`--validation_prompts`, `<instance_data_dir>/validation_input_ids.pt` [P,77] -- the prompts tokenised by the reference's tokenizer):
+the reference's flags (:49-450) and output layout (:1157-1209, :1236-1266).  Data sources, in order of preference (for
+`--validation_prompts` without a tokenizer: `<instance_data_dir>/validation_input_ids.pt` [P,77] -- the prompts tokenised by the reference's
+tokenizer):
 
+  * image files in `<instance_data_dir>` + `<pretrained_model_name_or_path>/tokenizer/` (the reference's own inputs): every image is decoded
+    ONCE, stays resident in HBM, and `TextBoostDataset.__getitem__` (dataset.py:353-381: template draw, `--augment pda|paug`
+    PairedAugmentation, Resize(LANCZOS), crop, normalise, tokenise) runs per sample on the device (textboost_amd/augment.py), feeding the
+    device VAE encoder; or
   * `<instance_data_dir>/pixel_values.pt` -- a [N,3,R,R] fp32 tensor in [-1,1] (what `TextBoostDataset` yields, dataset.py:420-457):
     the SD VAE encoder then runs on the device at the top of every step, exactly where the reference calls it (:1036-1037;
     weights from `<pretrained_model_name_or_path>/vae/diffusion_pytorch_model.safetensors`, else seeded random init), or
@@ -49,6 +53,15 @@ def multi_vector_names(token: str, n: int):
     stem = token[:-1] if token.endswith(">") else token
     tail = ">" if token.endswith(">") else ""
     return [f"{stem}_{i}{tail}" for i in range(n)]
+
+
+def load_tokenizer(model_dir):
+    """`AutoTokenizer.from_pretrained(..., subfolder="tokenizer", use_fast=False)` (:629-641) from LOCAL files only; None when absent."""
+    tdir = os.path.join(model_dir or "", "tokenizer")
+    if not os.path.exists(os.path.join(tdir, "vocab.json")):
+        return None
+    from transformers import CLIPTokenizer
+    return CLIPTokenizer.from_pretrained(tdir, local_files_only=True)
 
 
 def load_local_state_dict(path):
@@ -101,6 +114,11 @@ def main(args):
     latents = torch.load(lat_path) if args.instance_data_dir and os.path.exists(lat_path) else None
     px_path = os.path.join(args.instance_data_dir or "", "pixel_values.pt")
     pixels = torch.load(px_path) if args.instance_data_dir and os.path.exists(px_path) else None
+    tokenizer = load_tokenizer(mdir)
+    from textboost_amd import data as tbdata
+    use_images = tokenizer is not None and tbdata.has_instance_images(args.instance_data_dir)
+    if use_images:
+        latents, pixels, latent = None, None, args.resolution // 8
     if pixels is not None:
         latents, latent = None, pixels.shape[-1] // 8
     if latents is not None:
@@ -109,9 +127,11 @@ def main(args):
     # ---- validation sampling (:453-531, :1212-1228): prompts must arrive tokenised (no tokenizer offline)
     val_ids_path = os.path.join(args.instance_data_dir or "", "validation_input_ids.pt")
     val_ids = torch.load(val_ids_path) if args.validation_prompts and os.path.exists(val_ids_path) else None
+    if args.validation_prompts and tokenizer is not None:
+        val_ids = torch.zeros(len(args.validation_prompts), clip_geo.max_pos, dtype=torch.int64)  # filled once the tokens are registered
     sampler = None
     if args.validation_prompts and val_ids is None:
-        logger.warning("--validation_prompts given but %s is missing (prompts cannot be tokenised offline): validation is skipped", val_ids_path)
+        logger.warning("--validation_prompts given but neither a tokenizer nor %s exists: validation is skipped", val_ids_path)
     if val_ids is not None and is_main:
         from textboost_amd.sampler import HipSampler
         from textboost_amd.vae import HipVAEDecoder, VAEGeometry, vae_decoder_shapes
@@ -140,13 +160,25 @@ def main(args):
     g = torch.Generator().manual_seed(args.seed or 0)
     added_tokens, aug_token_dict = {}, {}
     n_place = 1
-    for name in multi_vector_names(args.placeholder_token, n_place):
-        added_tokens[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
-    if args.augment_inversion:
-        for tok, n in (AUG_TOKENS_OBJECT if args.augment_ops == "object" else AUG_TOKENS_STYLE):
-            for name in multi_vector_names(tok, n):
-                aug_token_dict[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
+    placeholder_names = None
+    if tokenizer is not None:  # the reference's own registration: one vector per BPE piece of the initialiser, rows copied from the pieces
+        placeholder_names, ids = tbdata.add_token(te, tokenizer, args.placeholder_token, args.initializer_token)
+        added_tokens.update(zip(placeholder_names, ids))
+        if args.augment_inversion:
+            _, aug_token_dict = tbdata.add_augmentation_tokens(te, tokenizer, "style" if args.augment_ops == "style" else "object")
+    else:
+        for name in multi_vector_names(args.placeholder_token, n_place):
+            added_tokens[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
+        if args.augment_inversion:
+            for tok, n in (AUG_TOKENS_OBJECT if args.augment_ops == "object" else AUG_TOKENS_STYLE):
+                for name in multi_vector_names(tok, n):
+                    aug_token_dict[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
     added_ids = list(added_tokens.values()) + list(aug_token_dict.values())
+    if args.validation_prompts and tokenizer is not None:  # log_validation (:502-505): `<i>` -> the i-th concept's placeholder vectors
+        for j, prompt in enumerate(args.validation_prompts):
+            prompt = prompt.replace("<0>", " ".join(placeholder_names))
+            val_ids[j] = tokenizer(prompt, truncation=True, padding="max_length", max_length=tokenizer.model_max_length,
+                                   return_tensors="pt").input_ids[0]
 
     # noise_scheduler = DDPMScheduler.from_pretrained(..., subfolder="scheduler") (:644): prediction type from its config (SD2.1-768: v)
     pred_type = "epsilon"
@@ -175,7 +207,7 @@ def main(args):
     if args.validation_prompts and args.validation_scheduler != "DPMSolverMultistepScheduler":
         raise NotImplementedError("validation sampling implements DPMSolverMultistepScheduler only")
     step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
-    if pixels is not None:  # :651-656, :938: the (frozen) VAE; the step then starts from pixel_values (:1027-1037)
+    if pixels is not None or use_images:  # :651-656, :938: the (frozen) VAE; the step then starts from pixel_values (:1027-1037)
         from textboost_amd.vae import HipVAEEncoder, VAEGeometry, vae_encoder_shapes
         vsd = load_local_state_dict(os.path.join(mdir, "vae", "diffusion_pytorch_model.safetensors")) if os.path.isdir(mdir) else None
         if vsd is None:
@@ -191,8 +223,35 @@ def main(args):
     inst_ids = torch.load(ids_path) if os.path.exists(ids_path) else None
     prior_ids = torch.load(pids_path) if os.path.exists(pids_path) else None
 
+    feeder, index_stream = None, None
+    if use_images:  # :856-890: PairedAugmentation + TextBoostDataset + Wrapper(...).shuffle(seed).repeat(), on the device
+        import random as pyrandom
+
+        import numpy as np
+        from textboost_amd import augment as tbaug
+        if args.augment not in ("none", "pda", "paug"):
+            raise NotImplementedError(f"--augment {args.augment}: only PairedAugmentation ('pda' / 'paug') is built")
+        pipe = None
+        if args.augment in ("pda", "paug"):
+            pipe = tbaug.PairedAugmentation(hflip="inversion" if args.augment_inversion else "false", augment_prompt=args.augment_prompt,
+                                            inversion=args.augment_inversion, p=args.augment_p, ops=args.augment_ops)
+        # the reference formats the template with the LIST of placeholder names (`concept["instance_token"] = placeholder_tokens`, :691-692)
+        paths = [p for p in tbdata.get_images_path(args.instance_data_dir, args.num_samples) if p.lower().endswith(tbdata.IMAGE_EXTENSIONS)]
+        images = [(tbaug.to_device_image(tbdata.decode_rgb(p)), placeholder_names) for p in paths]
+        feeder = tbaug.DeviceFeeder(images, tokenizer, tbdata.load_templates(args.template), size=args.resolution,
+                                    center_crop=args.center_crop, augment_pipe=pipe)
+        index_stream = tbdata.IndexStream(len(images), args.seed or 0, rank, world)
+        if args.seed is not None:  # set_seed(args.seed) (:601) also seeds `random` and numpy, which the augmentation draws from
+            pyrandom.seed(args.seed)
+            np.random.seed(args.seed)
+        logger.info("device feeder: %d resident instance image(s), template set %r (%d prompts), augment %s", len(images), args.template,
+                    len(feeder.templates), args.augment)
+
     def next_batch(it):
-        if pixels is not None:
+        if feeder is not None:
+            b = feeder.batch(index_stream.take(B), out=step.pixel_values)
+            step.input_ids.copy_(b["input_ids"])
+        elif pixels is not None:
             idx = shard_indices(pixels.shape[0], B, it, rank, world)
             step.pixel_values.copy_(pixels[idx])
             if inst_ids is not None:
@@ -204,7 +263,7 @@ def main(args):
                 step.input_ids.copy_(inst_ids[[i % inst_ids.shape[0] for i in idx]])
         else:
             step.x0.copy_(torch.randn(B, 4, latent, latent, generator=dg))
-        if (latents is None and pixels is None) or inst_ids is None:
+        if feeder is None and ((latents is None and pixels is None) or inst_ids is None):
             step.input_ids.copy_(synthetic_ids(B, added_ids, dg))
         if prior_ids is not None:
             j = torch.randint(0, prior_ids.shape[0], (B,), generator=dg)
