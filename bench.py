@@ -141,6 +141,41 @@ def cpu_baseline_leg(max_seconds=60.0):
                       f"fp32 eager oracle; best {best:.2f} s/step scaled to B=8", "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count()}
 
 
+def make_feeder(step, args, rank):
+    """The device feeder of textboost_amd/augment.py on synthetic camera-sized images; returns a callable that fills the step's inputs."""
+    import random
+    import types
+
+    import numpy as np
+    from textboost_amd import augment as aug
+    from textboost_amd.data import IndexStream, load_templates
+
+    class WordTokenizer:  # no tokenizer files exist offline: ids from a word hash, padded to 77 like CLIPTokenizer (synthetic, as the ids are)
+        model_max_length = 77
+
+        def __call__(self, prompt, truncation=True, padding="max_length", max_length=77, return_tensors="pt"):
+            ids = ([49406] + [sum(map(ord, w)) % 49405 for w in prompt.split()])[:max_length - 1]
+            return types.SimpleNamespace(input_ids=torch.tensor([ids + [49407] * (max_length - len(ids))], dtype=torch.int64))
+
+    images = []
+    for i in range(2):
+        r = np.random.default_rng(100 + i)
+        yy, xx = np.mgrid[0:1536, 0:2048]
+        a = np.clip(np.stack([xx // 8, yy // 6, (xx + yy) // 14], -1) + r.integers(-30, 31, (1536, 2048, 3)), 0, 255).astype(np.uint8)
+        images.append((aug.to_device_image(a), ["<sks>"]))
+    feeder = aug.DeviceFeeder(images, WordTokenizer(), load_templates("textboost"), size=8 * args.latent, center_crop=False,
+                              augment_pipe=aug.PairedAugmentation(hflip="inversion", inversion=True, p=0.8))
+    stream = IndexStream(len(images), 42, rank, int(os.environ.get("WORLD_SIZE", "1")))
+    random.seed(42 + rank)
+    np.random.seed(42 + rank)
+
+    def feed():
+        b = feeder.batch(stream.take(args.batch), out=step.pixel_values)
+        step.input_ids.copy_(b["input_ids"] % 49408, non_blocking=True)
+
+    return feed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,10 +189,15 @@ def main():
     ap.add_argument("--vae", action="store_true",
                     help="secondary measurement: the step starts from 8x-larger RGB pixels and runs the SD VAE encoder first "
                          "(train_textboost.py:1036-1037; SURVEY 8(f).1) -- the BASELINE.json metric uses synthetic latents")
+    ap.add_argument("--feeder", action="store_true",
+                    help="secondary measurement (implies --vae): every step ALSO runs the reference's per-sample dataset work on the device -- "
+                         "template draw, PairedAugmentation (p=0.8, inversion), Resize(512, LANCZOS), RandomCrop, normalise, tokenise "
+                         "(textboost/dataset.py:353-381; SURVEY 8(f).3) -- from two resident synthetic 1536x2048 instance images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
+    args.vae = args.vae or args.feeder
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,13 +229,21 @@ def main():
                              device=torch.device("cuda", local), unet_geo=models.SD21_UNET if sd21 else models.SD15_UNET,
                              clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4, with_vae=args.vae)
     step.force_dist = force_dist
+    feed = None
+    if args.feeder:
+        feed = make_feeder(step, args, rank)
     if args.no_graph:
         for _ in range(2):
             step.step_eager()
     else:
         step.capture(warmup=2)
-    for _ in range(args.warmup):
+    def one_step():
+        if feed is not None:
+            feed()
         step.replay()
+
+    for _ in range(args.warmup):
+        one_step()
 
     def barrier():
         if dist is not None:
@@ -205,7 +253,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step.replay()
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -236,6 +284,10 @@ def main():
             metric = metric[:-1] + ", + VAE encoder on %d^2 pixels)" % (8 * args.latent)
             workload += "; PLUS the SD VAE encoder (34.2M, fp16 MFMA / fp32 stats) on resident [B,3,%d,%d] fp32 pixels inside the graph" % (
                 8 * args.latent, 8 * args.latent)
+        if args.feeder:
+            metric = metric[:-1] + " + device feeder)"
+            workload += ("; PLUS, every step, the dataset work of textboost/dataset.py:353-381 for the batch on the device: PairedAugmentation "
+                         "(p=0.8, inversion), Lanczos resize 1536x2048 -> 512, RandomCrop, normalise, prompt tokenisation (word-hash stand-in, cached)")
         if sd21:  # secondary measurement; algorithmic FLOP taken from the recorded launches of the eager leg
             metric = "train steps/sec (batch=%d, SD2.1 shapes, %d^2 latents, LoRA r=8)" % (args.batch, args.latent)
             workload = ("SURVEY 8(d) config 4: SD2.x UNet (865.9M, Linear proj_in/out, head dim 64) + OpenCLIP-H text encoder (23 layers, "

@@ -233,7 +233,9 @@ int tb_affine_nearest_tables(const double* a, int in_w, int in_h, int out_w, int
                              int32_t* yt /* host [out_h] */);
 /* one pass of Image.resize: vertical = 0 resamples the width sw -> out_size (dst is [sh][out_size]), 1 the height sh -> out_size */
 int tb_img_resample(const uint32_t* src, int64_t sstride, int sw, int sh, uint32_t* dst, int64_t dstride, int out_size,
-                    const int32_t* bounds /* device */, const int32_t* kk /* device */, int ksize, int vertical, tb_stream_t stream);
+                    const int32_t* bounds /* device */, const int32_t* kk /* device */, int ksize, int vertical,
+                    int coeffs_fit_24bit /* 1: every |kk| < 2^23 (checked by the caller on the host table): full-rate 24-bit multiplies */,
+                    tb_stream_t stream);
 /* dst[y][x] = xt[x] >= 0 && yt[y] >= 0 ? src[yt[y]][xt[x]] : 0 (crop, pad, flip, collage tiling, NEAREST affine); gray = convert("L") luma */
 int tb_img_gather(const uint32_t* src, int64_t sstride, uint32_t* dst, int64_t dstride, int dw, int dh, const int32_t* xt /* device [dw] */,
                   const int32_t* yt /* device [dh] */, int gray, tb_stream_t stream);

@@ -241,3 +241,24 @@ def test_cli_trains_from_image_files_through_the_device_feeder(tmp_path, monkeyp
     # the augmentation tokens were registered through the tokenizer (word-level stand-in: 11 vectors) and saved next to the placeholder
     assert os.path.exists(os.path.join(out, "hflip.bin")) and os.path.exists(os.path.join(out, "zoom-in_0.bin"))
     assert "<dog>" in tok.vocab and "<left>" in tok.vocab
+
+
+def test_resample_24bit_and_32bit_multiply_paths_agree():
+    """The full-rate 24-bit multiply path is taken only when the host table fits (it always does for real images); the 32-bit path is the
+    general one.  Both must give Pillow's bytes."""
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    from textboost_amd import ops
+    a = rnd(77, 120, 333)
+    t = up(a)
+    for filt_o, filt_d, n_out in ((A.LANCZOS, D.LANCZOS, 100), (A.BICUBIC, D.BICUBIC, 500)):
+        _, b, kk = ops.resample_coeffs(333, n_out, filt_d)
+        assert ops.resample_fit24(kk)
+        want = A._resample_axis(a, n_out, filt_o, 1)
+        for fit in (False, True):
+            assert np.array_equal(down(ops.img_resample(t, n_out, b.cuda(), kk.cuda(), 0, fit)), want)
+        _, b, kk = ops.resample_coeffs(120, n_out // 4, filt_d)
+        want = A._resample_axis(a, n_out // 4, filt_o, 0)
+        for fit in (False, True):
+            assert np.array_equal(down(ops.img_resample(t, n_out // 4, b.cuda(), kk.cuda(), 1, fit)), want)
+    assert not ops.resample_fit24(torch.tensor([[1 << 23]], dtype=torch.int32))

@@ -108,7 +108,7 @@ _SIGS = {
     "tb_resample_ksize": ([_I, _I, _I], C.c_int),
     "tb_resample_coeffs": ([_I, _I, _I, _VP, _VP], C.c_int),
     "tb_affine_nearest_tables": ([C.POINTER(C.c_double), _I, _I, _I, _I, _VP, _VP], C.c_int),
-    "tb_img_resample": ([_VP, _I64, _I, _I, _VP, _I64, _I, _VP, _VP, _I, _I, _VP], C.c_int),
+    "tb_img_resample": ([_VP, _I64, _I, _I, _VP, _I64, _I, _VP, _VP, _I, _I, _I, _VP], C.c_int),
     "tb_img_gather": ([_VP, _I64, _VP, _I64, _I, _I, _VP, _VP, _I, _VP], C.c_int),
     "tb_img_affine_bicubic": ([_VP, _I64, _I, _I, _I, _I, _VP, _I64, _I, _I, _I, _I, C.POINTER(C.c_double), _VP], C.c_int),
     "tb_img_to_pixels": ([_VP, _I64, _I, _I, _I, _I, _VP, _I, _VP], C.c_int),

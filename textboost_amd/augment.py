@@ -58,9 +58,9 @@ def resize(img: torch.Tensor, size_wh: Tuple[int, int], filt: int) -> torch.Tens
         key = (n_in, n_out, filt, img.device)
         if key not in _coeff_cache:
             _, bounds, kk = ops.resample_coeffs(n_in, n_out, filt)
-            _coeff_cache[key] = (bounds.to(img.device), kk.to(img.device))
-        bounds, kk = _coeff_cache[key]
-        out = ops.img_resample(out, n_out, bounds, kk, vertical)
+            _coeff_cache[key] = (bounds.to(img.device), kk.to(img.device), ops.resample_fit24(kk))
+        bounds, kk, fit24 = _coeff_cache[key]
+        out = ops.img_resample(out, n_out, bounds, kk, vertical, fit24)
     return out.clone() if out is img else out
 
 

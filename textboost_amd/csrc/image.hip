@@ -113,10 +113,26 @@ __device__ __forceinline__ uint32_t clip8(int v) {
   return (uint32_t)min(max(v, 0), 255);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte load
+
+// pixel (8 bit) x coefficient: M24 = the coefficient table fits signed 24 bits (the caller checked: always, unless a window's weights nearly
+// cancel), so the product is the full-rate v_mad_i32_i24 instead of the quarter-rate 32-bit v_mul_lo -- the bound of the plain loop.
+template <int M24>
+__device__ __forceinline__ int tap(int acc, uint32_t px, int c) {
+  return M24 ? acc + __mul24((int)px, c) : acc + (int)px * c;
+}
+#define TAP(v, c)                             \
+  {                                           \
+    s0 = tap<M24>(s0, (v) & 255, (c));        \
+    s1 = tap<M24>(s1, ((v) >> 8) & 255, (c)); \
+    s2 = tap<M24>(s2, ((v) >> 16) & 255, (c)); \
+  }
+
 // One pass of Image.resize.  VERT = 0: out[y][xx] over src[y][xmin .. xmin+cnt); VERT = 1: out[yy][x] over src[ymin .. ymin+cnt)[x].
 // Horizontal blocks stage their 64 outputs' coefficient rows in LDS (each lane walks its own row: bank = (lane * ksize + k) % 32 --
-// conflict-free when ksize is odd, and Resample.c's ksize = 2 ceil(support) + 1 always is).
-template <int VERT>
+// conflict-free because Resample.c's ksize = 2 ceil(support) + 1 is odd); the vertical pass keeps four row loads in flight.
+template <int VERT, int M24>
 __global__ __launch_bounds__(256) void resample_kernel(const uint32_t* __restrict__ src, int64_t sstride, uint32_t* __restrict__ dst,
                                                        int64_t dstride, int out_w, int out_h, const int32_t* __restrict__ bounds,
                                                        const int32_t* __restrict__ kk, int ksize) {
@@ -129,12 +145,15 @@ __global__ __launch_bounds__(256) void resample_kernel(const uint32_t* __restric
     const int32_t* k = kk + (int64_t)y * ksize;  // wave-uniform: scalar loads
     int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
     const uint32_t* p = src + (int64_t)ymin * sstride + x;
-    for (int i = 0; i < cnt; i++) {
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+      uint32_t v0 = p[(int64_t)i * sstride], v1 = p[(int64_t)(i + 1) * sstride], v2 = p[(int64_t)(i + 2) * sstride],
+               v3 = p[(int64_t)(i + 3) * sstride];
+      TAP(v0, k[i]) TAP(v1, k[i + 1]) TAP(v2, k[i + 2]) TAP(v3, k[i + 3])
+    }
+    for (; i < cnt; i++) {
       uint32_t v = p[(int64_t)i * sstride];
-      int c = k[i];
-      s0 += (int)(v & 255) * c;
-      s1 += (int)((v >> 8) & 255) * c;
-      s2 += (int)((v >> 16) & 255) * c;
+      TAP(v, k[i])
     }
     dst[(int64_t)y * dstride + x] = clip8(s0) | (clip8(s1) << 8) | (clip8(s2) << 16);
   } else {
@@ -142,40 +161,48 @@ __global__ __launch_bounds__(256) void resample_kernel(const uint32_t* __restric
     const int nx = min(64, out_w - x0);
     for (int i = threadIdx.y * 64 + threadIdx.x; i < nx * ksize; i += 256) kk_s[i] = kk[(int64_t)x0 * ksize + i];
     __syncthreads();
-    if (x >= out_w) return;
-    const int xmin = bounds[2 * x], cnt = bounds[2 * x + 1];
-    const int32_t* k = kk_s + threadIdx.x * ksize;
+    const int xc = min(x, out_w - 1);
+    const int xmin = bounds[2 * xc], cnt = bounds[2 * xc + 1];
+    const int32_t* k = kk_s + (xc - x0) * ksize;
     for (int y = blockIdx.y * 4 + threadIdx.y; y < out_h; y += gridDim.y * 4) {
-      const uint32_t* p = src + (int64_t)y * sstride + xmin;
+      const uint32_t* p = src + (int64_t)y * sstride;
       int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+      // plain loop (the compiler unrolls it x4 around one 16-byte load, ~9 VALU ops per tap): hand-batching 8 loads per lane (+30 %),
+      // staging the row span through LDS (+10 %) and fewer, longer-running blocks (+20 %) all measured SLOWER under rocprofv3
       for (int i = 0; i < cnt; i++) {
-        uint32_t v = p[i];
-        int c = k[i];
-        s0 += (int)(v & 255) * c;
-        s1 += (int)((v >> 8) & 255) * c;
-        s2 += (int)((v >> 16) & 255) * c;
+        uint32_t v = p[xmin + i];
+        TAP(v, k[i])
       }
-      dst[(int64_t)y * dstride + x] = clip8(s0) | (clip8(s1) << 8) | (clip8(s2) << 16);
+      if (x < out_w) dst[(int64_t)y * dstride + x] = clip8(s0) | (clip8(s1) << 8) | (clip8(s2) << 16);
     }
   }
 }
 
 extern "C" int tb_img_resample(const uint32_t* src, int64_t sstride, int sw, int sh, uint32_t* dst, int64_t dstride, int out_size,
-                               const int32_t* bounds, const int32_t* kk, int ksize, int vertical, tb_stream_t stream) {
+                               const int32_t* bounds, const int32_t* kk, int ksize, int vertical, int coeffs_fit_24bit, tb_stream_t stream) {
   if (!src || !dst || !bounds || !kk || sw <= 0 || sh <= 0 || out_size <= 0 || ksize <= 0 || !(ksize & 1)) return TB_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (vertical) {
     if (dstride < sw || sstride < sw) return TB_EINVAL;
     dim3 grid((sw + 63) / 64, (out_size + 3) / 4);
-    hipLaunchKernelGGL(resample_kernel<1>, grid, dim3(64, 4), 0, st, src, sstride, dst, dstride, sw, out_size, bounds, kk, ksize);
+    if (coeffs_fit_24bit)
+      hipLaunchKernelGGL((resample_kernel<1, 1>), grid, dim3(64, 4), 0, st, src, sstride, dst, dstride, sw, out_size, bounds, kk, ksize);
+    else
+      hipLaunchKernelGGL((resample_kernel<1, 0>), grid, dim3(64, 4), 0, st, src, sstride, dst, dstride, sw, out_size, bounds, kk, ksize);
   } else {
     if (dstride < out_size || sstride < sw) return TB_EINVAL;
     size_t lds = (size_t)64 * ksize * sizeof(int32_t);
     if (lds > 64 * 1024) return TB_EINVAL;  // ksize <= 255: down-scaling by up to ~42x with Lanczos
+    // rows are strided over beyond 256 row groups (the coefficient tile is staged once per block); 128 / 256 / 384 groups for 1536 rows
+    // measured 16.0 / 13.1 / 14.5 us
+    const int gx = (out_size + 63) / 64;
     int gy = (sh + 3) / 4;
-    if (gy > 256) gy = 256;  // rows are strided over: the coefficient tile is staged once per block
-    dim3 grid((out_size + 63) / 64, gy);
-    hipLaunchKernelGGL(resample_kernel<0>, grid, dim3(64, 4), lds, st, src, sstride, dst, dstride, out_size, sh, bounds, kk, ksize);
+    if (gy > 256) gy = 256;
+    dim3 grid(gx, gy);
+    if (coeffs_fit_24bit)
+      hipLaunchKernelGGL((resample_kernel<0, 1>), grid, dim3(64, 4), lds, st, src, sstride, dst, dstride, out_size, sh, bounds, kk, ksize);
+    else
+      hipLaunchKernelGGL((resample_kernel<0, 0>), grid, dim3(64, 4), lds, st, src, sstride, dst, dstride, out_size, sh, bounds, kk, ksize);
   }
   TB_CHECK_LAUNCH();
   return TB_OK;
@@ -248,10 +275,17 @@ __global__ __launch_bounds__(256) void affine_bicubic_kernel(const uint32_t* __r
         cy[i] = min(max(min(max(by + i, 0), ph - 1) - pad_y, 0), sh - 1);
       }
       double r[4][3];
+      const bool interior = cx[3] - cx[0] == 3;  // no clamping in x: the four taps are one 16-byte load
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t* row = src + (int64_t)cy[j] * sstride;
-        uint32_t p0 = row[cx[0]], p1 = row[cx[1]], p2 = row[cx[2]], p3 = row[cx[3]];
+        uint32_t p0, p1, p2, p3;
+        if (interior) {
+          u32x4 v = *(const u32x4_u*)(row + cx[0]);
+          p0 = v.x, p1 = v.y, p2 = v.z, p3 = v.w;
+        } else {
+          p0 = row[cx[0]], p1 = row[cx[1]], p2 = row[cx[2]], p3 = row[cx[3]];
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++)
           r[j][c] = bicubic_poly((double)((p0 >> (8 * c)) & 255), (double)((p1 >> (8 * c)) & 255), (double)((p2 >> (8 * c)) & 255),

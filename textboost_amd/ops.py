@@ -397,12 +397,17 @@ def affine_nearest_tables(matrix, in_w, in_h, out_w, out_h):
     return xt, yt
 
 
-def img_resample(src, out_size, bounds, kk, vertical):
+def img_resample(src, out_size, bounds, kk, vertical, fit24=False):
+    """fit24: every |kk| < 2**23 -- a property of the HOST table, computed once by the caller (`resample_fit24`)."""
     sh, sw = src.shape
     out = torch.empty((out_size, sw) if vertical else (sh, out_size), dtype=torch.int32, device=src.device)
     L.check(L.lib().tb_img_resample(L.ptr(src), src.stride(0), sw, sh, L.ptr(out), out.stride(0), out_size, L.ptr(bounds), L.ptr(kk),
-                                    kk.shape[1], int(vertical), L.stream()), "tb_img_resample")
+                                    kk.shape[1], int(vertical), int(fit24), L.stream()), "tb_img_resample")
     return out
+
+
+def resample_fit24(kk_host) -> bool:
+    return bool(kk_host.abs().max().item() < (1 << 23))
 
 
 def img_gather(src, xt, yt, gray=False):
