@@ -228,6 +228,11 @@ def test_cli_trains_from_image_files_through_the_device_feeder(tmp_path, monkeyp
         Image.fromarray(a).save(str(data / f"{i:02d}.png"))
     tok = _WordTokenizer()
     monkeypatch.setattr(T, "load_tokenizer", lambda mdir: tok)
+    # the knowledge-preservation prompts come from the reference's hard-coded relative path (train_textboost.py:892)
+    (tmp_path / "data").mkdir()
+    (tmp_path / "data" / "human-written-prompts.jsonl").write_text(
+        "\n".join(json.dumps({"input": f"make the {w} blue", "output": f"a blue {w}"}) for w in ("car", "house", "sky", "boat")) + "\n")
+    monkeypatch.chdir(tmp_path)
     out = str(tmp_path / "run")
     args = T.parse_args(["--pretrained_model_name_or_path", "/nonexistent/sd15", "--instance_data_dir", str(data), "--output_dir", out,
                          "--train_batch_size", "2", "--resolution", "128", "--max_train_steps", "4", "--placeholder_token", "<dog>",
@@ -236,6 +241,7 @@ def test_cli_trains_from_image_files_through_the_device_feeder(tmp_path, monkeyp
     T.main(args)
     log = open(os.path.join(out, "training.log")).read()
     assert "device feeder: 2 resident instance image(s)" in log and "VAE" in log
+    assert "prior prompts: 8 edit prompts + 5 template prompts" in log
     d = torch.load(os.path.join(out, "dog.bin"))
     assert torch.isfinite(d["<dog>"]).all()
     # the augmentation tokens were registered through the tokenizer (word-level stand-in: 11 vectors) and saved next to the placeholder

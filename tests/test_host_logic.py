@@ -160,3 +160,39 @@ def test_templates_token_registration_and_image_listing(tmp_path):
     assert D.has_instance_images(str(tmp_path)) and not D.has_instance_images(str(tmp_path / "nope"))
     with pytest.raises(ValueError):
         D.get_images_path(str(tmp_path / "nope"))
+
+
+def test_prior_prompt_feeder_follows_prior_dataset(tmp_path):
+    """PriorDataset.__getitem__ / collate_fn (dataset.py:196-269) and InstructPix2PixDataset's file format (:162-175)."""
+    import json as js
+    import random
+    from textboost_amd import data as D
+    from textboost_amd.augment import PromptFeeder
+    f = tmp_path / "p.jsonl"
+    f.write_text("\n".join(js.dumps(r) for r in [{"input": "a cat", "output": "a dog"}, {"input": "make it red", "output": "NONE"},
+                                                   {"input": "add snow", "output": None}, {"input": "x y", "output": "z"}]) + "\n")
+    prompts = D.read_edit_prompts(str(f))
+    assert prompts == ["a cat", "a dog", "make it red", "add snow", "x y", "z"]
+    assert D.read_edit_prompts(str(f), 3) == ["a cat", "a dog", "make it red"]
+    tok = _WordTokenizer()
+    feeder = D.PriorPromptFeeder(prompts, PromptFeeder(tok), additional_template="textboost", additional_category=["dog", "puppy"],
+                                 template_prob=0.3, null_prob=0.2, seed=42)
+    assert feeder.template_data == ["dog", "puppy", "a dog", "a puppy", "one dog", "one puppy", "the dog", "the puppy", "photo of a dog",
+                                    "photo of a puppy"]
+    random.seed(9)
+    b = feeder.batch(40)
+    # replay the reference's logic with the same draws and the same Wrapper order
+    random.seed(9)
+    order = D._DropLastIndexStream(len(prompts), 42).take(40)
+    want = []
+    for i in order:
+        r = random.random()
+        want.append("" if r < 0.2 else random.choice(feeder.template_data) if r < 0.5 else prompts[i])
+    assert b["prompt"] == want and "" in want and any(w in feeder.template_data for w in want)
+    assert b["input_ids"].shape == (40, 77) and b["input_ids"].dtype == torch.int64
+    assert torch.equal(b["input_ids"][want.index("")], torch.tensor([49406] + [49407] * 76))  # the null prompt
+    # drop_last: 6 prompts over 4 ranks -> each epoch 4 of them, one per rank
+    got = [D._DropLastIndexStream(6, 1, r, 4).take(1)[0] for r in range(4)]
+    assert len(set(got)) == 4
+    with pytest.raises(ValueError):
+        D.PriorPromptFeeder(["a"], PromptFeeder(tok), additional_template="{}", additional_category=None, world=2)

@@ -118,3 +118,62 @@ class IndexStream:
                 self._refill()
             out.append(self._queue.pop(0))
         return out
+
+
+def read_edit_prompts(json_file: str, num_samples: Optional[int] = None) -> List[str]:
+    """`InstructPix2PixDataset.__init__` (dataset.py:162-175): one JSON object per line; its "input" and, unless null / "NONE", its "output"."""
+    prompts: List[str] = []
+    with open(json_file, "r") as f:
+        for line in f.readlines():
+            rec = json.loads(line)
+            prompts.append(rec["input"])
+            out = rec["output"]
+            if out is not None and out != "NONE":
+                prompts.append(out)
+    return prompts[:num_samples] if num_samples is not None else prompts
+
+
+class PriorPromptFeeder:
+    """`PriorDataset` + `collate_fn` behind `Wrapper(drop_last=True).shuffle(seed).repeat()` (dataset.py:196-269, train_textboost.py:892-907):
+    the knowledge-preservation prompts.  Per sample one `random.random()` draw: < null_prob -> "", < null_prob + template_prob -> a
+    `random.choice` of template x class-token prompts, else the source prompt at the stream's index.  Token ids come from the shared cache."""
+
+    def __init__(self, source_prompts: Sequence[str], tokenize, additional_template=None, additional_category=None, template_prob=0.1,
+                 null_prob=0.1, seed: int = 0, rank: int = 0, world: int = 1):
+        import random
+        self._random = random
+        self.data = list(source_prompts)
+        if len(self.data) < world:
+            raise ValueError("fewer prior prompts than ranks: Wrapper(drop_last=True) would leave a rank without data")
+        self.tokenize = tokenize
+        self.template_prob, self.null_prob = template_prob, null_prob
+        categories = additional_category if isinstance(additional_category, list) else [additional_category]
+        self.template_data = [t.format(c) for t in load_templates(additional_template) for c in categories]
+        self.stream = _DropLastIndexStream(len(self.data), seed, rank, world)
+
+    def batch(self, n: int):
+        import torch
+        prompts, ids = [], []
+        for index in self.stream.take(n):
+            r = self._random.random()
+            if r < self.null_prob:
+                prompt = ""
+            elif r < self.null_prob + self.template_prob:
+                prompt = self._random.choice(self.template_data)
+            else:
+                prompt = self.data[index]
+            prompts.append(prompt)
+            ids.append(self.tokenize(prompt))
+        return {"prompt": prompts, "input_ids": torch.cat(ids, dim=0)}
+
+
+class _DropLastIndexStream(IndexStream):
+    """Wrapper(drop_last=True): the tail that does not divide by the world size is dropped instead of padded (dataset.py:863-865)."""
+
+    def _refill(self):
+        if self.shuffle:
+            np.random.default_rng(self.seed + self.epoch).shuffle(self.keys)
+        rem = len(self.keys) % self.world
+        idx = self.keys if rem == 0 else self.keys[:-rem]
+        self._queue = [int(i) for i in idx[self.rank::self.world]]
+        self.epoch += 1

@@ -247,6 +247,18 @@ def main(args):
         logger.info("device feeder: %d resident instance image(s), template set %r (%d prompts), augment %s", len(images), args.template,
                     len(feeder.templates), args.augment)
 
+    # ---- knowledge-preservation prompts (:892-907): InstructPix2Pix edit prompts + template x class-token prompts + null prompts
+    prior_feeder = None
+    edit_prompts = os.path.join("data", "human-written-prompts.jsonl")  # the reference's hard-coded relative path (:892)
+    if tokenizer is not None and os.path.exists(edit_prompts):
+        from textboost_amd.augment import PromptFeeder
+        prior_feeder = tbdata.PriorPromptFeeder(tbdata.read_edit_prompts(edit_prompts), feeder.tokenize if feeder is not None else
+                                                PromptFeeder(tokenizer), additional_template=args.template,
+                                                additional_category=args.class_token, null_prob=args.null_prob, seed=args.seed or 0,
+                                                rank=rank, world=world)
+        logger.info("prior prompts: %d edit prompts + %d template prompts, null_prob %.2f", len(prior_feeder.data),
+                    len(prior_feeder.template_data), args.null_prob)
+
     def next_batch(it):
         if feeder is not None:
             b = feeder.batch(index_stream.take(B), out=step.pixel_values)
@@ -265,7 +277,9 @@ def main(args):
             step.x0.copy_(torch.randn(B, 4, latent, latent, generator=dg))
         if feeder is None and ((latents is None and pixels is None) or inst_ids is None):
             step.input_ids.copy_(synthetic_ids(B, added_ids, dg))
-        if prior_ids is not None:
+        if prior_feeder is not None:
+            step.prior_ids.copy_(prior_feeder.batch(B)["input_ids"])
+        elif prior_ids is not None:
             j = torch.randint(0, prior_ids.shape[0], (B,), generator=dg)
             step.prior_ids.copy_(prior_ids[j])
         else:
