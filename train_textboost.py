@@ -193,7 +193,9 @@ def main(args):
                    max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight, kpl_type="cos" if args.kpl_type == "cos" else "mse",
                    mixing=(args.augment_ops if args.augment_ops == "object" else "style") if args.mixing else None)
     if args.with_image_prior or args.unet_params_to_train != "none":
-        raise NotImplementedError("--with_image_prior (broken in the reference, SURVEY 0.6) / --unet_params_to_train are outside this round's hot path")
+        raise NotImplementedError("--with_image_prior (broken in the reference, SURVEY 0.6) and --unet_params_to_train (under the reference's "
+                                  "fp16 setting its UNet LoRA parameters are cast to fp16 at :938 and GradScaler.unscale_ rejects them; the saved "
+                                  "unet/ is never loaded by inference.py) have no runnable reference behaviour to match: not built")
     # options that change the step's arithmetic and are not built fail loudly instead of silently training something else
     if args.mixed_precision != "fp16":
         raise NotImplementedError("only --mixed_precision fp16 is built (the reference driver's setting, run_textboost_db.py:150): fp16 UNet / "
