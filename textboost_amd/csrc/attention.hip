@@ -29,6 +29,16 @@ namespace {
 
 constexpr int KVT = 64;      // keys (or queries, in the dK/dV kernel) per LDS tile
 constexpr int TLD = KVT + 4; // row stride (halfs) of transposed tiles: 136 B -> conflict-free ds_read_b64 across d
+// The transposed STORE (ds_write_b64, lanes = 8 column chunks x 8 row groups) hits each bank pair 4 times with that stride alone: rows 16
+// apart (chunks c, c+2) land on the same banks (16 * TLD * 2 B = 16 words mod 32).  Every group of 16 rows is therefore skewed by another
+// 4 words (TSK halfs): stores and reads are both conflict-free, and on the read side the skew is part of the lane's base address / the
+// compile-time row-block offset -- no extra register or VALU op in the MFMA loops (an XOR swizzle made the forward kernel spill: +30 %).
+// PMC before: SQ_LDS_BANK_CONFLICT = 192 cycles per K/V tile = 28 % of the forward kernel's LDS-active cycles.
+#ifndef TB_ATTN_TRSKEW
+#define TB_ATTN_TRSKEW 1
+#endif
+constexpr int TSK = TB_ATTN_TRSKEW ? 8 : 0;
+__device__ __forceinline__ int tr_row(int d) { return d * TLD + (d >> 4) * TSK; }  // offset (halfs) of row d of a transposed tile
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __attribute__((aligned(16))) const f16 g_zero8[8] = {};  // out-of-range lanes load this line: no divergent branches
 // single v_exp_f32 (no denormal-range fixup: softmax probabilities below 2^-126 may flush to 0)
@@ -41,7 +51,7 @@ struct RM {  // row-major [64][WD] tile, rows padded by 16 B
 };
 template <int WD>
 struct TR {  // transposed [WD][64] tile
-  static constexpr int SIZE = WD * TLD;
+  static constexpr int SIZE = WD * TLD + (WD / 16) * TSK;
 };
 
 // Staging of rows [row0, row0+64) x cols [0, WD) of a (rows x hd) matrix (row stride ld) into LDS, zero outside, split in
@@ -130,7 +140,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = t.v[it][k][i];
         if (ONES && i == 0 && ch * 8 == ones_row) o = f16x4{(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
-        *(f16x4*)(tr + (ch * 8 + i) * TLD + kg * 4) = o;
+        *(f16x4*)(tr + tr_row(ch * 8 + i) + kg * 4) = o;
       }
     }
   }
@@ -140,10 +150,12 @@ template <int WD>
 __device__ __forceinline__ f16x8 frag_rm(const f16* rm, int row, int chunk) {
   return *(const f16x8*)(rm + row * RM<WD>::LD + chunk * 8);
 }
-// A-operand fragment from a transposed tile: row d, contraction indices {k0+4hi..+3, k0+8+4hi..+3}
-__device__ __forceinline__ f16x8 frag_tr(const f16* tr, int d, int k0, int hi) {
-  const f16x4 a = *(const f16x4*)(tr + d * TLD + k0 + 4 * hi);
-  const f16x4 b = *(const f16x4*)(tr + d * TLD + k0 + 8 + 4 * hi);
+// A-operand fragment from a transposed tile: row 32 dblk + l31, contraction indices {k0+4hi..+3, k0+8+4hi..+3}.  tr_row(32 dblk + l31) =
+// tr_row(l31) + dblk * (32 TLD + 2 TSK): one per-lane base, everything else is an immediate of the unrolled loops.
+__device__ __forceinline__ f16x8 frag_tr(const f16* tr, int dblk, int l31, int k0, int hi) {
+  const f16* row = tr + tr_row(l31) + 4 * hi + (dblk * (32 * TLD + 2 * TSK) + k0);
+  const f16x4 a = *(const f16x4*)(row);
+  const f16x4 b = *(const f16x4*)(row + 8);
   f16x8 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
         const f16x8 pf = pack8(s[kt], 8 * jj);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Vt, d * 32 + l31, kt * 32 + 16 * jj, hi), pf, o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Vt, d, l31, kt * 32 + 16 * jj, hi), pf, o[d], 0, 0, 0);
       }
     TB_PRIO(0);
     if (PF) {
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
         const f16x8 dsf = pack8(s, 8 * jj);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Kt, d * 32 + l31, kt * 32 + 16 * jj, hi), dsf, dq[d], 0, 0, 0);
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Kt, d, l31, kt * 32 + 16 * jj, hi), dsf, dq[d], 0, 0, 0);
       }
     }
   }
@@ -634,8 +646,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
         const f16x8 dsf = pack8(dp, 8 * jj);
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(dOt, d * 32 + l31, qt * 32 + 16 * jj, hi), pf, dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Qt, d * 32 + l31, qt * 32 + 16 * jj, hi), dsf, dk[d], 0, 0, 0);
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(dOt, d, l31, qt * 32 + 16 * jj, hi), pf, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Qt, d, l31, qt * 32 + 16 * jj, hi), dsf, dk[d], 0, 0, 0);
         }
       }
     }
