@@ -268,3 +268,28 @@ def test_resample_24bit_and_32bit_multiply_paths_agree():
         for fit in (False, True):
             assert np.array_equal(down(ops.img_resample(t, n_out // 4, b.cuda(), kk.cuda(), 1, fit)), want)
     assert not ops.resample_fit24(torch.tensor([[1 << 23]], dtype=torch.int32))
+
+
+def test_random_shape_sweep_of_the_whole_item_pipeline():
+    """24 seeded random image shapes (portrait / landscape / tiny / odd sizes, up- and down-scaling) through augmentation + Lanczos resize + random
+    crop + normalise: device vs oracle, bit-exact pixel_values and equal prompts."""
+    from oracle import augment as A
+    from textboost_amd import augment as D
+    r = np.random.default_rng(2024)
+    templates = ["a {}", "photo of a {}"]
+    for case in range(24):
+        h, w = int(r.integers(20, 400)), int(r.integers(20, 400))
+        size = int(r.choice([16, 24, 33, 64]))
+        a = rnd(5000 + case, h, w)
+        cfg = dict(hflip=str(r.choice(["false", "true", "inversion"])), inversion=bool(r.integers(0, 2)), p=0.9, color_prob=0.5,
+                   ops=str(r.choice(["object", "style"])))
+        center = bool(r.integers(0, 2))
+        feeder = D.DeviceFeeder([(up(a), "<x>")], FakeTokenizer(), templates, size=size, center_crop=center, augment_pipe=D.PairedAugmentation(**cfg))
+        random.seed(case), np.random.seed(case), torch.manual_seed(case)
+        got = feeder.batch([0, 0])
+        random.seed(case), np.random.seed(case), torch.manual_seed(case)
+        pipe = A.PairedAugmentation(**cfg)
+        for b in range(2):
+            pv, prompt = A.dataset_item(a, "<x>", templates, size, center, pipe)
+            assert got["prompts"][b] == prompt, (case, b)
+            assert np.array_equal(got["pixel_values"][b].cpu().numpy(), pv), (case, b, h, w, size, cfg, center)
