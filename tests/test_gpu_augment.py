@@ -293,3 +293,47 @@ def test_random_shape_sweep_of_the_whole_item_pipeline():
             pv, prompt = A.dataset_item(a, "<x>", templates, size, center, pipe)
             assert got["prompts"][b] == prompt, (case, b)
             assert np.array_equal(got["pixel_values"][b].cpu().numpy(), pv), (case, b, h, w, size, cfg, center)
+
+
+def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch):
+    """Resume (train_textboost.py:959-981): a run interrupted at checkpoint-2 and resumed to step 4 sees the same samples (index streams
+    fast-forwarded, torch / numpy / `random` states restored from random_states_0.pkl) as the uninterrupted run."""
+    import sys
+    pytest.importorskip("PIL")
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+    from tests.test_host_logic import _WordTokenizer
+    data = tmp_path / "dog"
+    data.mkdir()
+    for i, (h, w) in enumerate([(160, 140), (150, 190), (200, 200)]):
+        Image.fromarray(rnd(40 + i, h, w)).save(str(data / f"{i}.png"))
+    monkeypatch.chdir(tmp_path)
+    base = ["--pretrained_model_name_or_path", "/nonexistent/sd15", "--instance_data_dir", str(data), "--train_batch_size", "2", "--resolution",
+            "64", "--placeholder_token", "<dog>", "--initializer_token", "dog", "--lora_rank", "4", "--mixed_precision", "fp16", "--seed", "11",
+            "--augment", "paug", "--augment_inversion", "--augment_p", "0.9", "--checkpointing_steps", "2", "--emb_learning_rate", "1e-2"]
+    prompts = {}
+
+    def run(out, extra):
+        monkeypatch.setattr(T, "load_tokenizer", lambda mdir: _WordTokenizer())
+        seen = []
+        from textboost_amd import augment as D
+        orig = D.DeviceFeeder.batch
+
+        def spy(self, indices, out=None):
+            b = orig(self, indices, out=out)
+            seen.append((list(indices), list(b["prompts"])))
+            return b
+        monkeypatch.setattr(D.DeviceFeeder, "batch", spy)
+        T.main(T.parse_args(base + ["--output_dir", out] + extra))
+        monkeypatch.setattr(D.DeviceFeeder, "batch", orig)
+        prompts.setdefault(out, []).extend(seen)
+        return torch.load(os.path.join(out, "dog.bin"))["<dog>"]
+
+    full = run(str(tmp_path / "full"), ["--max_train_steps", "4"])
+    run(str(tmp_path / "part"), ["--max_train_steps", "2"])
+    resumed = run(str(tmp_path / "part"), ["--max_train_steps", "4", "--resume_from_checkpoint", "latest"])
+    a, bc = prompts[str(tmp_path / "full")], prompts[str(tmp_path / "part")]
+    assert len(a) == 4 and bc == a  # same indices, same augmented prompts, batch by batch across the interruption
+    assert torch.allclose(full, resumed, rtol=0, atol=2e-3) and not torch.equal(full, torch.zeros_like(full))

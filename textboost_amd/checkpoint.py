@@ -13,9 +13,11 @@ from __future__ import annotations
 import json
 import os
 import pickle
+import random
 import shutil
 from typing import Dict
 
+import numpy as np
 import torch
 from safetensors.torch import load_file, save_file
 
@@ -91,7 +93,9 @@ def save_trainer_state(step_obj, ckpt_dir: str):
     torch.save({"scale": float(step_obj.state[0].item()), "growth_tracker": float(step_obj.state[1].item()), "growth_factor": 2.0,
                 "backoff_factor": 0.5, "growth_interval": step_obj.hp.growth_interval}, os.path.join(ckpt_dir, "scaler.pt"))
     with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "wb") as f:
-        pickle.dump({"torch_manual_seed": torch.get_rng_state(),
+        # accelerate's key names; `random` / numpy feed the augmentation draws of the device feeder (textboost_amd/augment.py)
+        pickle.dump({"random_state": random.getstate(), "numpy_random_seed": np.random.get_state(),
+                     "torch_manual_seed": torch.get_rng_state(),
                      "torch_cuda_manual_seed": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []}, f)
 
 
@@ -108,6 +112,10 @@ def load_trainer_state(step_obj, ckpt_dir: str):
     te.token_table[: te.first_added].mul_((1.0 - step_obj.hp.emb_lr * step_obj.hp.wd) ** n)
     with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "rb") as f:
         rs = pickle.load(f)
+    if "random_state" in rs:
+        random.setstate(rs["random_state"])
+    if "numpy_random_seed" in rs:
+        np.random.set_state(rs["numpy_random_seed"])
     torch.set_rng_state(rs["torch_manual_seed"])
     if rs["torch_cuda_manual_seed"]:
         torch.cuda.set_rng_state_all(rs["torch_cuda_manual_seed"])

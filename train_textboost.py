@@ -295,8 +295,12 @@ def main(args):
             dirs = sorted([d for d in os.listdir(args.output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
             path = os.path.join(args.output_dir, dirs[-1]) if dirs else None
         if path:
-            ckpt.load_trainer_state(step, path)
+            ckpt.load_trainer_state(step, path)  # also restores the torch / numpy / `random` generator states the feeder draws from
             first_step = int(os.path.basename(path.rstrip("/")).split("-")[1])
+            if index_stream is not None:          # the Wrapper streams are pure functions of (seed, position): fast-forward them
+                index_stream.take(first_step * B)
+            if prior_feeder is not None:
+                prior_feeder.stream.take(first_step * B)
     if is_main:
         logger.info("mean_norm %.6f | added tokens %s | world %d | per-GPU batch %d", step.mean_norm, list(added_tokens) +
                     list(aug_token_dict), world, B)
@@ -322,7 +326,8 @@ def main(args):
 
     from textboost_amd.trainer import lr_lambda
     lam = lr_lambda(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps, lr_init=hp.lr)  # :911-916
-    next_batch(0)
+    if feeder is None:
+        next_batch(0)  # the device feeder consumes random draws per batch: there the graph is captured over the (zero) input buffers
     step.capture(warmup=0)
     t0 = time.perf_counter()
     for it in range(first_step, args.max_train_steps):
