@@ -236,7 +236,8 @@ int tb_img_resample(const uint32_t* src, int64_t sstride, int sw, int sh, uint32
                     const int32_t* bounds /* device */, const int32_t* kk /* device */, int ksize, int vertical,
                     int coeffs_fit_24bit /* 1: every |kk| < 2^23 (checked by the caller on the host table): full-rate 24-bit multiplies */,
                     tb_stream_t stream);
-/* dst[y][x] = xt[x] >= 0 && yt[y] >= 0 ? src[yt[y]][xt[x]] : 0 (crop, pad, flip, collage tiling, NEAREST affine); gray = convert("L") luma */
+/* dst[y][x] = xt[x] >= 0 && yt[y] >= 0 ? src[yt[y]][xt[x]] : 0 (crop, pad, flip, collage tiling, NEAREST affine); gray = convert("L") luma.
+ * The caller owns the tables: entries must be -1 or valid column / row indices of src (they cannot be range-checked without reading them back). */
 int tb_img_gather(const uint32_t* src, int64_t sstride, uint32_t* dst, int64_t dstride, int dw, int dh, const int32_t* xt /* device [dw] */,
                   const int32_t* yt /* device [dh] */, int gray, tb_stream_t stream);
 /* Image.transform(AFFINE, a, BICUBIC) of the image edge-padded by (pad_x, pad_y), window [oy, oy + dh) x [ox, ox + dw) of its output (zeros

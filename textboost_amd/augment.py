@@ -16,6 +16,7 @@ An image is an int32 CUDA tensor [H, W] (one RGBX pixel per element).
 """
 from __future__ import annotations
 
+import collections
 import math
 import random
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -28,7 +29,9 @@ from . import ops
 
 NEAREST, LANCZOS, BICUBIC = 0, L.IMG_LANCZOS, L.IMG_BICUBIC
 
-_coeff_cache: Dict[tuple, tuple] = {}
+# resample tables per (in, out, filter, device): an LRU, because `crop` draws a new source size for almost every sample
+_coeff_cache: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_COEFF_CACHE_MAX = 1024
 
 
 def _dev_table(a: np.ndarray, device) -> torch.Tensor:
@@ -59,6 +62,10 @@ def resize(img: torch.Tensor, size_wh: Tuple[int, int], filt: int) -> torch.Tens
         if key not in _coeff_cache:
             _, bounds, kk = ops.resample_coeffs(n_in, n_out, filt)
             _coeff_cache[key] = (bounds.to(img.device), kk.to(img.device), ops.resample_fit24(kk))
+            if len(_coeff_cache) > _COEFF_CACHE_MAX:
+                _coeff_cache.popitem(last=False)
+        else:
+            _coeff_cache.move_to_end(key)
         bounds, kk, fit24 = _coeff_cache[key]
         out = ops.img_resample(out, n_out, bounds, kk, vertical, fit24)
     return out.clone() if out is img else out
