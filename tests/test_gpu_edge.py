@@ -93,3 +93,40 @@ def test_cli_rejects_unbuilt_arithmetic_options(tmp_path):
                   ["--mixed_precision", "fp16", "--lora_rank", "0"], ["--mixed_precision", "fp16", "--text_encoder_use_attention_mask"]):
         with pytest.raises(NotImplementedError):
             T.main(T.parse_args(base + extra))
+
+
+def test_cli_reads_the_architecture_from_the_model_directory(tmp_path, monkeypatch):
+    """from_pretrained semantics: unet/config.json + text_encoder/config.json select the geometry (here an SD2.x-style one: Linear proj_in/out,
+    per-level head counts, erf-GELU text MLP), scheduler_config.json the prediction type, assets/null_emb_sd21base.pt the null embedding."""
+    import json
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+    m = tmp_path / "sd2-tiny"
+    for sub in ("unet", "text_encoder", "scheduler"):
+        (m / sub).mkdir(parents=True)
+    json.dump({"attention_head_dim": [2, 4, 8, 8], "block_out_channels": [64, 128, 256, 256], "cross_attention_dim": 128,
+               "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3,
+               "in_channels": 4, "out_channels": 4, "layers_per_block": 2, "norm_num_groups": 32, "norm_eps": 1e-5,
+               "use_linear_projection": True, "act_fn": "silu"}, open(m / "unet" / "config.json", "w"))
+    json.dump({"hidden_act": "gelu", "hidden_size": 128, "intermediate_size": 256, "num_attention_heads": 4, "num_hidden_layers": 2,
+               "max_position_embeddings": 77, "vocab_size": 49408, "layer_norm_eps": 1e-5}, open(m / "text_encoder" / "config.json", "w"))
+    json.dump({"prediction_type": "v_prediction"}, open(m / "scheduler" / "scheduler_config.json", "w"))
+    (tmp_path / "assets").mkdir()
+    null = torch.randn(77, 128, generator=torch.Generator().manual_seed(0))
+    torch.save(null, str(tmp_path / "assets" / "null_emb_sd21base.pt"))
+    monkeypatch.chdir(tmp_path)
+    out = str(tmp_path / "run")
+    args = T.parse_args(["--pretrained_model_name_or_path", str(m), "--output_dir", out, "--train_batch_size", "2", "--resolution", "128",
+                         "--max_train_steps", "3", "--placeholder_token", "<dog>", "--lora_rank", "8", "--mixed_precision", "fp16", "--seed", "5"])
+    T.main(args)
+    log = open(os.path.join(out, "training.log")).read()
+    assert "null embedding loaded from assets/null_emb_sd21base.pt" in log
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(out, "text_encoder", "adapter_model.safetensors"))
+    assert len(sd) == 2 * 3 * 2 and sd["base_model.model.text_model.encoder.layers.1.self_attn.q_proj.lora_A.weight"].shape == (8, 128)
+    d = torch.load(os.path.join(out, "dog.bin"))
+    assert d["<dog>"].shape == (128,) and torch.isfinite(d["<dog>"]).all()

@@ -196,3 +196,28 @@ def test_prior_prompt_feeder_follows_prior_dataset(tmp_path):
     assert len(set(got)) == 4
     with pytest.raises(ValueError):
         D.PriorPromptFeeder(["a"], PromptFeeder(tok), additional_template="{}", additional_category=None, world=2)
+
+
+def test_geometry_from_published_model_configs():
+    """unet/config.json and text_encoder/config.json of SD1.5 and SD2.1 (the fields diffusers / transformers publish) -> the built geometries."""
+    from textboost_amd import models
+    sd15_unet = {"act_fn": "silu", "attention_head_dim": 8, "block_out_channels": [320, 640, 1280, 1280], "center_input_sample": False,
+                 "cross_attention_dim": 768, "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], "downsample_padding": 1,
+                 "flip_sin_to_cos": True, "freq_shift": 0, "in_channels": 4, "layers_per_block": 2, "mid_block_scale_factor": 1,
+                 "norm_eps": 1e-05, "norm_num_groups": 32, "out_channels": 4, "sample_size": 64,
+                 "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3}
+    sd21_unet = dict(sd15_unet, attention_head_dim=[5, 10, 20, 20], cross_attention_dim=1024, use_linear_projection=True, sample_size=96,
+                     dual_cross_attention=False, only_cross_attention=False, upcast_attention=False)
+    assert models.unet_geometry_from_config(sd15_unet) == models.SD15_UNET
+    assert models.unet_geometry_from_config(sd21_unet) == models.SD21_UNET
+    clip_l = {"hidden_act": "quick_gelu", "hidden_size": 768, "intermediate_size": 3072, "layer_norm_eps": 1e-05, "max_position_embeddings": 77,
+              "num_attention_heads": 12, "num_hidden_layers": 12, "vocab_size": 49408}
+    clip_h = dict(clip_l, hidden_act="gelu", hidden_size=1024, intermediate_size=4096, num_attention_heads=16, num_hidden_layers=23)
+    assert models.clip_geometry_from_config(clip_l) == models.SD15_CLIP
+    assert models.clip_geometry_from_config(clip_h) == models.SD21_CLIP
+    with pytest.raises(NotImplementedError):
+        models.unet_geometry_from_config(dict(sd15_unet, addition_embed_type="text_time"))       # SDXL
+    with pytest.raises(NotImplementedError):
+        models.unet_geometry_from_config(dict(sd15_unet, down_block_types=["DownBlock2D"] * 4))  # mirror check: up blocks still cross-attn
+    with pytest.raises(NotImplementedError):
+        models.clip_geometry_from_config(dict(clip_l, hidden_act="relu"))

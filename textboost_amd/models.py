@@ -139,3 +139,40 @@ def count_params(shapes) -> int:
             k *= s
         n += k
     return n
+
+
+def unet_geometry_from_config(cfg: dict) -> UNetGeometry:
+    """`UNet2DConditionModel.from_pretrained(..., subfolder="unet")` (train_textboost.py:651-656): the geometry a diffusers `unet/config.json`
+    describes.  `attention_head_dim` is the number of heads in SD1.x / SD2.x configs (8, or [5, 10, 20, 20]); anything this path does not
+    implement (other block types, dual cross-attention, class embeddings, ...) is rejected instead of being silently ignored."""
+    down = list(cfg.get("down_block_types", ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]))
+    up = list(cfg.get("up_block_types", ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3))
+    if set(down) - {"CrossAttnDownBlock2D", "DownBlock2D"} or set(up) - {"CrossAttnUpBlock2D", "UpBlock2D"}:
+        raise NotImplementedError(f"UNet block types {down} / {up} are not built")
+    cross = tuple(t == "CrossAttnDownBlock2D" for t in down)
+    if tuple(t == "CrossAttnUpBlock2D" for t in reversed(up)) != cross:
+        raise NotImplementedError("up_block_types must mirror down_block_types")
+    for key, ok in (("class_embed_type", (None,)), ("addition_embed_type", (None,)), ("dual_cross_attention", (False, None)),
+                    ("only_cross_attention", (False, None)), ("act_fn", ("silu", None)), ("mid_block_type", ("UNetMidBlock2DCrossAttn", None)),
+                    ("transformer_layers_per_block", (1, None)), ("center_input_sample", (False, None)), ("flip_sin_to_cos", (True, None)),
+                    ("freq_shift", (0, None)), ("downsample_padding", (1, None)), ("upcast_attention", (False, None))):
+        if cfg.get(key) not in ok:
+            raise NotImplementedError(f"unet config {key}={cfg.get(key)!r} is not built")
+    heads = cfg.get("attention_head_dim", 8)
+    heads = tuple(heads) if isinstance(heads, (list, tuple)) else int(heads)
+    return UNetGeometry(in_channels=cfg.get("in_channels", 4), out_channels=cfg.get("out_channels", 4),
+                        block_out_channels=tuple(cfg.get("block_out_channels", (320, 640, 1280, 1280))),
+                        layers_per_block=cfg.get("layers_per_block", 2), cross_attn_levels=cross, num_heads=heads,
+                        cross_attention_dim=cfg.get("cross_attention_dim", 768), norm_num_groups=cfg.get("norm_num_groups", 32),
+                        norm_eps=cfg.get("norm_eps", 1e-5), use_linear_projection=bool(cfg.get("use_linear_projection", False)))
+
+
+def clip_geometry_from_config(cfg: dict) -> CLIPGeometry:
+    """transformers `CLIPTextConfig` (`text_encoder/config.json`) -> the text-encoder geometry (SD1.x CLIP-L, SD2.x OpenCLIP-H's 23 layers)."""
+    act = cfg.get("hidden_act", "quick_gelu")
+    if act not in ("quick_gelu", "gelu"):
+        raise NotImplementedError(f"text encoder hidden_act={act!r} is not built")
+    return CLIPGeometry(vocab_size=cfg.get("vocab_size", 49408), hidden_size=cfg.get("hidden_size", 768),
+                        intermediate_size=cfg.get("intermediate_size", 3072), num_layers=cfg.get("num_hidden_layers", 12),
+                        num_heads=cfg.get("num_attention_heads", 12), max_pos=cfg.get("max_position_embeddings", 77), act=act,
+                        eps=cfg.get("layer_norm_eps", 1e-5))

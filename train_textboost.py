@@ -104,6 +104,11 @@ def main(args):
     usd = load_local_state_dict(os.path.join(mdir, "unet", "diffusion_pytorch_model.safetensors")) if os.path.isdir(mdir) else None
     csd = load_local_state_dict(os.path.join(mdir, "text_encoder", "model.safetensors")) if os.path.isdir(mdir) else None
     unet_geo, clip_geo = models.SD15_UNET, models.SD15_CLIP
+    ucfg, ccfg = os.path.join(mdir, "unet", "config.json"), os.path.join(mdir, "text_encoder", "config.json")
+    if os.path.exists(ucfg):  # from_pretrained reads the architecture from the model directory (SD1.x, SD2.x): so does this
+        unet_geo = models.unet_geometry_from_config(json.load(open(ucfg)))
+    if os.path.exists(ccfg):
+        clip_geo = models.clip_geometry_from_config(json.load(open(ccfg)))
     if usd is None or csd is None:
         logger.warning("no local weights under %s: seeded random-init SD1.5 / CLIP-L shapes are used", mdir)
         usd = models.random_state_dict(models.unet_shapes(unet_geo), 1234, device=dev)
@@ -150,6 +155,13 @@ def main(args):
     null_ids[0, 0] = BOS
     null = frozen.forward(null_ids, pins=False).clone()  # SD1.x null embedding (the reference ships one only for SD2.1: SURVEY 0.5)
     del frozen
+    shipped = os.path.join("assets", "null_emb_sd21base.pt")  # the reference's hard-coded relative path (:649), a [77, 1024] tensor
+    if os.path.exists(shipped):
+        t = torch.load(shipped, map_location="cpu")
+        t = t[0] if t.dim() == 3 else t
+        if tuple(t.shape) == tuple(null.shape[-2:]):
+            null = t.to(dev, null.dtype).reshape(null.shape)
+            logger.info("null embedding loaded from %s", shipped)
     te = HipTextEncoder(clip_geo, csd, B, mode="autocast", lora_rank=args.lora_rank, n_slots=1, device=dev, seed=args.seed)
     del csd
     te.set_null_embedding(null)
