@@ -169,9 +169,12 @@ def make_feeder(step, args, rank):
     random.seed(42 + rank)
     np.random.seed(42 + rank)
 
-    def feed():
-        b = feeder.batch(stream.take(args.batch), out=step.pixel_values)
-        step.input_ids.copy_(b["input_ids"] % 49408, non_blocking=True)
+    pre = aug.PrefetchFeeder(feeder, args.batch, step.pixel_values, step.input_ids)
+    pre.prefetch(stream.take(args.batch))
+
+    def feed():  # called right before each replay: commit the prefetched batch, then produce the next one while the step runs
+        pre.commit()
+        return lambda: pre.prefetch(stream.take(args.batch))
 
     return feed
 
@@ -238,9 +241,10 @@ def main():
     else:
         step.capture(warmup=2)
     def one_step():
-        if feed is not None:
-            feed()
+        after = feed() if feed is not None else None
         step.replay()
+        if after is not None:
+            after()
 
     for _ in range(args.warmup):
         one_step()

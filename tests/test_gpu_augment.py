@@ -337,3 +337,34 @@ def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch):
     a, bc = prompts[str(tmp_path / "full")], prompts[str(tmp_path / "part")]
     assert len(a) == 4 and bc == a  # same indices, same augmented prompts, batch by batch across the interruption
     assert torch.allclose(full, resumed, rtol=0, atol=2e-3) and not torch.equal(full, torch.zeros_like(full))
+
+
+def test_prefetch_feeder_matches_direct_batches():
+    """PrefetchFeeder (side stream + staging) delivers exactly what DeviceFeeder.batch would have, in order."""
+    from textboost_amd import augment as D
+    imgs = [rnd(61, 130, 170), rnd(62, 200, 120)]
+    templates = ["a {}", "{} on a table"]
+
+    def make():
+        return D.DeviceFeeder([(up(a), "<s>") for a in imgs], FakeTokenizer(), templates, size=48, center_crop=False,
+                              augment_pipe=D.PairedAugmentation(hflip="inversion", inversion=True, p=0.9, color_prob=0.5))
+    idx = [[0, 1, 1], [1, 0, 0], [0, 0, 1], [1, 1, 0]]
+    random.seed(8), np.random.seed(8), torch.manual_seed(8)
+    f = make()
+    want = [f.batch(i) for i in idx]
+    want = [(b["pixel_values"].clone(), b["input_ids"].clone(), b["prompts"]) for b in want]
+    random.seed(8), np.random.seed(8), torch.manual_seed(8)
+    pv = torch.zeros(3, 3, 48, 48, device="cuda")
+    ids = torch.zeros(3, 77, dtype=torch.int64, device="cuda")
+    pre = D.PrefetchFeeder(make(), 3, pv, ids)
+    pre.prefetch(idx[0])
+    for k in range(4):
+        prompts = pre.commit()
+        if k + 1 < 4:
+            pre.prefetch(idx[k + 1])  # overlaps with the consumer below, as in the training loop
+        busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")  # stand-in for the step on the main stream
+        assert prompts == want[k][2]
+        assert torch.equal(pv, want[k][0]) and torch.equal(ids.cpu(), want[k][1])
+        del busy
+    with pytest.raises(RuntimeError):
+        pre.commit()

@@ -273,10 +273,11 @@ def main(args):
         logger.info("prior prompts: %d edit prompts + %d template prompts, null_prob %.2f", len(prior_feeder.data),
                     len(prior_feeder.template_data), args.null_prob)
 
+    prefetcher = None
+
     def next_batch(it):
-        if feeder is not None:
-            b = feeder.batch(index_stream.take(B), out=step.pixel_values)
-            step.input_ids.copy_(b["input_ids"])
+        if prefetcher is not None:
+            prefetcher.commit()
         elif pixels is not None:
             idx = shard_indices(pixels.shape[0], B, it, rank, world)
             step.pixel_values.copy_(pixels[idx])
@@ -341,6 +342,10 @@ def main(args):
     if feeder is None:
         next_batch(0)  # the device feeder consumes random draws per batch: there the graph is captured over the (zero) input buffers
     step.capture(warmup=0)
+    if feeder is not None:  # batch k+1 is produced on a side stream while step k runs (augment.PrefetchFeeder)
+        from textboost_amd.augment import PrefetchFeeder
+        prefetcher = PrefetchFeeder(feeder, B, step.pixel_values, step.input_ids)
+        prefetcher.prefetch(index_stream.take(B))
     t0 = time.perf_counter()
     for it in range(first_step, args.max_train_steps):
         next_batch(it)
@@ -361,6 +366,9 @@ def main(args):
             ckpt.save_trainer_state(step, cdir)
             ckpt.save_text_encoder_adapter(te, os.path.join(cdir, "text_encoder"), mdir)
             ckpt.save_token_embeddings(te, cdir, added_tokens, aug_token_dict if args.augment_inversion else None)
+        if prefetcher is not None and done < args.max_train_steps:
+            # after the checkpoint, so that the generator states saved in it are those BEFORE the next batch's draws (resume replays them)
+            prefetcher.prefetch(index_stream.take(B))
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
