@@ -194,41 +194,60 @@ class TextBoostStep:
         self.noise.normal_(generator=self.gen)
         self.timesteps.random_(0, self.hp.num_train_timesteps, generator=self.gen)
 
-    def forward_backward(self):
+    # the step body in four phases; `forward_backward` runs them in the reference's order on one stream (teacher on a forked side stream)
+    def _phase_student(self):
         hp, te, B = self.hp, self.te, self.B
-        st = self.state
         if self.vae is not None:
             self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))                  # :1027-1037
         ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
         te.pack_lora()
-        BT = B * te.T
-        h_all = te.forward(self.ids_all, slot=0)                                   # :1054-1059 and :1099 in one batch
-        ops.convert(h_all[:BT], self.ehs16)                                        # .to(unet.dtype) :1066
-        main = torch.cuda.current_stream()
-        fork = None
-        if self.kpl:
-            fork = torch.cuda.Event()
-            fork.record(main)
-        pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)           # :1063-1067
-        if self.kpl:                                                               # :1096-1106
-            # the frozen fp16 teacher + KPL loss depend only on the student's hidden states: they are issued on a side stream (a
-            # fork/join inside the HIP graph) after the UNet forward.  ROCm 7 serialises the branch at replay (same steps/s with and
-            # without the second stream), so today this only keeps the dependency structure honest.
-            self.side.wait_event(fork)
-            with torch.cuda.stream(self.side), ops.workspace_slot(1):
-                h0 = self.teacher.forward(self.prior_ids, slot=0)
-                kpl = ops.kpl_cos if hp.kpl_type == "cos" else ops.kpl_mse
-                kpl(h_all[BT:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
+        self.h_all = te.forward(self.ids_all, slot=0)                              # :1054-1059 and :1099 in one batch
+        ops.convert(self.h_all[:B * te.T], self.ehs16)                             # .to(unet.dtype) :1066
+
+    def _phase_teacher(self):
+        """:1096-1106 -- the frozen fp16 teacher + the KPL loss; depends only on the student's hidden states."""
+        hp, st = self.hp, self.state
+        h0 = self.teacher.forward(self.prior_ids, slot=0)
+        kpl = ops.kpl_cos if hp.kpl_type == "cos" else ops.kpl_mse
+        kpl(self.h_all[self.B * self.te.T:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
+
+    def _phase_unet_forward(self):
+        self.pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16)      # :1063-1067
+
+    def _phase_unet_backward(self):
+        hp, st = self.hp, self.state
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
-        ops.mse_loss(pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
+        ops.mse_loss(self.pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
         self.unet.backward(self.dpred, d_ehs_out=self.d_ehs)                       # :1108 (UNet part, dgrad only)
-        if self.kpl:
-            main.wait_stream(self.side)
+
+    def _phase_encoder_backward(self):
+        hp, te = self.hp, self.te
         self.flat_grad.zero_()
         te.backward(self.d_all, slot=0)
         if hp.mixing is not None:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
             gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
             gB[:, :, (1 if hp.mixing == "object" else 0)::2, :].zero_()
+
+    def forward_backward(self):
+        self._phase_student()
+        main = torch.cuda.current_stream()
+        fork = None
+        if self.kpl:
+            fork = torch.cuda.Event()
+            fork.record(main)
+        self._phase_unet_forward()
+        if self.kpl:
+            # the teacher is issued on a side stream (a fork/join inside the HIP graph) after the UNet forward.  ROCm 7 serialises a graph's
+            # branches at replay (same steps/s with and without the second stream); the teacher as its OWN graph on the side stream, which
+            # does run concurrently with the UNet graph, measured the same steps/s too (26.0 vs 26.0 / 26.1): the UNet's kernels already
+            # occupy every CU, concurrency only re-divides them (DESIGN.md section 4).
+            self.side.wait_event(fork)
+            with torch.cuda.stream(self.side), ops.workspace_slot(1):
+                self._phase_teacher()
+        self._phase_unet_backward()
+        if self.kpl:
+            main.wait_stream(self.side)
+        self._phase_encoder_backward()
 
     def set_lr_multiplier(self, mult: float):
         """LambdaLR semantics of diffusers `get_scheduler` (:911-916, `lr_scheduler.step()` :1135): every param group's lr of the NEXT
@@ -276,19 +295,22 @@ class TextBoostStep:
                 self.step_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if self.world > 1 or self.force_dist:
+        dist = self.world > 1 or self.force_dist
+        G = lambda: torch.cuda.CUDAGraph()  # noqa: E731
+        cap = lambda g, **kw: torch.cuda.graph(g, capture_error_mode="thread_local", **kw)  # noqa: E731  (thread_local: the RCCL watchdog
+        #                                                                      thread keeps polling its events while this thread captures)
+        if dist:
             # keep the collective outside the graphs: two graphs around one eager RCCL call
-            self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread keeps polling its events while this thread captures
-            with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
+            self.g1, self.g2 = G(), G()
+            with cap(self.g1):
                 self.draw()
                 self.forward_backward()
-            with torch.cuda.graph(self.g2, capture_error_mode="thread_local"):
+            with cap(self.g2):
                 self.optimizer_step()
             self.graph = (self.g1, self.g2)
         else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            g = G()
+            with cap(g):
                 self.draw()
                 self.forward_backward()
                 self.optimizer_step()
