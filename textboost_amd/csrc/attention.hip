@@ -121,7 +121,8 @@ __device__ __forceinline__ void tile_load(TileRegs<WD>& t, const f16* g, int64_t
   }
 }
 // ONES: row `ones_row` (a multiple of 8 inside the zero padding hd..WD-1) of the transposed image is all ones
-template <int WD, bool ROWMAJOR, bool TRANSPOSED, bool ONES = false>
+// ONECOL: column `ones_row` (a multiple of 8 inside the padding hd..WD-1) of the row-major image is all ones (attn_fwd_kernel FOLDM)
+template <int WD, bool ROWMAJOR, bool TRANSPOSED, bool ONES = false, bool ONECOL = false>
 __device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* tr, int ones_row = -1) {
   constexpr int CPR = TileRegs<WD>::CPR;
 #pragma unroll
@@ -131,7 +132,11 @@ __device__ __forceinline__ void tile_store(const TileRegs<WD>& t, f16* rm, f16* 
     const int kg = idx / CPR, ch = idx - kg * CPR;
     if (ROWMAJOR) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) *(f16x8*)(rm + (kg * 4 + k) * RM<WD>::LD + ch * 8) = t.v[it][k];
+      for (int k = 0; k < 4; ++k) {
+        f16x8 v = t.v[it][k];
+        if (ONECOL && ch * 8 == ones_row) v[0] = (f16)1.f;
+        *(f16x8*)(rm + (kg * 4 + k) * RM<WD>::LD + ch * 8) = v;
+      }
     }
     if (TRANSPOSED) {
 #pragma unroll
@@ -201,6 +206,9 @@ __device__ __forceinline__ void scale_frags(f16x8* f, float c) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+#ifndef TB_ATTN_FOLDM
+#define TB_ATTN_FOLDM 1
+#endif
 #ifndef TB_ATTN_REBASE
 #define TB_ATTN_REBASE 8.f
 #endif
@@ -209,7 +217,12 @@ __device__ __forceinline__ void scale_frags(f16x8* f, float c) {
 #else
 #define TB_FWD_OCC3 1
 #endif
-template <int DT, int KS, bool ONES>
+// FOLDM (hd a multiple of 8 with hd < 16 KS, i.e. SD1.x's hd = 40): the running max enters the score product through the head-dim PADDING --
+// K's padding column hd is all ones in LDS and the lane-owned Q fragment carries -m (rounded to fp16, and m is kept fp16-representable so l, the
+// re-base factor and the stored LSE all use exactly the value that was subtracted) in that slot -- so the score accumulators start from the
+// inline constant 0: no 16-register -m tuple (the 168-VGPR kernel spilled with it) and no 32 accumulator-init moves per tile (PMC: 32 of the
+// ~115 non-MFMA VALU ops per wave-tile).
+template <int DT, int KS, bool ONES, bool FOLDM>
 __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {  // 3 blocks/CU only where 168 VGPRs hold without spills
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -232,7 +245,10 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
   // running max m (log2 domain) enters the score MFMA as its accumulator input: s' = c * q.k - m is the exp2 argument
   float m = 0.f, l = 0.f;
   f32x16 negm;
-  ZERO16(negm);
+  if (!FOLDM) ZERO16(negm);
+  // FOLDM: column hd of the lane's Q row lives in element 0 of chunk hd / 16 of the hi == (hd / 8) & 1 lanes
+  const int fj = p.hd >> 4;
+  const bool fold_lane = FOLDM && hi == ((p.hd >> 3) & 1);
   int kv_end = p.Skv;
   if (p.causal) kv_end = min(p.Skv, qblk + 128);  // keys beyond the block's last query are never visible
   // K / V^T tiles are double-buffered in LDS (PF: DT <= 3): tile t+1 is written (from the registers its global loads landed in during
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
   if (PF) {
     tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
     tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
-    tile_store<WD, true, false>(kreg, Ks, nullptr);
+    tile_store<WD, true, false, false, FOLDM>(kreg, Ks, nullptr, p.hd);
     tile_store<WD, false, true, ONES>(vreg, nullptr, Vt, p.hd);
     if (KVT < kv_end) {
       tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
       Vt = Ks + RM<WD>::SIZE;
       if (kv0 + KVT < kv_end) {  // next tile -> the other buffer (every wave left it at the barrier that ended the previous iteration)
         f16* Kn = reinterpret_cast<f16*>(smem_raw) + (cur ^ 1) * TILE;
-        tile_store<WD, true, false>(kreg, Kn, nullptr);
+        tile_store<WD, true, false, false, FOLDM>(kreg, Kn, nullptr, p.hd);
         tile_store<WD, false, true, ONES>(vreg, nullptr, Kn + RM<WD>::SIZE, p.hd);
         if (kv0 + 2 * KVT < kv_end) {
           tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, kv0 + 2 * KVT, p.Skv, p.hd);
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
       __syncthreads();
       tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, kv0, p.Skv, p.hd);
       tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, kv0, p.Skv, p.hd);
-      tile_store<WD, true, false>(kreg, Ks, nullptr);
+      tile_store<WD, true, false, false, FOLDM>(kreg, Ks, nullptr, p.hd);
       tile_store<WD, false, true, ONES>(vreg, nullptr, Vt, p.hd);
       __syncthreads();
     }
@@ -279,7 +295,11 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
     TB_PRIO(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      s[kt] = negm;
+      if (FOLDM) {
+        ZERO16(s[kt]);  // the inline constant 0 as the first MFMA's accumulator input
+      } else {
+        s[kt] = negm;
+      }
 #pragma unroll
       for (int j = 0; j < KS; ++j)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s[kt], 0, 0, 0);
@@ -311,7 +331,8 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
     // re-based (one of a wave's 32 rows sees a new maximum with probability ~ 1 - (1 - 1/t)^32 at tile t): ~70 VALU ops each (PMC:
     // SQ_INSTS_VALU_MUL_F32 / ADD_F32 ~ 11 per wave-tile).
     if (first || __any(mx > TB_ATTN_REBASE)) {
-      const float d = first ? mx : fmaxf(mx, 0.f);
+      float d = first ? mx : fmaxf(mx, 0.f);
+      if (FOLDM) d = (float)(f16)(m + d) - m;  // keep m fp16-representable: the Q slot subtracts exactly m (the difference is exact in fp32)
       if (!first) {
         const float alpha = fast_exp2(-d);
         l *= alpha;
@@ -325,7 +346,13 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] -= d;
       m += d;
-      FILL16(negm, -m);
+      if (FOLDM) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+          if (j == fj && fold_lane) qf[j][0] = (f16)(-m);
+      } else {
+        FILL16(negm, -m);
+      }
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -723,10 +750,12 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
   size_t lds = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16) * (DT <= 3 ? 2 : 1);  // double-buffered K / V^T tiles
   dim3 grid((d.Sq + 127) / 128, d.H, d.B);
-  if (d.hd < WD)  // head-dim padding exists: the row sum rides on the PV product (all-ones row hd of V^T)
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true>), grid, dim3(256), lds, s, d);
+  if (TB_ATTN_FOLDM && DT <= 2 && d.hd < WD && d.hd < 16 * KS && d.hd % 8 == 0)  // padding in the head dim of BOTH products: see FOLDM
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, (DT <= 2)>), grid, dim3(256), lds, s, d);
+  else if (d.hd < WD)  // head-dim padding exists: the row sum rides on the PV product (all-ones row hd of V^T)
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, false>), grid, dim3(256), lds, s, d);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false, false>), grid, dim3(256), lds, s, d);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
