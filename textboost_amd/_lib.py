@@ -66,6 +66,9 @@ _SIGS = {
     "tb_last_hip_error": ([], C.c_char_p),
     "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_gemm_last_config": ([_VP], None),
+    "tb_gemm8_set": ([_I], C.c_int),
+    "tb_gemm8_last": ([_VP], C.c_int),
+    "tb_gemm8_debug": ([_VP], C.c_int),
     "tb_groupnorm_ws_floats": ([_I, _I, _I, _I], _I64),
     "tb_groupnorm_fwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
     "tb_groupnorm_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I, _I, _I, _I, _I, _VP], C.c_int),

@@ -1,0 +1,587 @@
+// 8-wave wide-tile MFMA GEMM / 3x3 convolution for the large-M levels of the UNet (gfx950).
+//
+// Why a second kernel next to gemm.hip: at the 64x64 and 32x32 feature maps (M = 32768 / 8192 output rows) the 4-wave 128x64 tiles
+// of gemm.hip are bound by the operand stream from L2 into the LDS, not by the matrix pipe -- a 128x64x64 step moves 24 KB for
+// 1 MFLOP (43 FLOP/B), and the 3x3 convolution re-streams every weight tap once per 128 pixels (128 FLOP per weight byte).  Here one
+// workgroup of 8 waves owns a 256-pixel x 160-channel (conv) or 128-row x 320-column (Linear) tile:
+//   * conv:   the (R+2) x (W+2) input halo of 256 output pixels is resident in LDS per 64-channel chunk (double buffered, the next
+//             chunk's halo is fetched piecewise under the current chunk's taps) and each weight tap tile is used by 256 pixels:
+//             205 FLOP per byte moved into the LDS, 2.3x less operand traffic than conv_halo_kernel<64>;
+//   * Linear: the tile spans 320 output columns, so for the C = 320 / 640 layers the activation matrix is read once
+//             (not once per 64-column tile) -- these layers are HBM-bound and the re-reads were most of their L2 traffic.
+// Each wave computes a (16 MT) x (16 NT) sub-tile with v_mfma_f32_16x16x32_f16 (the 16-wide shape fits N = 320 = 4 x 80 and
+// 160 = 2 x 80 without padding), accumulators transposed like gemm.hip (a lane owns 4 consecutive output columns of one row).
+// One workgroup per CU (2 waves per SIMD), grid sized to exactly one round of the chip.
+// Operand path: global_load_lds_dwordx4 (no staging registers), 128-byte LDS rows with the 16-byte chunk XOR-swizzled by row & 7
+// (conflict-free for the 16x16x32 fragment reads at ANY row offset, which the shifted halo reads of the conv need).
+#include "gemm_epi.h"
+
+#ifndef G8_PROF
+#define G8_PROF 0  // profiling build: per-phase s_memtime sums of waves 0 and 4 of workgroup 0 into dbg[16..]
+#endif
+#ifndef G8_ABL
+#define G8_ABL 0  // profiling builds (TB_CFLAGS=-DG8_ABL=bits): 1 = no MFMAs, 2 = no in-loop global->LDS loads, 4 = no fragment reads
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int BM, int BN>
+struct G8Epi {
+  static constexpr int LDC = BN + 4;                                           // padded fp32 staging pitch: conflict-free b128 stores
+  static constexpr int PASSES = (BM * LDC * 4 <= 96 * 1024) ? 1 : 2;           // stage the tile in halves when it does not fit
+  static constexpr int PR = BM / PASSES;
+  static constexpr size_t BYTES = (size_t)PR * LDC * 4;
+};
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {  // 32-bit LDS byte address of a __shared__ pointer
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// ds_read_b128 the compiler does not count: completion is awaited with wait_lgkmcnt() + sched_barrier(0) (cdna guide 5.7, rule 18)
+__device__ __forceinline__ f16x8 lds_read16(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int STRIDE>
+__device__ __forceinline__ f16x8 lds_read16_off(uint32_t addr, int j) {  // addr + j * STRIDE as the instruction's immediate offset
+  f16x8 v;
+  switch (j) {
+    case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); break;
+    case 1: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(STRIDE)); break;
+    case 2: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(2 * STRIDE)); break;
+    case 3: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(3 * STRIDE)); break;
+    case 4: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(4 * STRIDE)); break;
+    default: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(5 * STRIDE)); break;
+  }
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt_c() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkmcnt(int n) {  // n is a compile-time constant after unrolling
+  switch (n) {
+    case 0: wait_lgkmcnt_c<0>(); break;
+    case 1: wait_lgkmcnt_c<1>(); break;
+    case 2: wait_lgkmcnt_c<2>(); break;
+    case 3: wait_lgkmcnt_c<3>(); break;
+    case 4: wait_lgkmcnt_c<4>(); break;
+    case 5: wait_lgkmcnt_c<5>(); break;
+    case 6: wait_lgkmcnt_c<6>(); break;
+    case 7: wait_lgkmcnt_c<7>(); break;
+    case 8: wait_lgkmcnt_c<8>(); break;
+    case 9: wait_lgkmcnt_c<9>(); break;
+    case 10: wait_lgkmcnt_c<10>(); break;
+    case 11: wait_lgkmcnt_c<11>(); break;
+    case 12: wait_lgkmcnt_c<12>(); break;
+    case 13: wait_lgkmcnt_c<13>(); break;
+    case 14: wait_lgkmcnt_c<14>(); break;
+    default: wait_lgkmcnt_c<15>(); break;
+  }
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
+}
+
+// WM x WN waves (WM * WN == 8), each wave (16 MT) x (16 NT) outputs; CONV: 3x3 stride-1 halo convolution, else A rows linear
+template <int WM, int WN, int MT, int NT, bool CONV, int NS>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int a_rows8,
+                                                          unsigned long long* dbg) {
+  static_assert(WM * WN == 8, "8 waves");
+#define G8_STAMP(k)                                                                                  \
+  if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                  \
+    dbg[(blockIdx.x ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime();
+  G8_STAMP(0)
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BK = 64;
+  constexpr int TAPS = CONV ? 9 : 1;
+  constexpr int NI_W = BN / 8;               // weight-tile load instructions (8 rows x 128 B each) per step
+  constexpr int WI = (NI_W + 7) / 8;         // ... per wave
+  constexpr int MAXHI = CONV ? 7 : (BM / 64 > 0 ? BM / 64 : 1);  // A-panel load instructions per wave per chunk
+  const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  // LDS: [A panels | W stages]: conv 2 halo panels (a_rows8 pixels x 128 B), Linear NS tile-row panels; NS weight stages of BN rows x 128 B
+  constexpr int NA = CONV ? 2 : NS;
+  f16* const As = reinterpret_cast<f16*>(smem_raw);
+  const int a_elems = a_rows8 * BK;
+  f16* const Ws = As + NA * a_elems;
+
+  const int nwg = tiles_m * tiles_n;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
+  const int64_t n0 = (int64_t)tn * BN;
+
+  // ---- tile geometry
+  const int TW = 1 << wshift, W = p.Wout, H = p.Hout;
+  const int R = BM >> wshift, HC = TW + 2, NH = CONV ? (R + 2) * HC : BM;
+  const int NI_H = a_rows8 >> 3;
+  int64_t m0;
+  int y0 = 0, x0 = 0, bimg = 0;
+  const int hw = H * W;
+  if (CONV) {
+    const int tiles_x = W >> wshift, tiles_img = (H / R) * tiles_x;
+    bimg = tm / tiles_img;
+    const int trem = tm - bimg * tiles_img;
+    y0 = (trem / tiles_x) * R;
+    x0 = (trem % tiles_x) << wshift;
+    m0 = (int64_t)bimg * hw + (int64_t)y0 * W + x0;
+  } else {
+    m0 = (int64_t)tm * BM;
+  }
+
+  const int cp = lane & 7, rl = lane >> 3;
+  // ---- A-panel sources of this lane (fixed across chunks, + 64 halfs per chunk)
+  const f16* h_ptr[MAXHI];
+  int h_step[MAXHI];
+  const f16* zero = g_zero_line;
+#pragma unroll
+  for (int i = 0; i < MAXHI; ++i) {
+    const int j = wave + 8 * i;  // instruction index: rows j*8 .. j*8+7 of the panel
+    const int hr = j * 8 + rl;
+    bool ok;
+    int64_t grow;
+    if (CONV) {
+      const int hy = hr / HC, hx = hr - hy * HC;
+      const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+      ok = j < NI_H && hr < NH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      grow = (int64_t)bimg * hw + (int64_t)yy * W + xx;
+    } else {
+      ok = j < NI_H && m0 + hr < p.M;
+      grow = m0 + hr;
+    }
+    h_ptr[i] = ok ? (const f16*)p.A + grow * p.lda + ((cp ^ (hr & 7)) << 3) : zero;
+    h_step[i] = ok ? BK : 0;
+  }
+  uint32_t w_off[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = (wave + 8 * i) * 8 + rl;
+    const int64_t n = n0 + (row < BN ? row : 0);
+    w_off[i] = (uint32_t)((n * p.ldw + ((cp ^ (row & 7)) << 3)) * 2);
+  }
+  const int kpt = CONV ? p.Cin / BK : 1;                 // k-tiles per tap
+  const int nchunk = CONV ? kpt : (int)(p.K / BK);
+
+  auto stage_a_piece = [&](int c, int i) {  // one load instruction of chunk c's panel
+    const int j = wave + 8 * i;
+    if (j < NI_H) glds16(h_ptr[i] + (int64_t)c * h_step[i], As + (c & 1) * a_elems + j * 8 * BK);
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing (bytes inside a panel / stage): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 s + lq for sub-step s
+  int arow0[MT];  // panel row of this lane's output row for tap offset (0, 0)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ml = (wm * MT + i) * 16 + l15;
+    arow0[i] = CONV ? (ml >> wshift) * HC + (ml & (TW - 1)) : ml;
+  }
+  uint32_t arow128[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) arow128[i] = (uint32_t)arow0[i] * 128;
+  // W rows wn*NT*16 + 16 j + l15: row & 7 == l15 & 7 for every j, so one base + immediates
+  const int brow = wn * NT * 16 + l15;
+  const int boff0 = brow * 128 + ((lq ^ (brow & 7)) << 4), boff1 = boff0 ^ 64;
+
+  // loads this wave issues per weight stage (wave-uniform), for the counted waits below
+  int n_w = 0;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) n_w += (wave + 8 * i < NI_W) ? 1 : 0;
+  int n_a = 0;
+#pragma unroll
+  for (int i = 0; i < MAXHI; ++i) n_a += (wave + 8 * i < NI_H) ? 1 : 0;
+
+  // ---- software pipeline: NS weight stages (and, for Linear, NS activation stages); the loads of step s + NS - 1 are issued in step s,
+  // so NS - 2 steps of loads stay in flight across each barrier (counted vmcnt, raw s_barrier: cdna guide T3/T4).  An L2 round trip under
+  // load is ~1 us, as long as one step of MFMAs: with NS = 2 every step waited for it.
+  static_assert(!CONV || TAPS % NS == 0, "the weight ring slot of a conv step is tap % NS");
+  // The stage loaded during step (c, tap) is the one NS - 1 steps ahead: (lc, ltap).  The tap loop is fully unrolled, so tap, ltap, the
+  // ring slots and the tap's halo offset are compile-time; only the chunk index is a loop variable.  (With a rolled tap loop the LOAD
+  // phase was ~100 instructions, half of them scalar index arithmetic, and took 420 cycles against 340 for the 20 MFMAs of the partner.)
+  constexpr int NSLOT = CONV ? WI + 1 : WI + MAXHI;  // load slots per step: WI weight pieces, then the halo piece (conv) / MAXHI A pieces
+  // dgrad (sign < 0) gathers with flipped offsets: walk the taps in reverse weight order instead, so that the gather offset of unrolled
+  // step t is always (t / 3, t % 3)
+  const int wtap0 = p.sign > 0 ? 0 : TAPS - 1, wtapd = p.sign > 0 ? 1 : -1;
+  auto issue_slot = [&](int k, int lc, int ltap, int lslot, int c, int tap) {
+    if (G8_ABL & 2) return;
+    if (k < WI) {
+      const int j = wave + 8 * k;
+      if (lc < nchunk && j < NI_W) {
+        const char* base = (const char*)p.W + (int64_t)((wtap0 + wtapd * ltap) * kpt + lc) * BK * 2;
+        glds16((const f16*)(base + w_off[k]), Ws + lslot * (BN * BK) + j * 8 * BK);
+      }
+    } else if (CONV) {
+      if (tap >= 0 && tap < MAXHI && c + 1 < nchunk) stage_a_piece(c + 1, tap);
+    } else if (lc < nchunk) {
+      const int i = k - WI, j = wave + 8 * i;
+      if (j < NI_H) glds16(h_ptr[i] + (int64_t)lc * h_step[i], As + lslot * a_elems + j * 8 * BK);
+    }
+  };
+  auto stage_count = [&](int lc, int c, int tap) -> int {  // loads this wave issues in step (c, tap): for the counted wait of the NEXT step
+    int n = lc < nchunk ? n_w + (CONV ? 0 : n_a) : 0;
+    if (CONV && c + 1 < nchunk && tap < MAXHI && wave + 8 * tap < NI_H) ++n;
+    return n;
+  };
+  int cnt_prev = 0;
+  if (CONV) {
+#pragma unroll
+    for (int i = 0; i < MAXHI; ++i) stage_a_piece(0, i);
+  }
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st) {  // stages 0 .. NS-2; the youngest one's loads may stay in flight at step 0 (NS = 3)
+    const int lc = st / TAPS, ltap = st % TAPS;
+    cnt_prev = lc < nchunk ? n_w + (CONV ? 0 : n_a) : 0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+      if (!CONV || k < WI) issue_slot(k, lc, ltap, st % NS, -2, -1);
+  }
+  if (NS == 2) cnt_prev = 0;
+  wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave
+  G8_STAMP(1)
+
+  // ---- main loop: the two waves of each SIMD (wave w and w + 4) run the SAME stream one phase apart.  A step is 2 * HALVES phases
+  // separated by s_barrier: in its LOAD phase a wave issues the fragment reads of one half-step plus its share of the next stage's
+  // global->LDS loads and waits for the reads; in its COMPUTE phase it only issues the half-step's MFMAs.  With the second wave group
+  // shifted by one barrier, every SIMD always has one wave on the matrix pipe and one on the LDS / address / DMA-issue side.
+  // (Measured before: run in lockstep, the load side (0.73 us per step) and the MFMA side (0.68 us) simply added up -- an LDS-DMA
+  // instruction blocks its wave for ~100 issue cycles and the partner wave was doing exactly the same thing at the same time.)
+  constexpr int HALVES = MT >= 4 ? 2 : 1;          // half-steps (32 of the 64 k) per phase pair; small wave tiles do the whole step at once
+  constexpr int SPH = 2 / HALVES;                  // 32-wide sub-steps per half
+  constexpr int SLOTS0 = NS == 2 ? NSLOT : (NSLOT + HALVES - 1) / HALVES;  // load slots issued in the first LOAD phase of a step
+  const int group = wave >> 2;
+#if G8_PROF
+  unsigned long long pf_sum[4] = {0, 0, 0, 0}, pf_t = 0;
+#define G8_PF(k)                                                     \
+  {                                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    if ((k) >= 0) pf_sum[(k) < 0 ? 0 : (k)] += now_ - pf_t;          \
+    pf_t = now_;                                                     \
+  }
+#else
+#define G8_PF(k)
+#endif
+  if (group == 1) asm volatile("s_barrier" ::: "memory");  // phase shift of the second wave group
+  const uint32_t as_addr = lds_addr(As), ws_addr = lds_addr(Ws);
+  int lin_slot = 0, lin_lslot = (NS - 1) % NS;  // Linear: ring slots of the current / the loaded stage (conv: tap % NS, compile-time)
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      constexpr int dummy_ = 0;
+      (void)dummy_;
+      const int ltap = (tap + NS - 1) % TAPS, lc = c + (tap + NS - 1) / TAPS;
+      const int wslot = CONV ? tap % NS : lin_slot, lslot = CONV ? (tap + NS - 1) % NS : lin_lslot;
+      const int cnt_step = NS == 2 ? 0 : stage_count(lc, c, tap);
+      const int shift = CONV ? (tap / 3) * HC + (tap % 3) : 0;
+      const uint32_t ab_addr = as_addr + (CONV ? (c & 1) : wslot) * (a_elems * 2) + shift * 128;
+      const uint32_t wb_addr = ws_addr + wslot * (BN * BK * 2);
+      f16x8 af[2][MT], bf[2][NT];
+      if (G8_ABL & 4) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(bf[s][j]));
+#pragma unroll
+          for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(af[s][i]));
+        }
+      }
+      uint32_t a0[MT];
+      const uint32_t b0 = wb_addr + boff0, b1 = wb_addr + boff1;
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+        // ---- LOAD phase (fragment reads are inline asm: the compiler neither waits for them nor moves them; the wait is below)
+        G8_PF(-1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (h == 0) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a0[i] = ab_addr + arow128[i] + ((lq ^ ((arow0[i] + shift) & 7)) << 4);
+        }
+#pragma unroll
+        for (int q = 0; q < SPH; ++q) {
+          const int s = h * SPH + q;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            if (!(G8_ABL & 4)) bf[s][j] = lds_read16_off<2048>(s ? b1 : b0, j);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            if (!(G8_ABL & 4)) af[s][i] = lds_read16(s ? (a0[i] ^ 64) : a0[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k)
+          if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        // after the step's last issue: everything except THIS step's loads has landed (this wave's part), i.e. the next step's stage
+        if (h == HALVES - 1) wait_vmcnt(cnt_step);
+#if G8_PROF
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G8_PF(0)
+        asm volatile("s_barrier" ::: "memory");
+        G8_PF(1)
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- COMPUTE phase
+#pragma unroll
+        for (int q = 0; q < SPH; ++q) {
+          const int s = h * SPH + q;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)  // transposed: rows of D = output columns (from W), columns of D = output rows (from A)
+              if (!(G8_ABL & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+              else asm volatile("" ::"v"(bf[s][j]), "v"(af[s][i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        G8_PF(2)
+        asm volatile("s_barrier" ::: "memory");
+        G8_PF(3)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!CONV) {
+        lin_slot = lin_slot + 1 == NS ? 0 : lin_slot + 1;
+        lin_lslot = lin_lslot + 1 == NS ? 0 : lin_lslot + 1;
+      }
+    }
+  }
+  if (group == 0) asm volatile("s_barrier" ::: "memory");  // pairs with the second group's last barrier
+#if G8_PROF
+  if (dbg && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256))
+    for (int k = 0; k < 4; ++k) dbg[16 + group * 4 + k] = pf_sum[k];
+#endif
+  G8_STAMP(2)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand buffers: the epilogue reuses the LDS
+
+  // ---- epilogue: accumulators -> padded fp32 tile in LDS -> (row, 8 columns) units with 16-byte global accesses.  A thread keeps ONE
+  // column group (bias loaded once) and walks rows; all residual / auxiliary loads of its units are issued before the arithmetic.
+  using E = G8Epi<BM, BN>;
+  constexpr int LDC = E::LDC, PASSES = E::PASSES, PR = E::PR;
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+  const EpiFlags ef = epi_flags(p);
+  constexpr int UPR = BN / 8;            // 8-column groups per row
+  constexpr int TPR = 512 / UPR;         // rows covered per sweep (threads beyond UPR * TPR idle)
+  constexpr int NU = (PR + TPR - 1) / TPR;
+  const int cg = t % UPR, rslot = t / UPR;
+  const int64_t n = n0 + cg * 8;
+  float b8[8];
+  epi_load_bias8(p, n, b8);
+  // Fast path (every UNet launch that reaches this kernel): fp16 output and residual with 16-byte accesses, activation none / SiLU, and a
+  // row bias (time embedding) that is constant over the tile.  Everything it needs from the descriptor is copied into locals FIRST: read
+  // through `p` inside the unit loop the fields were re-fetched from the kernarg segment (s_load + wait, a few hundred cycles each, ten per
+  // unit) -- the generic epilogue8 path cost 8 us of a 23 us 32768x320x320 launch, against 3 us for the stores themselves.
+  const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + (CONV ? ((int64_t)(R - 1) * W + TW - 1) : BM - 1)) / p.rows_per_group);
+  const bool fast = p.c_dtype == TB_F16 && ef.c_vec && (!p.R || (ef.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
+                    !p.C2 && rb_uniform;
+  if (fast) {
+    const float alpha = p.alpha;
+    const bool silu = p.act == TB_ACT_SILU;
+    f16* const Cg = (f16*)p.C + n;
+    const f16* const Rg = p.R ? (const f16*)p.R + n : nullptr;
+    const int64_t ldc = p.ldc, ldr = p.ldr, Mtot = p.M;
+    if (p.rowbias) {
+      const float* rb = p.rowbias + (m0 / p.rows_per_group) * p.ldrb + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[e] += rb[e];
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int rp = pass * PR;
+      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int row = (wm * MT + i) * 16 + l15 - rp;
+            const int col = (wn * NT + j) * 16 + 4 * lq;
+            *(f32x4_t*)(Cs + row * LDC + col) = acc[i][j];
+          }
+      }
+      auto m_of = [&](int row) -> int64_t {
+        const int r = rp + row;
+        return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r;
+      };
+      f16x8 rv[NU];  // all residual loads of the pass are in flight across the staging barrier
+      if (Rg && rslot < TPR) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const int64_t m = min(m_of(min(rslot + it * TPR, PR - 1)), Mtot - 1);
+          rv[it] = *(const f16x8*)(Rg + m * ldr);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only: no vmcnt drain (residual loads, previous pass's stores)
+      if (pass == 0) { G8_STAMP(5) }
+      if (rslot < TPR) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const int row = rslot + it * TPR;
+          const int64_t m = m_of(min(row, PR - 1));
+          if (row < PR && m < Mtot) {
+            const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = (e < 4 ? c0[e] : c1[e - 4]) * alpha + b8[e];
+              if (Rg) x += (float)rv[it][e];
+              if (silu) x = silu_f(x);
+              o[e] = (f16)x;
+            }
+            *(f16x8*)(Cg + m * ldc) = o;
+          }
+        }
+      }
+      if (pass == 0) { G8_STAMP(6) }
+      if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      G8_STAMP(3 + pass)
+    }
+    return;
+  }
+  // ---- generic path (fp32 output / residual, GELU variants, unaligned rows): rolled loops around the shared epilogue8
+#pragma unroll 1
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int rp = pass * PR;
+    if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = (wm * MT + i) * 16 + l15 - rp;
+          const int col = (wn * NT + j) * 16 + 4 * lq;
+          *(f32x4_t*)(Cs + row * LDC + col) = acc[i][j];
+        }
+    }
+    auto m_of = [&](int row) -> int64_t {
+      const int r = rp + row;
+      return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r;
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (rslot < TPR) {
+#pragma unroll 1
+      for (int it = 0; it < NU; ++it) {
+        const int row = rslot + it * TPR;
+        if (row >= PR) break;
+        const int64_t m = m_of(row);
+        if (m >= p.M) continue;
+        float v[8], r8[8];
+        epi_load_r8(p, ef, m, n, r8);
+        const f16x8 aux = epi_load_aux8(p, ef, m, n);
+        const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = c0[e];
+          v[4 + e] = c1[e];
+        }
+        epilogue8(p, ef, m, n, v, b8, r8, aux);
+      }
+    }
+    if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#undef G8_STAMP
+}
+
+unsigned long long* g8_dbg = nullptr;  // profiling aid (tb_gemm8_debug): s_memtime stamps of the first and the last block
+int g8_enable = 3;   // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers take the wide-tile path (0: A/B runs without it)
+int g8_last[6] = {0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
+
+template <int WM, int WN, int MT, int NT, bool CONV, int NS>
+int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+  const int tiles_m = (int)(d.M / BM), tiles_n = (int)(d.N / BN);
+  int a_rows;
+  if (CONV) {
+    const int TW = 1 << wshift, R = BM >> wshift;
+    a_rows = (R + 2) * (TW + 2);
+  } else {
+    a_rows = BM;
+  }
+  const int a_rows8 = (a_rows + 7) & ~7;
+  if (CONV && (a_rows8 >> 3) > 8 * 7) return 1;  // more panel load instructions than the kernel issues
+  size_t lds = (size_t)(CONV ? 2 : NS) * a_rows8 * 128 + (size_t)NS * BN * 128;
+  if (lds < G8Epi<BM, BN>::BYTES) lds = G8Epi<BM, BN>::BYTES;
+  if (lds > 160 * 1024) return 1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return TB_ELAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), lds, s, d, tiles_m, tiles_n,
+                     wshift, a_rows8, g8_dbg);
+  TB_CHECK_LAUNCH();
+  g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV;
+  return TB_OK;
+}
+
+inline int halo_wshift8(int W) {  // tile width: the largest power of two (16..64) dividing W
+  int sh = 0;
+  while (sh < 6 && !(W & (1 << sh))) ++sh;
+  return sh >= 4 ? sh : 0;
+}
+
+}  // namespace
+
+extern "C" int tb_gemm8_set(int v) {
+  const int old = g8_enable;
+  g8_enable = v;
+  return old;
+}
+extern "C" int tb_gemm8_debug(void* stamps16) {  // device buffer of 16 x u64 (or NULL): s_memtime at start / prologue done / loop done /
+  g8_dbg = (unsigned long long*)stamps16;       // epilogue passes done, for the first ([0..7]) and the last ([8..15]) workgroup
+  return TB_OK;
+}
+extern "C" int tb_gemm8_last(int* out5) {
+  if (out5)
+    for (int i = 0; i < 5; ++i) out5[i] = g8_last[1 + i];
+  return g8_last[0];
+}
+
+// returns TB_OK when the launch was taken, 1 when the shape is not covered (the caller falls back to gemm.hip), < 0 on error
+int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
+  g8_last[0] = 0;
+  if (!g8_enable) return 1;
+  if (d.A2 || d.W2 || d.act == TB_ACT_GEGLU || d.act == TB_ACT_GEGLU_GRAD) return 1;
+  if (d.K % 64 || d.N % 8) return 1;
+  const int64_t lim = (int64_t)1 << 32;
+  if (((d.N - 1) * d.ldw + d.K) * 2 >= lim) return 1;
+  if (d.a_mode == TB_A_CONV3X3) {
+    if (!(g8_enable & 1)) return 1;
+    if (d.stride != 1 || d.upsample || d.transposed || d.shift || d.Hin != d.Hout || d.Win != d.Wout) return 1;
+    const int wshift = halo_wshift8(d.Wout);
+    if (!wshift) return 1;
+    const int TW = 1 << wshift;
+    if (d.Wout % TW) return 1;
+    // 256 pixels x 160 channels (one round of >= 200 blocks), else 256 x 80
+    if (256 % TW == 0 && d.Hout % (256 / TW) == 0 && d.M % 256 == 0) {
+      if (d.N % 160 == 0 && (d.M / 256) * (d.N / 160) >= 200) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift);
+      if (d.N % 80 == 0 && (d.M / 256) * (d.N / 80) >= 200) return launch8<8, 1, 2, 5, true, 3>(d, s, wshift);
+    }
+    return 1;
+  }
+  if (!(g8_enable & 2)) return 1;
+  if (d.N % 320) return 1;
+  if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
+  if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);
+  return 1;
+}

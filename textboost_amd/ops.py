@@ -120,7 +120,10 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
             import ctypes
             cfg = (ctypes.c_int * 5)()
             L.lib().tb_gemm_last_config(cfg)
-            if cfg[2] == 2:
+            c8 = (ctypes.c_int * 5)()
+            if L.lib().tb_gemm8_last(c8):
+                r.name = f"gemm8_kernel<{c8[0]}, {c8[1]}, {c8[2]}, {c8[3]}, {'true' if c8[4] else 'false'}>"
+            elif cfg[2] == 2:
                 r.name = f"conv_halo_kernel<{cfg[1]}>"
             else:
                 r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
