@@ -1,0 +1,39 @@
+"""A/B inside one process: graph-replayed UNet fwd+bwd and whole step under alternating kernel knobs.
+usage: ab_step.py name:variant[,variant..] ...   variants are tb_gemm_set_variant codes or g8:<bits>"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from textboost_amd.workload import build_step
+from textboost_amd import ops, _lib as L
+lib = L.lib()
+step, _ = build_step(batch=8, latent=64, data_seed=1000, world_size=1, device=torch.device("cuda", 0))
+for _ in range(2): step.step_eager()
+def apply(codes):
+    for c in codes:
+        if c.startswith("g8:"): lib.tb_gemm8_set(int(c[3:]))
+        else: lib.tb_gemm_set_variant(int(c))
+configs = []
+for a in sys.argv[1:]:
+    name, codes = a.split(":", 1)
+    configs.append((name, codes.split(",")))
+graphs = {}
+for name, codes in configs:
+    apply(codes)
+    step.step_eager(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step.draw(); step.forward_backward(); step.optimizer_step()
+    graphs[name] = g
+res = {n: [] for n, _ in configs}
+for rnd in range(5):
+    for name, _ in configs:
+        g = graphs[name]
+        g.replay(); torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10): g.replay()
+        e.record(); torch.cuda.synchronize()
+        res[name].append(s.elapsed_time(e) / 10)
+for name, v in res.items():
+    v = sorted(v)
+    print(f"{name:24s} median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f}  ({1000/v[len(v)//2]:.2f} steps/s)")

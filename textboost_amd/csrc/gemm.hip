@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
 template <int BM, int BN, int TM, int TN, int PASSES>
 __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, int64_t m0, int64_t n0,
                                               int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad, int mshift = 30,
-                                              int mstride = 0) {
+                                              int mstride = 0, bool lean_ok = true) {
   // tile row r (0..BM-1) is output row  m0 + (r >> mshift) * mstride + (r & (2^mshift - 1)):  contiguous rows for the GEMMs (defaults),
   // a 2^mshift-pixel-wide block of image rows (mstride = image width) for the LDS-halo conv
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -84,6 +84,17 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
   //  (b) barrier; (c) thread t walks (row, 8-column group) units: bias / residual / activation / stores in 16-byte vectors.
   float* Cs = reinterpret_cast<float*>(smem_raw);
   const EpiFlags ef = epi_flags(p);
+  // lean-path eligibility and the descriptor fields it uses (block-uniform; see the `fast` branch below)
+  const int64_t Mtot = p.M, ldc = p.ldc, ldr = p.ldr;
+  const int64_t m_first = m0, m_last_ = m0 + (int64_t)((BM - 1) >> mshift) * mstride + ((BM - 1) & ((1 << mshift) - 1));
+  const int64_t m_last = m_last_ < Mtot ? m_last_ : Mtot - 1;
+  const bool rb_uniform = !p.rowbias || (m_first / p.rows_per_group == m_last / p.rows_per_group);
+  const bool fast = lean_ok && S == 1 && (p.N % 8 == 0) && ef.c_vec && (!p.R || ef.r_vec) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) && !p.C2 &&
+                    rb_uniform;
+  const float alpha = p.alpha;
+  const bool silu = p.act == TB_ACT_SILU, c_f32 = p.c_dtype == TB_F32, r_f32 = p.r_dtype == TB_F32;
+  void* const Cb = p.C;
+  const void* const Rb = p.R;
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     if (PASSES == 1 || wm == pass) {
@@ -172,6 +183,65 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
 #pragma unroll
             for (int q = 0; q < 2; ++q)
               *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+          }
+        } else if (fast) {
+          // Lean path (every UNet launch and the CLIP out / fc2 projections): the descriptor fields are in locals -- read through `p` in
+          // the unit loop they were re-fetched from the kernarg segment by scalar loads (one dependent wait each, ~10 per unit):
+          // measured on the 8-wave kernel, 8 us of a 23 us 32768x320x320 launch against 3 us for the stores themselves.
+          float b8[8];
+          epi_load_bias8(p, n, b8);
+          if (p.rowbias) {
+            const float* rb = p.rowbias + (m_first / p.rows_per_group) * p.ldrb + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[e] += rb[e];
+          }
+          float r8[NU][8];
+#pragma unroll
+          for (int it = 0; it < NU; ++it) {
+            const int64_t m = m_of(row0 + it * RS);
+            const int64_t mm = m < Mtot ? m : Mtot - 1;
+            if (!Rb) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) r8[it][e] = 0.f;
+            } else if (r_f32) {
+              const f32x4 x0 = *(const f32x4*)((const float*)Rb + mm * ldr + n), x1 = *(const f32x4*)((const float*)Rb + mm * ldr + n + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) r8[it][e] = x0[e], r8[it][4 + e] = x1[e];
+            } else {
+              const f16x8 x = *(const f16x8*)((const f16*)Rb + mm * ldr + n);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) r8[it][e] = (float)x[e];
+            }
+          }
+#pragma unroll
+          for (int it = 0; it < NU; ++it) {
+            const int row = row0 + it * RS;
+            const int64_t m = m_of(row);
+            if (m >= Mtot) continue;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 a = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] = v[e] * alpha + b8[e] + r8[it][e];
+              if (silu) v[e] = silu_f(v[e]);
+            }
+            if (c_f32) {
+              f32x4 o0, o1;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o0[e] = v[e], o1[e] = v[4 + e];
+              *(f32x4*)((float*)Cb + m * ldc + n) = o0;
+              *(f32x4*)((float*)Cb + m * ldc + n + 4) = o1;
+            } else {
+              f16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+              *(f16x8*)((f16*)Cb + m * ldc + n) = o;
+            }
           }
         } else {
           float b8[8];
@@ -514,7 +584,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
 #undef SWZ
 
   if (abl & 4) return;  // profiling: no epilogue
-  tile_epilogue<BM, BN, TM, TN, (BKT == 32 ? 2 : 1)>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad);
+  tile_epilogue<BM, BN, TM, TN, (BKT == 32 ? 2 : 1)>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, 30, 0, !(abl & 8));
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
