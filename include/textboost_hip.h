@@ -210,13 +210,18 @@ int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const 
 enum { TB_ST_LOSS_SCALE = 0, TB_ST_GROWTH_TRACKER = 1, TB_ST_STEP = 2, TB_ST_FOUND_INF = 3, TB_ST_COEF_LORA = 4,
        TB_ST_COEF_EMB = 5, TB_ST_BC1 = 6, TB_ST_BC2 = 7, TB_ST_GRAD_NORM = 8, TB_ST_SUMSQ_LORA = 9, TB_ST_SUMSQ_EMB = 10,
        TB_ST_LOSS_MSE = 11, TB_ST_LOSS_KPL = 12,
-       TB_ST_LR_MULT = 13, /* lr_scheduler (diffusers get_scheduler, :911-916): holds lambda(step) - 1, written by the host, so a zeroed
+       TB_ST_LR_MULT = 13, /* lr_scheduler (diffusers get_scheduler, :911-916): holds lambda(step) - 1, written by the host or by tb_lr_from_table, so a zeroed
                               state means the constant schedule; every group's lr = base lr * (1 + state[13]) */
        TB_ST_COUNT = 16 };
 int tb_sumsq(const float* x, int64_t n, float* out, float* ws64 /* 64 floats scratch */, tb_stream_t stream);
-/* GradScaler unscale/inf-check/update + clip_grad_norm_ coefficient + Adam bias corrections (:1108, :1128-1134) */
+/* GradScaler unscale/inf-check/update + clip_grad_norm_ coefficient + Adam bias corrections (:1108, :1128-1134).  grad_div >= 1 is the
+ * data-parallel world size: the gradient buffers then hold the all-reduce SUM and DDP's division (:919-926) is folded into the unscale
+ * coefficients state[TB_ST_COEF_*] and the reported norm -- no separate pass over the gradients */
 int tb_scaler_update(float* state, float max_norm, float beta1, float beta2, float growth_factor, float backoff_factor,
-                     float growth_interval, int use_scaler, tb_stream_t stream);
+                     float growth_interval, int use_scaler, float grad_div, tb_stream_t stream);
+/* lr_scheduler on the device: state[TB_ST_LR_MULT] = table[min(state[TB_ST_STEP], n - 1)] - 1 (table[k] = lambda(k) of diffusers
+ * get_scheduler, :911-916); indexed by the number of optimizer steps that were not skipped, like accelerate's AcceleratedScheduler */
+int tb_lr_from_table(float* state, const float* table, int n, tb_stream_t stream);
 /* torch.optim.AdamW step on a flat fp32 buffer; g is multiplied by state[coef_slot]; skipped when state says inf */
 int tb_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
              const float* state, int coef_slot, tb_stream_t stream);

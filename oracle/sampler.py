@@ -10,7 +10,8 @@ their published algorithms:
   * `AutoencoderKL.decode`: `post_quant_conv` + `Decoder` (conv_in, UNetMidBlock2D with one single-head attention, 4 UpDecoderBlock2D of
     3 resnets (+ nearest-x2 Upsample2D with a 3x3 conv on the first three), GroupNorm/SiLU/conv_out);
   * `DPMSolverMultistepScheduler` with the defaults `from_config` fills in on top of SD1.x's scheduler config: dpmsolver++, solver_order 2,
-    epsilon prediction, "linspace" timestep spacing, lower_order_final / final sigma zero (Lu et al., DPM-Solver++ 2M, multistep midpoint);
+    prediction type / timestep spacing ("leading", steps_offset 1) inherited from the model's scheduler config, lower_order_final / final
+    sigma zero (Lu et al., DPM-Solver++ 2M, multistep midpoint);
   * the pipeline's classifier-free-guidance loop.
 
 Pinning: "parity unpinned" (no reference tests, diffusers absent).  What IS pinned (tests/test_oracle_sampler.py): the published decoder
@@ -114,7 +115,7 @@ def count_decoder_params(cfg: VAEConfig = VAEConfig()):
 # ----------------------------------------------------------------------------------------------------------------- scheduler
 class DPMSolverPP2M:
     """DPMSolverMultistepScheduler(algorithm_type="dpmsolver++", solver_order=2, solver_type="midpoint", prediction_type="epsilon",
-    timestep_spacing="linspace", lower_order_final=True, final_sigmas_type="zero") on SD's scaled-linear betas.
+    lower_order_final=True, final_sigmas_type="zero") on SD's scaled-linear betas; timestep_spacing / steps_offset / prediction_type as inherited.
 
     Notation of the diffusers implementation: sigma = sqrt((1 - abar) / abar), alpha_t = 1 / sqrt(sigma^2 + 1), sigma_t = sigma * alpha_t,
     lambda = log(alpha_t) - log(sigma_t).  Data prediction x0 = (x - sigma_t * eps) / alpha_t.
@@ -123,15 +124,25 @@ class DPMSolverPP2M:
                     D0 = m0, D1 = (m0 - m1) / r0, r0 = h_prev / h
     The first step and (final sigma zero) the last step are first order."""
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, prediction_type="epsilon",
+                 timestep_spacing="leading", steps_offset=1):
+        """`from_config(pipeline.scheduler.config)` (train_textboost.py:493-495) inherits prediction_type / timestep_spacing / steps_offset
+        from the model's PNDM (SD1.x, SD2.1-base) or DDIM (SD2.1-768) scheduler instance: spacing "leading" (their class default),
+        steps_offset 1 (SD's scheduler_config.json) -- the defaults here."""
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.T = num_train_timesteps
+        self.prediction_type, self.timestep_spacing, self.steps_offset = prediction_type, timestep_spacing, steps_offset
         self.init_noise_sigma = 1.0
 
     def set_timesteps(self, n: int):
         ac = self.alphas_cumprod.double()
-        ts = torch.linspace(0, self.T - 1, n + 1, dtype=torch.float64).round().flip(0)[:-1].long()
+        if self.timestep_spacing == "linspace":
+            ts = torch.linspace(0, self.T - 1, n + 1, dtype=torch.float64).round().flip(0)[:-1].long()
+        elif self.timestep_spacing == "leading":   # DPMSolverMultistepScheduler.set_timesteps: step_ratio = last_timestep // (n + 1)
+            ts = (torch.arange(0, n + 1, dtype=torch.float64) * (self.T // (n + 1))).round().flip(0)[:-1].long() + self.steps_offset
+        else:                                       # "trailing"
+            ts = torch.arange(self.T, 0, -self.T / n, dtype=torch.float64).round().long() - 1
         sig_all = ((1 - ac) / ac).sqrt()
         self.timesteps = ts
         self.sigmas = torch.cat([sig_all[ts], torch.zeros(1, dtype=torch.float64)])  # final_sigmas_type = "zero"
@@ -170,7 +181,10 @@ class DPMSolverPP2M:
     def step(self, eps, sample):
         i = self.step_index
         a_t, s_t = self._alpha_sigma(self.sigmas[i])
-        m0 = (sample - float(s_t) * eps) / float(a_t)
+        if self.prediction_type == "epsilon":
+            m0 = (sample - float(s_t) * eps) / float(a_t)
+        else:  # v_prediction: x0 = alpha_t x - sigma_t v
+            m0 = float(a_t) * sample - float(s_t) * eps
         a, b, c = self.coefficients(i)
         out = a * sample + b * m0 + (c * self.m_prev if c != 0.0 else 0.0)
         self.m_prev = m0
@@ -178,10 +192,10 @@ class DPMSolverPP2M:
         return out
 
 
-def sample_latents(unet: Callable, cond, uncond, latents, steps=25, guidance=7.5):
+def sample_latents(unet: Callable, cond, uncond, latents, steps=25, guidance=7.5, **scheduler_kwargs):
     """The denoising loop of StableDiffusionPipeline.__call__ with classifier-free guidance (do_classifier_free_guidance = g > 1):
     eps = eps_uncond + g (eps_cond - eps_uncond); `unet(x[2B], t[2B], ehs[2B])` -> eps[2B]."""
-    sch = DPMSolverPP2M()
+    sch = DPMSolverPP2M(**scheduler_kwargs)
     ts = sch.set_timesteps(steps)
     x = latents * sch.init_noise_sigma
     B = x.shape[0]

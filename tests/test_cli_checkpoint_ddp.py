@@ -80,15 +80,38 @@ def test_output_layout_matches_reference_readers(tmp_path):
     assert sorted(d for d in os.listdir(out) if d.startswith("checkpoint")) == ["checkpoint-150"]
 
 
+FLAT_L, FLAT_R, FLAT_D, FLAT_K = 12, 4, 768, 18       # SD1.5 / CLIP-L flat gradient layout [grad_A | grad_B | added rows]: 0.94 MB
+N_LORA = 2 * FLAT_L * 3 * FLAT_R * FLAT_D
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
-    from textboost_amd.trainer import average_gradients, shard_indices
+    from textboost_amd.trainer import average_gradients, shard_indices, sum_gradients
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.arange(10, dtype=torch.float32) * (rank + 1)
     average_gradients(g, world)
     idx = shard_indices(1, 4, 3, rank, world) + shard_indices(5, 2, 1, rank, world)
-    q.put((rank, g.tolist(), idx))
+    # --- the step's exchange on the real flat layout with rank-dependent gradients:
+    # reference (DDP, train_textboost.py:919-926 + :1109-1117): dense embedding gradient averaged over ranks, THEN rows < first_added zeroed;
+    # here: only the added rows travel, summed, and 1/W is folded into the unscale coefficient (tb_scaler_update grad_div)
+    gen = torch.Generator().manual_seed(100 + rank)
+    first_added, window = 16, 16 + FLAT_K                     # a window of the table: 16 original rows + the 18 added ones
+    lora = torch.randn(N_LORA, generator=gen)
+    dense_emb = torch.randn(window, FLAT_D, generator=gen)    # this rank's (scaled) embedding gradient, dense like autograd makes it
+    ref_lora, ref_emb = lora.clone(), dense_emb.clone()
+    dist.all_reduce(ref_lora); dist.all_reduce(ref_emb)
+    ref_lora /= world; ref_emb /= world
+    ref_emb[:first_added] = 0                                 # :1114-1117
+    flat = torch.cat([lora, dense_emb[first_added:].reshape(-1)])
+    sum_gradients(flat, world)
+    scale = 65536.0
+    coef = 1.0 / (scale * world)                              # what scaler_update_kernel writes to state[TB_ST_COEF_EMB]
+    err_l = ((flat[:N_LORA] * coef - ref_lora / scale).abs().max() / (ref_lora / scale).abs().max()).item()
+    err_e = ((flat[N_LORA:].view(FLAT_K, FLAT_D) * coef - ref_emb[first_added:] / scale).abs().max()).item() / (ref_emb.abs().max().item() / scale)
+    norm_ours = (flat[:N_LORA].double().pow(2).sum().sqrt() * coef).item()      # state[TB_ST_GRAD_NORM]
+    norm_ref = (ref_lora.double() / scale).norm().item()
+    q.put((rank, g.tolist(), idx, err_l, err_e, abs(norm_ours - norm_ref) / norm_ref, flat.numel() * 4))
     dist.destroy_process_group()
 
 
@@ -108,3 +131,24 @@ def test_gloo_world2_gradient_average_and_sharding():
     assert res[0][1] == expect and res[1][1] == expect            # mean over ranks, identical on every rank
     assert res[0][2][:4] == [0, 0, 0, 0] and res[1][2][:4] == [0, 0, 0, 0]   # one image: every shard non-empty
     assert res[0][2][4:] == [4, 0] and res[1][2][4:] == [1, 2]   # it=1: rank0 -> samples 4,5%5 ; rank1 -> 6%5, 7%5
+    for r in res:  # masking and averaging commute; the folded 1/W equals DDP's mean (fp32 rounding only)
+        assert r[3] < 1e-6 and r[4] < 1e-6 and r[5] < 1e-6, r[3:]
+        assert r[6] == (N_LORA + FLAT_K * FLAT_D) * 4 == 940032   # the 0.94 MB bucket of DESIGN.md section 5
+
+
+def test_sharding_for_eight_ranks_never_leaves_a_rank_empty():
+    """8 ranks, 1..5 instance images (the DreamBooth one-shot case hangs in the reference): every rank gets data, every image
+    is used, and the per-epoch multiset is the tiled key list."""
+    from textboost_amd.data import IndexStream
+    from textboost_amd.trainer import shard_indices
+    for n in (1, 3, 5, 8, 11):
+        taken = []
+        for rank in range(8):
+            st = IndexStream(n, seed=42, rank=rank, world=8)
+            got = st.take(4)
+            assert len(got) == 4 and all(0 <= i < n for i in got)
+            taken.append(got[0])
+        assert set(taken) == set(range(min(n, 8))) or n > 8       # first pass: ranks cover the (tiled) key list
+        for it in range(3):
+            cover = [i for rank in range(8) for i in shard_indices(n, 2, it, rank, 8)]
+            assert len(cover) == 16 and set(cover) == set(range(n)) or n > 16

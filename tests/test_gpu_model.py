@@ -243,9 +243,10 @@ def test_cli_end_to_end_writes_reference_layout(tmp_path):
     assert d["<dog>"].shape == (768,) and torch.isfinite(d["<dog>"]).all()
 
 
-def test_collective_two_graph_path_with_one_rank_group():
-    """The N>1 code path (eager RCCL all-reduce between two HIP graphs) exercised with a 1-rank nccl group: results must equal
-    the single-graph path bit for bit (mean over one rank is the identity)."""
+def test_collective_paths_with_one_rank_group():
+    """The N>1 code paths -- the RCCL all-reduce captured INSIDE the one step graph, and the fallback of an eager all-reduce between two
+    graphs -- exercised with a 1-rank nccl group: both must equal the no-collective single-graph path bit for bit (the sum over one
+    rank is the identity, and grad_div = 1)."""
     import os
     import torch.distributed as dist
     from oracle import train_step as ts
@@ -258,20 +259,22 @@ def test_collective_two_graph_path_with_one_rank_group():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True
     try:
-        for force in (False, True):
+        for force, single in ((False, True), (True, True), (True, False)):
             st_ref, step, added = build_step(B, hw, D)
             step.force_dist = force
             g = torch.Generator().manual_seed(8)
             step.input_ids.copy_(ts.synthetic_ids(B, added, g)); step.prior_ids.copy_(ts.synthetic_ids(B, added, g, prior=True))
             step.x0.copy_(torch.randn(B, 4, hw, hw, generator=g)); step.noise.copy_(torch.randn(B, 4, hw, hw, generator=g))
             step.timesteps.copy_(torch.randint(0, 1000, (B,), generator=g))
-            step.capture(warmup=1)
-            assert len(step.graph) == (2 if force else 1)
+            step.capture(warmup=1, single_graph=single)
+            assert step.graph_mode == ("single" if not force else ("single+rccl" if single else "two+eager-rccl")), step.graph_mode
+            assert len(step.graph) == (1 if single else 2)
             step.replay(); step.replay()
             torch.cuda.synchronize()
             outs.append((step.te.lora_A.clone(), step.te.lora_B.clone(), step.te.token_table[49408:].clone()))
-        for a, b in zip(*outs):
-            torch.testing.assert_close(a, b, rtol=0, atol=0)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                torch.testing.assert_close(a, b, rtol=0, atol=0)
     finally:
         if created:
             dist.destroy_process_group()
@@ -320,3 +323,92 @@ def test_v_prediction_target_matches_oracle():
     torch.testing.assert_close(step.velocity.cpu(), ts.get_velocity(x0, noise, t, st_ref.acp), rtol=1e-5, atol=1e-6)
     assert sc["found_inf"] == 0.0 and abs(sc["loss_mse"] - out["mse"]) < 2e-2 * abs(out["mse"]) + 1e-4, (sc, out["mse"])
     assert rel_err(step.te.grad_added / 65536.0, out["g_emb_added"]) < 5e-2
+
+
+def _fill_inputs(step, added, B, hw, seed, rows=None):
+    """deterministic step inputs; `rows` selects a slice of a larger global batch (data-parallel shard)"""
+    from oracle import train_step as ts
+    g = torch.Generator().manual_seed(seed)
+    n = B if rows is None else rows[1]
+    ids, pids = ts.synthetic_ids(n, added, g), ts.synthetic_ids(n, added, g, prior=True)
+    x0, noise = torch.randn(n, 4, hw, hw, generator=g), torch.randn(n, 4, hw, hw, generator=g)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    sl = slice(0, n) if rows is None else slice(rows[0], rows[0] + B)
+    step.input_ids.copy_(ids[sl]); step.prior_ids.copy_(pids[sl]); step.x0.copy_(x0[sl]); step.noise.copy_(noise[sl])
+    step.timesteps.copy_(t[sl])
+
+
+def test_data_parallel_equivalence_of_the_gradient_exchange():
+    """DDP semantics without a second GPU: two ranks with per-rank batch B (each normalising its losses over its OWN B samples, as the
+    reference does under DDP) whose flat gradients are SUMMED and divided by W -- folded into the unscale coefficient by
+    tb_scaler_update(grad_div=W) -- must give the gradient, the clip norm and the parameter update of ONE step over the 2B samples."""
+    from textboost_amd import _lib as L
+    B, hw, D, W = 2, 16, 64, 2
+    _, big, added = build_step(W * B, hw, D)
+    _fill_inputs(big, added, W * B, hw, seed=21)
+    big.forward_backward()
+    shards = []
+    for r in range(W):
+        _, st, _ = build_step(B, hw, D)
+        _fill_inputs(st, added, B, hw, seed=21, rows=(r * B, W * B))
+        st.forward_backward()
+        shards.append(st)
+    summed = shards[0].flat_grad + shards[1].flat_grad
+    e = rel_err(summed / W, big.flat_grad)
+    assert e < 5e-3, f"mean of the shard gradients vs the 2B-sample gradient: rel err {e}"
+    # the step as rank 0 runs it: summed buffer + world = 2, against the big step with world = 1
+    r0 = shards[0]
+    r0.flat_grad.copy_(summed)
+    r0.world = W
+    r0.optimizer_step(); big.optimizer_step()
+    torch.cuda.synchronize()
+    s0, sb = r0.scalars(), big.scalars()
+    assert s0["found_inf"] == 0.0 and abs(s0["grad_norm"] - sb["grad_norm"]) < 5e-3 * sb["grad_norm"], (s0, sb)
+    assert abs(r0.state[L.ST_COEF_EMB].item() * W - big.state[L.ST_COEF_EMB].item()) < 1e-12
+    # Adam's first step is lr * sign(g) (+ decay): identical up to sign flips of near-zero gradients -> compare the update direction
+    dA0, dAb = r0.m_lora, big.m_lora
+    assert rel_err(dA0, dAb) < 5e-3
+    torch.testing.assert_close(r0.te.token_table[:49408], big.te.token_table[:49408], rtol=0, atol=0)   # decay-only rows: bit-equal
+
+
+def test_resume_from_checkpoint_is_bit_exact_under_an_lr_schedule(tmp_path):
+    """with a non-constant --lr_scheduler the never-updated embedding rows decay by a different factor every step; the
+    checkpoint therefore carries the whole table.  save after 2 steps -> fresh trainer -> load -> 2 more steps == 4 uninterrupted steps."""
+    from textboost_amd import checkpoint as ckpt
+    from textboost_amd.trainer import lr_lambda
+    B, hw, D = 2, 16, 64
+    lam = lr_lambda("linear", 2, 6)
+    table = [lam(k) for k in range(7)]
+
+    def fresh():
+        _, st, added = build_step(B, hw, D)
+        st.set_lr_table(table)
+        return st, added
+
+    ref, added = fresh()
+    for it in range(4):
+        _fill_inputs(ref, added, B, hw, seed=30 + it)
+        ref.step_eager()
+    a, _ = fresh()
+    for it in range(2):
+        _fill_inputs(a, added, B, hw, seed=30 + it)
+        a.step_eager()
+    ckpt.save_trainer_state(a, str(tmp_path / "checkpoint-2"))
+    b, _ = fresh()
+    ckpt.load_trainer_state(b, str(tmp_path / "checkpoint-2"))
+    for it in range(2, 4):
+        _fill_inputs(b, added, B, hw, seed=30 + it)
+        b.step_eager()
+    torch.cuda.synchronize()
+    assert ref.scalars()["opt_steps"] == 4.0 and b.scalars()["opt_steps"] == 4.0
+    for x, y in ((ref.te.token_table, b.te.token_table), (ref.te.lora_A, b.te.lora_A), (ref.te.lora_B, b.te.lora_B),
+                 (ref.m_lora, b.m_lora), (ref.v_emb, b.v_emb), (ref.state, b.state)):
+        torch.testing.assert_close(x, y, rtol=0, atol=0)
+    # and the schedule really was non-constant: rows below first_added decayed by prod(1 - emb_lr * wd * lambda(k)), k = 0..3
+    hp = ref.hp
+    expect = 1.0
+    for k in range(4):
+        expect *= 1.0 - hp.emb_lr * hp.wd * table[k]
+    _, untouched, _ = build_step(B, hw, D)
+    ratio = (ref.te.token_table[100] / untouched.te.token_table[100]).mean().item()
+    assert abs(ratio - expect) < 1e-6 and abs(ratio - (1.0 - hp.emb_lr * hp.wd) ** 4) > 1e-7

@@ -24,11 +24,14 @@ def _decoder_pair(cfg_oracle, geo, seed, B, h, w):
     return ref, HipVAEDecoder(geo, {k: v.to(dev) for k, v in sd.items()}, B, h, w, device=dev)
 
 
-def test_dpm_step_kernel_follows_the_oracle_scheduler():
+@pytest.mark.parametrize("spacing,offset,pred", [("leading", 1, "epsilon"), ("linspace", 0, "epsilon"), ("trailing", 0, "v_prediction"),
+                                                 ("leading", 1, "v_prediction")])
+def test_dpm_step_kernel_follows_the_oracle_scheduler(spacing, offset, pred):
     from oracle.sampler import DPMSolverPP2M as Ref
     from textboost_amd import ops
     from textboost_amd.sampler import DPMSolverPP2M
-    ref, sch = Ref(), DPMSolverPP2M()
+    ref = Ref(prediction_type=pred, timestep_spacing=spacing, steps_offset=offset)
+    sch = DPMSolverPP2M.from_config({"prediction_type": pred, "timestep_spacing": spacing, "steps_offset": offset})
     ts = ref.set_timesteps(25)
     assert sch.set_timesteps(25) == ts.tolist()
     torch.manual_seed(0)
@@ -39,7 +42,7 @@ def test_dpm_step_kernel_follows_the_oracle_scheduler():
         e = (torch.randn(2 * B, n) * 0.8).half()
         eps = e[:B].float() + g * (e[B:].float() - e[:B].float())
         x_ref = ref.step(eps, x_ref)
-        a_t, s_t = sch.alpha_sigma(sch.sigmas[i])
+        a_t, s_t = sch.data_prediction_scalars(i)
         ops.dpm_step(x, e.to(dev), m_prev, x2, n, B, g, a_t, s_t, *sch.coefficients(i))
         assert rel_err(x, x_ref) < 1e-5, i
         # x2 = fp16 of the update (the compiler may round the exact fma once, v_fma_mixlo_f16, instead of fp32 -> fp16: <= 1 fp16 ulp on ties)

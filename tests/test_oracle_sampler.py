@@ -21,8 +21,35 @@ def test_decoder_shapes_and_postprocess():
     torch.testing.assert_close(img, (m(z / 0.18215) / 2 + 0.5).clamp(0, 1))
 
 
+def test_dpm_solver_timestep_spacings():
+    """DPMSolverMultistepScheduler.set_timesteps [3P, diffusers 0.29]: `from_config` on SD's PNDM / DDIM scheduler instance inherits
+    timestep_spacing "leading" + steps_offset 1 -> 951, 913, ..., 39 for 25 steps (step_ratio = 1000 // 26)."""
+    ts = DPMSolverPP2M().set_timesteps(25)
+    assert ts.tolist() == [951 - 38 * i for i in range(25)]
+    ts = DPMSolverPP2M(timestep_spacing="trailing").set_timesteps(25)
+    assert ts.tolist() == [999 - 40 * i for i in range(25)]
+    ts = DPMSolverPP2M(timestep_spacing="leading", steps_offset=0).set_timesteps(10)
+    assert ts.tolist() == [900 - 90 * i for i in range(10)]
+
+
+def test_dpm_solver_v_prediction_point_mass_exactness():
+    """SD2.1-768: the model predicts v = alpha_t eps - sigma_t x0; with the exact v of a point mass the solver must stay on x_t."""
+    sch = DPMSolverPP2M(prediction_type="v_prediction")
+    sch.set_timesteps(20)
+    c = torch.tensor([0.7, -1.3, 2.0]); e = torch.tensor([0.3, 0.1, -0.9])
+    a0, s0 = sch._alpha_sigma(sch.sigmas[0])
+    x = (a0 * c + s0 * e).float()
+    for i in range(20):
+        a_t, s_t = sch._alpha_sigma(sch.sigmas[i])
+        eps = (x - float(a_t) * c) / float(s_t)
+        v = float(a_t) * eps - float(s_t) * c
+        x = sch.step(v, x)
+        a_n, s_n = sch._alpha_sigma(sch.sigmas[i + 1])
+        torch.testing.assert_close(x, (a_n * c + s_n * e).float(), rtol=1e-4, atol=1e-4)
+
+
 def test_dpm_solver_timesteps_and_point_mass_exactness():
-    sch = DPMSolverPP2M()
+    sch = DPMSolverPP2M(timestep_spacing="linspace")
     ts = sch.set_timesteps(25)
     assert ts[0].item() == 999 and len(ts) == 25 and (ts[:-1] > ts[1:]).all() and ts[-1].item() == 40
     assert sch.sigmas[-1] == 0 and abs(sch.sigmas[0].item() - 14.6146) < 1e-3        # sqrt((1 - abar_999) / abar_999)

@@ -84,10 +84,15 @@ def save_trainer_state(step_obj, ckpt_dir: str):
     os.makedirs(ckpt_dir, exist_ok=True)
     model = dict(lora_state_dict(te))
     model["token_embedding.added_rows"] = te.token_table[te.first_added:].detach().float().cpu().contiguous()
+    # the WHOLE table, as accelerate's model.safetensors holds it: rows below first_added carry the accumulated decoupled weight decay of
+    # every optimizer step so far, which depends on the lr schedule and on skipped steps -- saving them makes resume bit-exact
+    model["text_model.embeddings.token_embedding.weight"] = te.token_table.detach().float().cpu().contiguous()
     save_file(model, os.path.join(ckpt_dir, "model.safetensors"))
     torch.save({"m_lora": step_obj.m_lora.cpu(), "v_lora": step_obj.v_lora.cpu(), "m_emb": step_obj.m_emb.cpu(),
                 "v_emb": step_obj.v_emb.cpu(), "state": step_obj.state.cpu(),
-                "orig_rows_decay_steps": float(step_obj.state[2].item())}, os.path.join(ckpt_dir, "optimizer.bin"))
+                "orig_rows_decay_steps": float(step_obj.state[2].item()),
+                "lr_table": step_obj.lr_table.cpu() if getattr(step_obj, "lr_table", None) is not None else None},
+               os.path.join(ckpt_dir, "optimizer.bin"))
     torch.save({"last_epoch": float(step_obj.state[2].item()), "lr_multiplier": 1.0 + float(step_obj.state[13].item())},
                os.path.join(ckpt_dir, "scheduler.bin"))  # lambda(step) of --lr_scheduler is recomputed from the step index on resume
     torch.save({"scale": float(step_obj.state[0].item()), "growth_tracker": float(step_obj.state[1].item()), "growth_factor": 2.0,
@@ -103,13 +108,18 @@ def load_trainer_state(step_obj, ckpt_dir: str):
     te = step_obj.te
     model = load_file(os.path.join(ckpt_dir, "model.safetensors"))
     load_lora_state_dict(te, model)
-    te.token_table[te.first_added:].copy_(model["token_embedding.added_rows"])
     opt = torch.load(os.path.join(ckpt_dir, "optimizer.bin"))
     for k in ("m_lora", "v_lora", "m_emb", "v_emb", "state"):
         getattr(step_obj, k).copy_(opt[k])
-    # rows below first_added only ever see the decoupled decay: re-apply it for the steps already taken
-    n = opt["orig_rows_decay_steps"]
-    te.token_table[: te.first_added].mul_((1.0 - step_obj.hp.emb_lr * step_obj.hp.wd) ** n)
+    full = model.get("text_model.embeddings.token_embedding.weight")
+    if full is not None:
+        te.token_table.copy_(full)
+    else:  # checkpoints written before the full table was saved: constant-lr approximation of the decay of the never-updated rows
+        te.token_table[te.first_added:].copy_(model["token_embedding.added_rows"])
+        n = opt["orig_rows_decay_steps"]
+        te.token_table[: te.first_added].mul_((1.0 - step_obj.hp.emb_lr * step_obj.hp.wd) ** n)
+    if "lr_table" in opt and opt["lr_table"] is not None and getattr(step_obj, "lr_table", None) is None:
+        step_obj.set_lr_table(opt["lr_table"].tolist())
     with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "rb") as f:
         rs = pickle.load(f)
     if "random_state" in rs:

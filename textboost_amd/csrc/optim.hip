@@ -29,11 +29,12 @@ __global__ void sumsq_final_kernel(const float* __restrict__ part, int nb, float
 
 // one thread: derive every per-step scalar from the two gradient sums of squares
 __global__ void scaler_update_kernel(float* __restrict__ st, float max_norm, float beta1, float beta2, float growth_factor,
-                                     float backoff_factor, float growth_interval, int use_scaler) {
+                                     float backoff_factor, float growth_interval, int use_scaler, float grad_div) {
   const float scale = st[TB_ST_LOSS_SCALE];
   const float ss_lora = st[TB_ST_SUMSQ_LORA], ss_emb = st[TB_ST_SUMSQ_EMB];
   const bool found_inf = !(isfinite(ss_lora) && isfinite(ss_emb));
-  const float inv = 1.f / scale;
+  // grad_div = data-parallel world size: the gradient buffer holds the all-reduce SUM, DDP's mean is folded into the coefficients here
+  const float inv = 1.f / (scale * grad_div);
   const float total = sqrtf(ss_lora) * inv;                      // norm of the unscaled LoRA grads
   const float clip = fminf(max_norm / (total + 1e-6f), 1.f);    // torch clip_grad_norm_
   st[TB_ST_FOUND_INF] = found_inf ? 1.f : 0.f;
@@ -60,6 +61,14 @@ __global__ void scaler_update_kernel(float* __restrict__ st, float max_norm, flo
       }
     }
   }
+}
+
+// lr_scheduler.step() (diffusers get_scheduler LambdaLR, :911-916, :1135) on the device: the multiplier of the NEXT optimizer step is
+// lambda(k), k = optimizer steps that were NOT skipped so far (accelerate's AcceleratedScheduler does not advance on an overflow step)
+__global__ void lr_from_table_kernel(float* __restrict__ st, const float* __restrict__ table, int n) {
+  int k = (int)st[TB_ST_STEP];
+  k = k < 0 ? 0 : (k >= n ? n - 1 : k);
+  st[TB_ST_LR_MULT] = table[k] - 1.f;
 }
 
 // torch.optim.AdamW (decoupled decay first, then Adam update with bias corrections), grads pre-multiplied by coef
@@ -134,11 +143,19 @@ extern "C" int tb_sumsq(const float* x, int64_t n, float* out, float* ws64, tb_s
 }
 
 extern "C" int tb_scaler_update(float* state, float max_norm, float beta1, float beta2, float growth_factor, float backoff_factor,
-                                float growth_interval, int use_scaler, tb_stream_t stream) {
+                                float growth_interval, int use_scaler, float grad_div, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!state) return TB_EINVAL;
+  if (!state || !(grad_div >= 1.f)) return TB_EINVAL;
   hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, max_norm, beta1, beta2, growth_factor,
-                     backoff_factor, growth_interval, use_scaler);
+                     backoff_factor, growth_interval, use_scaler, grad_div);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_lr_from_table(float* state, const float* table, int n, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!state || !table || n <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(lr_from_table_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, table, n);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

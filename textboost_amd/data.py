@@ -106,8 +106,10 @@ class IndexStream:
         if self.shuffle:
             np.random.default_rng(self.seed + self.epoch).shuffle(self.keys)
         keys = self.keys
-        rem = len(keys) % self.world
-        idx = keys if rem == 0 else np.concatenate((keys, keys[:self.world - rem]))
+        # pad to a multiple of the world size by TILING the keys (the reference's Wrapper pads with keys[:world - rem], which with fewer
+        # images than ranks leaves ranks without data -- its one-image multi-GPU runs hang): every rank gets >= 1 index
+        n = -(-len(keys) // self.world) * self.world
+        idx = keys if n == len(keys) else np.resize(keys, n)
         self._queue = [int(i) for i in idx[self.rank::self.world]]
         self.epoch += 1
 

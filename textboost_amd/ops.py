@@ -353,9 +353,13 @@ def sumsq(x, out):
 
 
 def scaler_update(state, max_norm=1.0, beta1=0.9, beta2=0.999, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
-                  use_scaler=True):
+                  use_scaler=True, grad_div=1.0):
     L.check(L.lib().tb_scaler_update(L.ptr(state), max_norm, beta1, beta2, growth_factor, backoff_factor, float(growth_interval),
-                                     int(use_scaler), L.stream()), "tb_scaler_update")
+                                     int(use_scaler), float(grad_div), L.stream()), "tb_scaler_update")
+
+
+def lr_from_table(state, table):
+    L.check(L.lib().tb_lr_from_table(L.ptr(state), L.ptr(table), table.numel(), L.stream()), "tb_lr_from_table")
 
 
 def adamw(p, g, m, v, lr, state, coef_slot, beta1=0.9, beta2=0.999, eps=1e-8, wd=1e-2):

@@ -20,18 +20,49 @@ from . import ops
 
 
 class DPMSolverPP2M:
-    """diffusers DPMSolverMultistepScheduler as `from_config` builds it on SD's scheduler config: algorithm_type "dpmsolver++",
-    solver_order 2, solver_type "midpoint", epsilon prediction, timestep_spacing "linspace", final sigma zero (last step first order).
-    sigma = sqrt((1 - abar) / abar); alpha_t = 1 / sqrt(sigma^2 + 1); sigma_t = sigma alpha_t; lambda = log(alpha_t / sigma_t)."""
+    """diffusers DPMSolverMultistepScheduler as `from_config(pipeline.scheduler.config)` builds it (train_textboost.py:493-495): algorithm
+    "dpmsolver++", solver_order 2, solver_type "midpoint", final sigma zero (last step first order), and -- inherited from the model's own
+    scheduler config (`<model>/scheduler/scheduler_config.json`; a PNDMScheduler for SD1.x / SD2.1-base, a DDIMScheduler for SD2.1-768) --
+    the betas, `prediction_type` ("epsilon" | "v_prediction"), `timestep_spacing` and `steps_offset`.  PNDM / DDIM instances carry
+    timestep_spacing "leading" (their class default) and SD's files say steps_offset 1, so that is the default when no file exists.
+    sigma = sqrt((1 - abar) / abar); alpha_t = 1 / sqrt(sigma^2 + 1); sigma_t = sigma alpha_t; lambda = log(alpha_t / sigma_t).
+    [3P: diffusers 0.29 is not installed here; the three spacings are restated from its set_timesteps.]"""
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
-        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="epsilon", timestep_spacing="leading", steps_offset=1):
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"beta_schedule {beta_schedule}")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type {prediction_type}")
+        if timestep_spacing not in ("linspace", "leading", "trailing"):
+            raise ValueError(f"timestep_spacing {timestep_spacing}")
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double()
         self.T = num_train_timesteps
+        self.prediction_type, self.timestep_spacing, self.steps_offset = prediction_type, timestep_spacing, int(steps_offset)
         self.init_noise_sigma = 1.0
 
+    @classmethod
+    def from_config(cls, cfg: Optional[dict]):
+        """cfg = the parsed scheduler_config.json of the model (None: SD1.x's values)."""
+        cfg = cfg or {}
+        return cls(num_train_timesteps=cfg.get("num_train_timesteps", 1000), beta_start=cfg.get("beta_start", 0.00085),
+                   beta_end=cfg.get("beta_end", 0.012), beta_schedule=cfg.get("beta_schedule", "scaled_linear"),
+                   prediction_type=cfg.get("prediction_type", "epsilon"), timestep_spacing=cfg.get("timestep_spacing", "leading"),
+                   steps_offset=cfg.get("steps_offset", 1))
+
     def set_timesteps(self, n: int) -> List[int]:
-        ts = torch.linspace(0, self.T - 1, n + 1, dtype=torch.float64).round().flip(0)[:-1].long()
+        T = self.T  # last_timestep (lambda_min_clipped = -inf: nothing is clipped)
+        if self.timestep_spacing == "linspace":
+            ts = torch.linspace(0, T - 1, n + 1, dtype=torch.float64).round().flip(0)[:-1].long()
+        elif self.timestep_spacing == "leading":
+            ratio = T // (n + 1)
+            ts = (torch.arange(0, n + 1, dtype=torch.float64) * ratio).round().flip(0)[:-1].long() + self.steps_offset
+        else:  # trailing
+            ts = torch.arange(T, 0, -T / n, dtype=torch.float64).round().long() - 1
         ac = self.alphas_cumprod[ts]
         self.timesteps = ts.tolist()
         self.sigmas = ((1 - ac) / ac).sqrt().tolist() + [0.0]
@@ -42,8 +73,14 @@ class DPMSolverPP2M:
         a = 1.0 / math.sqrt(sigma * sigma + 1.0)
         return a, sigma * a
 
+    def data_prediction_scalars(self, i: int) -> Tuple[float, float]:
+        """(a, s) such that the data prediction of step i is m0 = (x - s * model_output) / a -- the form `tb_dpm_step` evaluates.
+        epsilon: m0 = (x - sigma_t eps) / alpha_t;  v_prediction: m0 = alpha_t x - sigma_t v = (x - (sigma_t / alpha_t) v) / (1 / alpha_t)."""
+        a_t, s_t = self.alpha_sigma(self.sigmas[i])
+        return (a_t, s_t) if self.prediction_type == "epsilon" else (1.0 / a_t, s_t / a_t)
+
     def coefficients(self, i: int) -> Tuple[float, float, float]:
-        """x_next = ca x + cb m0 + cc m_prev  for step i  (m = data prediction (x - sigma_t eps) / alpha_t)."""
+        """x_next = ca x + cb m0 + cc m_prev  for step i  (m = data prediction)."""
         a0, st0 = self.alpha_sigma(self.sigmas[i])
         a1, st1 = self.alpha_sigma(self.sigmas[i + 1])
         if i == len(self.timesteps) - 1:      # sigma_next = 0: exp(-h) = 0, alpha_next = 1
@@ -63,11 +100,11 @@ class HipSampler:
     """`sample(cond_ehs, uncond_ehs, latents=None) -> images [B,3,8h,8w] in [0,1]`.  `unet` must be built for batch 2B (guidance runs the
     unconditional and conditional rows in one call, as the pipeline does), `vae_decoder` for batch B."""
 
-    def __init__(self, unet, vae_decoder, steps: int = 25, guidance: float = 7.5):
+    def __init__(self, unet, vae_decoder, steps: int = 25, guidance: float = 7.5, scheduler_config: Optional[dict] = None):
         assert unet.B == 2 * vae_decoder.B and unet.H == vae_decoder.h and unet.W == vae_decoder.w
         self.unet, self.vae, self.steps, self.g = unet, vae_decoder, steps, guidance
         self.B = vae_decoder.B
-        self.sch = DPMSolverPP2M()
+        self.sch = DPMSolverPP2M.from_config(scheduler_config)
         self.timesteps = self.sch.set_timesteps(steps)
         dev = unet.dev
         B, h, w = self.B, unet.H, unet.W
@@ -90,7 +127,7 @@ class HipSampler:
         n = self.x[0].numel()
         for i in range(self.steps):
             eps2 = self.unet.forward(self.x2, self.t_dev[i], ehs)
-            a_t, s_t = sch.alpha_sigma(sch.sigmas[i])
+            a_t, s_t = sch.data_prediction_scalars(i)
             ca, cb, cc = sch.coefficients(i)
             ops.dpm_step(self.x, eps2, self.m_prev, self.x2, n, B, self.g, a_t, s_t, ca, cb, cc)
         return self.x

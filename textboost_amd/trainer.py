@@ -47,13 +47,22 @@ def alphas_cumprod(T=1000, beta_start=0.00085, beta_end=0.012, device="cuda"):
     return torch.cumprod(1.0 - betas, dim=0).to(device)
 
 
-def average_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = False):
-    """sum over ranks, then 1/W: what DDP's bucketed all-reduce does to every trainable gradient.  Row masking (:1114-1117)
-    commutes with the average, so reducing only the k added rows + the LoRA tensors is identical to the reference's dense
-    reduction.  Backend-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
+def sum_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = False):
+    """The exchange step of DDP (:919-926): ONE all-reduce (SUM) of the flat trainable-gradient buffer.  DDP's division by the world size
+    is not a pass over the buffer: `tb_scaler_update(grad_div=W)` folds it into the unscale / clip coefficients the optimizer kernels
+    multiply the gradients with.  Row masking (:1114-1117) commutes with the mean, so reducing only the k added rows + the LoRA tensors is
+    identical to the reference's dense reduction.  Backend-agnostic (RCCL on GPUs -- capturable in a HIP graph --, gloo in the CPU tests)."""
     if world_size > 1 or force:
         import torch.distributed as dist
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return flat_grad
+
+
+def average_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = False):
+    """sum over ranks, then 1/W: the gradient DDP hands to the optimizer (reference semantics; host-side helper for tests / tools -- the
+    step itself uses `sum_gradients` + the folded division)."""
+    sum_gradients(flat_grad, world_size, force)
+    if world_size > 1 or force:
         flat_grad.mul_(1.0 / world_size)
     return flat_grad
 
@@ -174,6 +183,7 @@ class TextBoostStep:
         self.external_noise = False
         self.side = torch.cuda.Stream(device=device) if self.kpl else None
         self.vae = None  # attach_vae(): the step then starts from pixels (:1027-1037) instead of latents
+        self.lr_table = None  # set_lr_table(): lambda(k) of --lr_scheduler on the device, indexed by the successful-step count
 
     def attach_vae(self, vae):
         """Run `vae.encode(pixel_values).latent_dist.sample() * scaling_factor` (:1036-1037) at the top of every step, inside the
@@ -254,10 +264,15 @@ class TextBoostStep:
         optimizer step is its base lr times `mult`.  A one-element device write outside the captured graph (no sync)."""
         self.state[L.ST_LR_MULT:L.ST_LR_MULT + 1].fill_(float(mult) - 1.0)  # the slot holds lambda - 1 (zeroed state = constant)
 
+    def set_lr_table(self, lambdas):
+        """diffusers get_scheduler + accelerate's AcceleratedScheduler (:911-916, :1135): lambdas[k] multiplies every group's base lr on the
+        optimizer step that follows k successful (non-skipped) ones.  Looked up on the device inside the captured step: no host sync."""
+        self.lr_table = torch.tensor([float(x) for x in lambdas], dtype=torch.float32, device=self.dev)
+
     def all_reduce(self):
         """DDP gradient averaging (:919-926): ONE RCCL all-reduce of the flat trainable-gradient buffer
         (k*D + 2*L*3*r*D floats ~ 0.94 MB at SD1.5, r=4) instead of the reference's dense 152.7 MB."""
-        average_gradients(self.flat_grad, self.world, force=self.force_dist)
+        sum_gradients(self.flat_grad, self.world, force=self.force_dist)
 
     def optimizer_step(self):
         hp, te, st = self.hp, self.te, self.state
@@ -265,7 +280,10 @@ class TextBoostStep:
         ops.sumsq(self.flat_grad[: self.n_lora], st[L.ST_SUMSQ_LORA:])
         if te.n_added:
             ops.sumsq(self.flat_grad[self.n_lora:], st[L.ST_SUMSQ_EMB:])
-        ops.scaler_update(st, hp.max_grad_norm, hp.beta1, hp.beta2, 2.0, 0.5, hp.growth_interval, hp.use_grad_scaler)
+        if self.lr_table is not None:
+            ops.lr_from_table(st, self.lr_table)
+        ops.scaler_update(st, hp.max_grad_norm, hp.beta1, hp.beta2, 2.0, 0.5, hp.growth_interval, hp.use_grad_scaler,
+                          grad_div=float(self.world))
         ops.adamw(self.flat_lora, self.flat_grad[: self.n_lora], self.m_lora, self.v_lora, hp.lr, st, L.ST_COEF_LORA, hp.beta1,
                   hp.beta2, hp.eps, hp.wd)
         # group 0: the whole embedding matrix is an AdamW param; rows < first_added have zero grad (:1114-1117) and
@@ -285,7 +303,7 @@ class TextBoostStep:
         self.optimizer_step()
 
     # ------------------------------------------------------------------ HIP graph
-    def capture(self, warmup: int = 2):
+    def capture(self, warmup: int = 2, single_graph: bool = True):
         """Capture draw + forward/backward [+ all-reduce] + optimizer into one HIP graph (static shapes, no host sync).
         Warm-up iterations run eagerly first (they DO update parameters, like any training step)."""
         s = torch.cuda.Stream()
@@ -299,8 +317,25 @@ class TextBoostStep:
         G = lambda: torch.cuda.CUDAGraph()  # noqa: E731
         cap = lambda g, **kw: torch.cuda.graph(g, capture_error_mode="thread_local", **kw)  # noqa: E731  (thread_local: the RCCL watchdog
         #                                                                      thread keeps polling its events while this thread captures)
+        if dist and single_graph:
+            # RCCL collectives are stream-ordered and capturable: the whole step, exchange included, is ONE graph (no host involvement
+            # between backward and optimizer).  Falls back to two graphs around an eager all-reduce if the capture is refused.
+            try:
+                g = G()
+                with cap(g):
+                    self.draw()
+                    self.forward_backward()
+                    self.all_reduce()
+                    self.optimizer_step()
+                self.graph = (g,)
+                self.graph_mode = "single+rccl"
+                return
+            except Exception as e:  # noqa: BLE001 -- capture refused by this RCCL / torch build
+                import warnings
+                warnings.warn(f"RCCL all-reduce could not be captured in the step graph ({e}); using two graphs around an eager collective")
+                torch.cuda.synchronize()
         if dist:
-            # keep the collective outside the graphs: two graphs around one eager RCCL call
+            # the collective outside the graphs: two graphs around one eager RCCL call
             self.g1, self.g2 = G(), G()
             with cap(self.g1):
                 self.draw()
@@ -308,6 +343,7 @@ class TextBoostStep:
             with cap(self.g2):
                 self.optimizer_step()
             self.graph = (self.g1, self.g2)
+            self.graph_mode = "two+eager-rccl"
         else:
             g = G()
             with cap(g):
@@ -315,6 +351,7 @@ class TextBoostStep:
                 self.forward_backward()
                 self.optimizer_step()
             self.graph = (g,)
+            self.graph_mode = "single"
 
     def replay(self):
         if self.graph is None:

@@ -145,8 +145,13 @@ def main(args):
         if dsd is None:
             logger.warning("no local VAE weights under %s: seeded random-init SD VAE decoder shapes are used for validation images", mdir)
             dsd = models.random_state_dict(vae_decoder_shapes(VAEGeometry()), 1237, device=dev)
+        # `scheduler_class.from_config(pipeline.scheduler.config)` (:493-495): betas, prediction_type, timestep_spacing ("leading": the PNDM /
+        # DDIM instance's value) and steps_offset are inherited from the model's own scheduler
+        scfg_path = os.path.join(mdir, "scheduler", "scheduler_config.json")
+        scfg = json.load(open(scfg_path)) if os.path.exists(scfg_path) else None
         sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),
-                             HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5)
+                             HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5,
+                             scheduler_config=scfg)
         del dsd
     del usd
     teacher = HipTextEncoder(clip_geo, csd, B, mode="half", device=dev) if args.kpl_weight > 0 else None
@@ -212,6 +217,11 @@ def main(args):
     if args.mixed_precision != "fp16":
         raise NotImplementedError("only --mixed_precision fp16 is built (the reference driver's setting, run_textboost_db.py:150): fp16 UNet / "
                                   "teacher, autocast text encoder with fp32 masters, dynamic loss scaling; got %r" % (args.mixed_precision,))
+    if getattr(args, "concepts_list", None):
+        raise NotImplementedError("--concepts_list (multi-concept training, :661-694) is not built: a run would silently train only "
+                                  "--placeholder_token")
+    if getattr(args, "tokenizer_name", None):
+        raise NotImplementedError("--tokenizer_name is not built: the tokenizer is read from <pretrained_model_name_or_path>/tokenizer")
     if args.gradient_accumulation_steps != 1:
         raise NotImplementedError("--gradient_accumulation_steps > 1 is not built (one optimizer step per batch, as the reference's driver runs)")
     if args.text_encoder_use_attention_mask:
@@ -307,6 +317,11 @@ def main(args):
         if path == "latest":
             dirs = sorted([d for d in os.listdir(args.output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
             path = os.path.join(args.output_dir, dirs[-1]) if dirs else None
+        else:  # :961-981: only the basename counts, the checkpoint is looked up under --output_dir
+            path = os.path.join(args.output_dir, os.path.basename(path.rstrip("/")))
+            if not os.path.isdir(path):
+                print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")  # :968-972
+                path = None
         if path:
             ckpt.load_trainer_state(step, path)  # also restores the torch / numpy / `random` generator states the feeder draws from
             first_step = int(os.path.basename(path.rstrip("/")).split("-")[1])
@@ -323,8 +338,10 @@ def main(args):
         """log_validation (:453-531): 25 DPM-Solver++ steps, guidance 7.5, num_validation_images per prompt -> validation_{step}.jpg"""
         import copy
         from textboost_amd.sampler import make_image_grid
-        te_val = copy.copy(te)       # same parameters (incl. the LoRA operands packed by the last step), private activation buffers
+        te_val = copy.copy(te)       # same parameters, private activation buffers
         te_val._bufs = {}
+        te_val.pack_lora()           # the fp16 LoRA operands were packed BEFORE the last optimizer step: refresh them from the fp32 masters,
+        #                              so that the images show the weights the checkpoint saves
         ids = val_ids.to(dev).repeat_interleave(args.num_validation_images, dim=0)
         empty = torch.full_like(ids, EOS)
         empty[:, 0] = BOS
@@ -341,6 +358,10 @@ def main(args):
     lam = lr_lambda(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps, lr_init=hp.lr)  # :911-916
     if feeder is None:
         next_batch(0)  # the device feeder consumes random draws per batch: there the graph is captured over the (zero) input buffers
+    if args.lr_scheduler != "constant":
+        # lambda(k) for k = 0 .. max_train_steps lives on the device and is indexed by the count of SUCCESSFUL optimizer steps, like
+        # accelerate's AcceleratedScheduler, which does not advance on an overflow-skipped step
+        step.set_lr_table([lam(k) for k in range(args.max_train_steps + 1)])
     step.capture(warmup=0)
     if feeder is not None:  # batch k+1 is produced on a side stream while step k runs (augment.PrefetchFeeder)
         from textboost_amd.augment import PrefetchFeeder
@@ -349,8 +370,6 @@ def main(args):
     t0 = time.perf_counter()
     for it in range(first_step, args.max_train_steps):
         next_batch(it)
-        if args.lr_scheduler != "constant":
-            step.set_lr_multiplier(lam(it))
         step.replay()
         done = it + 1
         if is_main and (done % 50 == 0 or done == args.max_train_steps):  # scalars are read off the hot loop
