@@ -46,7 +46,7 @@ def roofline_leg(step):
         a[3] += byts
     # the roofline object is about ONE kernel symbol: candidates are the single-kernel records (the attention-backward and
     # GroupNorm entry points launch 2-3 kernels per call and are listed in the table only)
-    single = {k: v for k, v in agg.items() if k.startswith(("gemm_kernel<", "conv_halo_kernel<")) or k == "attn_fwd_kernel"}
+    single = {k: v for k, v in agg.items() if k.startswith(("gemm_kernel<", "conv_halo_kernel<", "gemm8_kernel<")) or k == "attn_fwd_kernel"}
     dom = max(single.items(), key=lambda kv: kv[1][1])
     name, (n, t, fl, _) = dom
     table = {k: {"launches": v[0], "total_ms": round(v[1] * 1e3, 3), "avg_us": round(v[1] / v[0] * 1e6, 2),
@@ -70,19 +70,23 @@ def roofline_leg(step):
     # HBM traffic per launch of that kernel: PMC passes cannot run inside this process (separate rocprofv3 --pmc runs, FETCH_SIZE and
     # WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md); the committed summary of those passes (scratch/pmc_bench.sh ->
     # scratch/pmc_traffic.py) is quoted when it has the same kernel symbol
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if name in pmc:
-            roof["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
-    except (OSError, ValueError, KeyError):
-        pass
+    for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
+            if name in pmc:
+                roof["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
+                roof["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
+                break
+        except (OSError, ValueError, KeyError):
+            pass
+    roof["table"] = table  # per kernel family of the same eager step: launches, total ms, avg us, TFLOP/s or GB/s (algorithmic)
     return roof, table
 
 
-def cpu_baseline_leg(max_seconds=60.0):
+def cpu_baseline_leg(max_seconds=150.0, n_steps=6):
     """oracle/ (the eager-PyTorch fp32 restatement of the reference step) timed on this box's host cores:
-    bounded sample = optimizer steps at B=1 (1/8 of the metric's batch) of the same SD1.5 shapes; value is scaled to B=8."""
+    bounded sample = `n_steps` optimizer steps at B=1 (1/8 of the metric's batch) of the same SD1.5 shapes, the first one discarded as
+    warm-up, MEDIAN of the rest; value is scaled to B=8."""
     import torch.nn as nn
     from oracle import train_step as ts
     from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
@@ -117,7 +121,7 @@ def cpu_baseline_leg(max_seconds=60.0):
     g = torch.Generator().manual_seed(1)
     times = []
     t_begin = time.perf_counter()
-    for i in range(3):
+    for i in range(n_steps):
         ids = synthetic_ids(1, added, g)
         pids = synthetic_ids(1, added, g, prior=True)
         x0, noise = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g)
@@ -125,9 +129,10 @@ def cpu_baseline_leg(max_seconds=60.0):
         t0 = time.perf_counter()
         st.step(x0, noise, t, ids, pids)
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_begin > max_seconds / 2:
+        if time.perf_counter() - t_begin > max_seconds and len(times) >= 3:
             break
-    best = min(times)
+    timed = sorted(times[1:]) if len(times) > 1 else times
+    best = timed[len(timed) // 2]  # median of the steps after the warm-up one
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -137,8 +142,9 @@ def cpu_baseline_leg(max_seconds=60.0):
     except OSError:
         pass
     return {"value": round(1.0 / (8.0 * best), 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} optimizer step(s) at B=1 (1/8 of the metric's batch), SD1.5 UNet + CLIP-L r=4 + KPL, 64x64 latents, "
-                      f"fp32 eager oracle; best {best:.2f} s/step scaled to B=8", "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count()}
+            "sample": f"{len(times)} optimizer steps at B=1 (1/8 of the metric's batch), SD1.5 UNet + CLIP-L r=4 + KPL, 64x64 latents, "
+                      f"fp32 eager oracle; first step discarded, median of the other {len(timed)} = {best:.2f} s/step, scaled to B=8 "
+                      f"(all: {', '.join(f'{x:.2f}' for x in times)} s)", "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count()}
 
 
 def make_feeder(step, args, rank):
@@ -182,7 +188,7 @@ def make_feeder(step, args, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (BASELINE.json configs[1] is a 250-step run)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE.json metric: 8)")
     ap.add_argument("--latent", type=int, default=None, help="latent side (default 64 = 512^2 images; 96 for --workload sd21)")

@@ -1,7 +1,16 @@
-"""Full-size (BASELINE.json shapes) parity on the GPU box: SD1.5 UNet (859.5M) and CLIP-L with random-init weights at B=1 / B=2
-against the CPU oracle (~20 s of host time), plus size-independent properties at the metric's B=8."""
+"""Full-size (BASELINE.json shapes) parity on the GPU box: SD1.5 / SD2.x UNets and CLIP-L / OpenCLIP-H text encoders with random-init
+weights against the fp32 CPU oracle -- B=1..2 forward + backward, the UNet forward at the metric's B=8, the SD2.x UNet at 96x96 latents --
+plus size-independent properties of the whole step at B=8.
+
+Tolerances (fp16 MFMA operands / fp32 accumulation vs the fp32 oracle; every check is whole-tensor rel-L2 AND max-abs relative to the
+largest reference magnitude AND the worst per-channel rel-L2): UNet prediction 3e-3 / 4e-3 / 4e-3 (measured ~1.1e-3), d(encoder hidden
+states) 5e-3 / 6e-3 / 3e-2 (measured ~2e-3; single low-energy channels reach 1.4e-2), encoder hidden states 2e-3 (measured 8e-4),
+LoRA / embedding gradients 3e-3 / 4e-3 / 5e-3 (measured ~1e-3).  A faithful fp16 module (oracle/fp16_mode.py) sits 4.9e-3 / 9.5e-3 from
+the same fp32 oracle (tests/test_gpu_model.py): the kernels here are inside the reference's own fp16 rounding noise."""
 import pytest
 import torch
+
+from parity import parity
 
 pytestmark = pytest.mark.gpu
 dev = "cuda"
@@ -33,11 +42,9 @@ def test_sd15_unet_full_size_forward_backward_vs_oracle():
     pred_ref.backward(dpred)
     hip = HipUNet(models.SD15_UNET, {k: v.to(dev) for k, v in sd.items()}, B, 64, 64, device=dev)
     pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, 768).to(dev).contiguous())
-    e = rel_err(pred, pred_ref)
-    assert e < 2e-2, f"SD1.5 UNet forward rel-L2 {e}"
+    parity("SD1.5 UNet pred", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
     d_ehs = hip.backward(dpred.to(dev))
-    e = rel_err(d_ehs.view(B, 77, 768), ehs.grad)
-    assert e < 5e-2, f"SD1.5 UNet d_ehs rel-L2 {e}"
+    parity("SD1.5 UNet d_ehs", d_ehs.view(B, 77, 768), ehs.grad, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
 
 
 def test_clip_l_full_size_forward_backward_vs_oracle():
@@ -70,13 +77,14 @@ def test_clip_l_full_size_forward_backward_vs_oracle():
     (out_ref * R).sum().backward()
     hip.pack_lora()
     out = hip.forward(ids.to(dev))
-    assert rel_err(out.view(B, 77, 768), out_ref) < 5e-3
+    parity("CLIP-L hidden states", out.view(B, 77, 768), out_ref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-2)
     hip.zero_grad()
     hip.backward(R.view(B * 77, 768).to(dev).contiguous())
     gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
     gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
-    assert rel_err(hip.grad_A, gA) < 3e-2 and rel_err(hip.grad_B, gB) < 3e-2
-    assert rel_err(hip.grad_added, ref.token_embedding.weight.grad[added]) < 3e-2
+    parity("CLIP-L grad lora_A", hip.grad_A, gA, rel=3e-3, maxabs=4e-3, ch_dim=0, ch_rel=5e-3)
+    parity("CLIP-L grad lora_B", hip.grad_B, gB, rel=3e-3, maxabs=4e-3, ch_dim=0, ch_rel=5e-3)
+    parity("CLIP-L grad added rows", hip.grad_added, ref.token_embedding.weight.grad[added], rel=3e-3, maxabs=4e-3, ch_dim=0, ch_rel=5e-3)
 
 
 def test_metric_config_properties_at_batch_8():
@@ -136,11 +144,9 @@ def test_sd21_unet_full_size_forward_backward_vs_oracle():
     pred_ref.backward(dpred)
     hip = HipUNet(models.SD21_UNET, {k: v.to(dev) for k, v in sd.items()}, B, 64, 64, device=dev)
     pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, 1024).to(dev).contiguous())
-    e = rel_err(pred, pred_ref)
-    assert e < 2e-2, f"SD2.1 UNet forward rel-L2 {e}"
+    parity("SD2.1 UNet pred", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
     d_ehs = hip.backward(dpred.to(dev))
-    e = rel_err(d_ehs.view(B, 77, 1024), ehs.grad)
-    assert e < 5e-2, f"SD2.1 UNet d_ehs rel-L2 {e}"
+    parity("SD2.1 UNet d_ehs", d_ehs.view(B, 77, 1024), ehs.grad, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
 
 
 def test_openclip_h_full_size_forward_backward_vs_oracle():
@@ -175,10 +181,64 @@ def test_openclip_h_full_size_forward_backward_vs_oracle():
     (out_ref * R).sum().backward()
     hip.pack_lora()
     out = hip.forward(ids.to(dev))
-    assert rel_err(out.view(B, 77, 1024), out_ref) < 5e-3
+    parity("OpenCLIP-H hidden states", out.view(B, 77, 1024), out_ref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-2)
     hip.zero_grad()
     hip.backward(R.view(B * 77, 1024).to(dev).contiguous())
     gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
     gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
-    assert rel_err(hip.grad_A, gA) < 3e-2 and rel_err(hip.grad_B, gB) < 3e-2
-    assert rel_err(hip.grad_added, ref.token_embedding.weight.grad[added]) < 3e-2
+    parity("OpenCLIP-H grad lora_A", hip.grad_A, gA, rel=3e-3, maxabs=4e-3, ch_dim=0, ch_rel=5e-3)
+    parity("OpenCLIP-H grad lora_B", hip.grad_B, gB, rel=3e-3, maxabs=4e-3, ch_dim=0, ch_rel=5e-3)
+    parity("OpenCLIP-H grad added rows", hip.grad_added, ref.token_embedding.weight.grad[added], rel=3e-3, maxabs=4e-3, ch_dim=0, ch_rel=5e-3)
+
+
+def _full_unet_pair(geo, cfg, seed, B, hw):
+    from oracle.unet_sd import UNet2DCondition
+    from textboost_amd import models
+    from textboost_amd.unet import HipUNet
+    sd = models.random_state_dict(models.unet_shapes(geo), seed, device="cpu")
+    sd = {k: v.half().float() for k, v in sd.items()}
+    with torch.device("meta"):
+        ref = UNet2DCondition(cfg)
+    ref = ref.to_empty(device="cpu")
+    ref.load_state_dict(sd)
+    hip = HipUNet(geo, {k: v.to(dev) for k, v in sd.items()}, B, hw, hw, device=dev)
+    return ref, hip
+
+
+def test_sd15_unet_forward_at_the_metric_batch_vs_oracle():
+    """BASELINE.json configs[1]: the UNet forward at the metric's per-GPU batch 8, 64x64 latents, against the fp32 oracle (every sample with
+    its own timestep) -- the same launches (tile shapes, wide-tile kernels, split-K decisions) as the benchmarked step."""
+    from oracle.unet_sd import UNetConfig
+    from textboost_amd import models
+    B = 8
+    ref, hip = _full_unet_pair(models.SD15_UNET, UNetConfig.sd15(), 81, B, 64)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 4, 64, 64, generator=g).half().float()
+    t = torch.tensor([999, 0, 611, 250, 17, 801, 500, 333])
+    ehs = torch.randn(B, 77, 768, generator=g).half().float()
+    with torch.no_grad():
+        pred_ref = ref(x, t, ehs)
+    pred = hip.forward(x.half().to(dev), t.to(dev), ehs.half().view(B * 77, 768).to(dev).contiguous())
+    parity("SD1.5 UNet pred, B=8", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
+    for b in range(B):  # no sample may hide behind the others
+        parity(f"  sample {b} (t={int(t[b])})", pred[b], pred_ref[b], rel=3e-3, maxabs=5e-3, verbose=False)
+
+
+def test_sd21_unet_at_96x96_latents_vs_oracle():
+    """BASELINE.json configs[3] / SURVEY 8(d) config 4: the SD2.x UNet at 768^2 images = 96x96 latents (9216-token self-attention, 96-wide
+    halo tiles), forward + dgrad backward, B=1."""
+    from oracle.unet_sd import UNetConfig
+    from textboost_amd import models
+    B, hw = 1, 96
+    ref, hip = _full_unet_pair(models.SD21_UNET, UNetConfig.sd21(), 82, B, hw)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 4, hw, hw, generator=g).half().float()
+    t = torch.tensor([402])
+    ehs = torch.randn(B, 77, 1024, generator=g).half().float().requires_grad_(True)
+    pred_ref = ref(x, t, ehs)
+    dpred = torch.randn(B, 4, hw, hw, generator=g)
+    pred_ref.backward(dpred)
+    pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, 1024).to(dev).contiguous())
+    parity("SD2.1 UNet pred @96x96", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
+    d_ehs = hip.backward(dpred.to(dev))
+    parity("SD2.1 UNet d_ehs @96x96", d_ehs.view(B, 77, 1024), ehs.grad, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)

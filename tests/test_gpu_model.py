@@ -1,9 +1,17 @@
 """GPU parity of the HIP executors (UNet fwd + dgrad bwd, text encoder fwd/bwd, full optimizer step) against the
-CPU oracle (oracle/) on small configs the oracle finishes in seconds. Tolerances are fp16-mixed-precision vs fp32."""
+CPU oracle (oracle/) on small configs the oracle finishes in seconds.
+
+Tolerances (fp16 MFMA operands, fp32 accumulation / statistics, vs the fp32 oracle; every check = rel-L2 AND max-abs / max|ref| AND, where
+a channel axis exists, the worst per-channel rel-L2 -- tests/parity.py): UNet prediction 3e-3 / 4e-3 / 4e-3 (measured 1.2e-3), d(ehs)
+5e-3 / 6e-3 / 2e-2 (1.9e-3), trainable-encoder hidden states 5e-4 (3.5e-5), encoder-only LoRA gradients 1.5e-3 (4.5e-4), whole-step
+gradients through the UNet 4e-3 / 6e-3 (1-1.7e-3), fp16 teacher 1.5e-3 (3.7e-4).  The reference's own fp16 UNet, emulated by rounding every
+operator result of the oracle to fp16 (oracle/fp16_mode.py), is 4.9e-3 / 9.5e-3 away from the fp32 oracle: asserted as the noise floor."""
 import copy
 
 import pytest
 import torch
+
+from parity import parity
 
 pytestmark = pytest.mark.gpu
 dev = "cuda"
@@ -52,11 +60,19 @@ def test_unet_forward_and_dgrad_backward_match_oracle():
     dpred = torch.randn(B, 4, hw, hw, generator=g)
     pred_ref.backward(dpred)
     pred = hip.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, D).to(dev).contiguous())
-    e = rel_err(pred, pred_ref)
-    assert e < 1.5e-2, f"unet forward rel err {e}"
+    e_pred = parity("tiny UNet pred", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)[0]
     d_ehs = hip.backward(dpred.to(dev))
-    e = rel_err(d_ehs.view(B, 77, D), ehs.grad)
-    assert e < 3e-2, f"unet d_ehs rel err {e}"
+    e_dehs = parity("tiny UNet d_ehs", d_ehs.view(B, 77, D), ehs.grad, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=2e-2)[0]
+    # the noise floor of the REFERENCE's own fp16 UNet: the same oracle with every operator result rounded to fp16 (oracle/fp16_mode.py).
+    # The HIP kernels (fp32 epilogues, fused norm / activation / residual) must sit inside it.
+    from oracle.fp16_mode import fp16_rounding
+    ehs16 = ehs.detach().clone().requires_grad_(True)
+    with fp16_rounding():
+        p16 = ref(x, t, ehs16)
+        p16.backward(dpred.half().float())
+    f_pred, f_dehs = rel_err(p16, pred_ref), rel_err(ehs16.grad, ehs.grad)
+    print(f"[parity] fp16-faithful oracle vs fp32 oracle: pred {f_pred:.3e}, d_ehs {f_dehs:.3e}")
+    assert 2e-3 < f_pred < 2e-2 and e_pred < f_pred and e_dehs < f_dehs
 
 
 def make_encoders(B=2, D=64, r=4, n_added=3, seed=0, act="quick_gelu"):
@@ -115,20 +131,20 @@ def test_text_encoder_forward_backward_match_oracle():
     (out_ref * R).sum().backward()
     hip.pack_lora()
     out = hip.forward(ids.to(dev), slot=0)
-    assert rel_err(out.view(B, 77, D), out_ref) < 5e-3
+    parity("tiny encoder hidden states", out.view(B, 77, D), out_ref, rel=5e-4, maxabs=1e-3, ch_dim=2, ch_rel=2e-3)
     assert torch.equal(out.view(B, 77, D)[1].cpu(), null)
     hip.zero_grad()
     hip.backward(R.view(B * 77, D).to(dev).contiguous(), slot=0)
     gA, gB = lora_grads_from_oracle(student)
-    assert rel_err(hip.grad_A, gA) < 2e-2, rel_err(hip.grad_A, gA)
-    assert rel_err(hip.grad_B, gB) < 2e-2, rel_err(hip.grad_B, gB)
-    assert rel_err(hip.grad_added, student.token_embedding.weight.grad[added]) < 2e-2
+    parity("tiny encoder grad lora_A", hip.grad_A, gA, rel=1.5e-3, maxabs=2e-3, ch_dim=0, ch_rel=2e-3)
+    parity("tiny encoder grad lora_B", hip.grad_B, gB, rel=1.5e-3, maxabs=2e-3, ch_dim=0, ch_rel=2e-3)
+    parity("tiny encoder grad added rows", hip.grad_added, student.token_embedding.weight.grad[added], rel=1e-3, maxabs=1.5e-3)
     # the fp16 teacher
     pids = ts.synthetic_ids(B, added, g, prior=True)   # the teacher never sees added tokens (49408-row table, :650)
     with torch.no_grad():
         t_ref = teacher(pids)
     t_out = hip_teacher.forward(pids.to(dev), slot=0)
-    assert rel_err(t_out.view(B, 77, D), t_ref) < 1e-2
+    parity("tiny fp16 teacher hidden states", t_out.view(B, 77, D), t_ref, rel=1.5e-3, maxabs=5e-3)
 
 
 def build_step(B=2, hw=16, D=64, use_scaler=True, sd2=False, kpl_type="cos", mixing=None, prediction_type="epsilon"):
@@ -174,12 +190,9 @@ def test_full_step_matches_oracle_elementwise():
         # oracle g_lora are post-clip; compare directions through the clip coefficient
         clip = min(1.0, 1.0 / (out["lora_grad_norm"] + 1e-6))
         assert abs(sc["grad_norm"] - out["lora_grad_norm"]) < 5e-2 * out["lora_grad_norm"]
-        e = rel_err(step.te.grad_A * inv * clip, gA)
-        assert e < 5e-2, f"step {it} grad_A rel err {e}"
-        e = rel_err(step.te.grad_B * inv * clip, gB)
-        assert e < 5e-2, f"step {it} grad_B rel err {e}"
-        e = rel_err(step.te.grad_added * inv, out["g_emb_added"])
-        assert e < 5e-2, f"step {it} grad_added rel err {e}"
+        parity(f"step {it} grad lora_A", step.te.grad_A * inv * clip, gA, rel=4e-3, maxabs=6e-3)
+        parity(f"step {it} grad lora_B", step.te.grad_B * inv * clip, gB, rel=4e-3, maxabs=6e-3)
+        parity(f"step {it} grad added rows", step.te.grad_added * inv, out["g_emb_added"], rel=4e-3, maxabs=6e-3)
         # parameters after the update, elementwise
         w = step.te.token_table.cpu()
         wr = te_ref.token_embedding.weight.detach()
@@ -301,10 +314,10 @@ def test_sd2_style_models_kpl_mse_and_mixing_match_oracle():
     clip = min(1.0, 1.0 / (out["lora_grad_norm"] + 1e-6))
     inv = 1.0 / 65536.0
     gB = torch.stack([torch.cat(out["g_lora"][6 * l + 1: 6 * l + 6: 2]) for l in range(len(te_ref.layers))])
-    assert rel_err(step.te.grad_B * inv * clip, gB) < 5e-2
+    parity("mixing step grad lora_B", step.te.grad_B * inv * clip, gB, rel=4e-3, maxabs=6e-3)
     gBv = step.te.grad_B.view(len(te_ref.layers), 3, D, 4)
     assert gBv[:, :, 1::2].abs().max().item() == 0.0 and gBv[:, :, 0::2].abs().max().item() > 0.0   # :1119-1126, object
-    assert rel_err(step.te.grad_added * inv, out["g_emb_added"]) < 5e-2
+    parity("mixing step grad added rows", step.te.grad_added * inv, out["g_emb_added"], rel=4e-3, maxabs=6e-3)
 
 
 def test_v_prediction_target_matches_oracle():
@@ -322,7 +335,7 @@ def test_v_prediction_target_matches_oracle():
     sc = step.scalars()
     torch.testing.assert_close(step.velocity.cpu(), ts.get_velocity(x0, noise, t, st_ref.acp), rtol=1e-5, atol=1e-6)
     assert sc["found_inf"] == 0.0 and abs(sc["loss_mse"] - out["mse"]) < 2e-2 * abs(out["mse"]) + 1e-4, (sc, out["mse"])
-    assert rel_err(step.te.grad_added / 65536.0, out["g_emb_added"]) < 5e-2
+    parity("v-prediction step grad added rows", step.te.grad_added / 65536.0, out["g_emb_added"], rel=4e-3, maxabs=6e-3)
 
 
 def _fill_inputs(step, added, B, hw, seed, rows=None):
