@@ -86,3 +86,44 @@ def test_wrapper_order_golden(golden_dir):
     g = torch.load(os.path.join(golden_dir, "wrapper_order.pt"))
     assert g["n5_seed42_rep2"] == [4, 2, 3, 1, 0, 0, 2, 3, 4, 1]
     assert g["n1_seed42_rep4"] == [0, 0, 0, 0]
+
+
+def test_full_size_clip_l_equals_installed_transformers_and_its_state_dict_manifest():
+    """SD1.x text encoder at FULL size against the INSTALLED transformers CLIPTextModel (same arithmetic as the pinned 4.40.2 eager path in
+    fp32): (a) the state-dict manifest -- every key and shape of transformers' model equals the oracle's HF key map and the
+    product's shape table; (b) hidden states of random prompts; (c) gradients w.r.t. the token embedding rows."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder
+    from textboost_amd import models
+    torch.manual_seed(0)
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                         max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5, bos_token_id=49406, eos_token_id=49407,
+                         pad_token_id=1, projection_dim=768)
+    hf = CLIPTextModel(cfg).eval()
+    sd = {k: v for k, v in hf.state_dict().items() if "position_ids" not in k}
+    if not any(k.startswith("text_model.") for k in sd):  # transformers 5.x dropped the `text_model.` wrapper level of 4.40.2's key names
+        sd = {"text_model." + k: v for k, v in sd.items()}
+    shapes = models.clip_shapes(models.SD15_CLIP)
+    assert set(sd) == set(shapes), (set(sd) ^ set(shapes))
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert sum(v.numel() for v in sd.values()) == 123_060_480
+    ours = TextBoostEncoder(CLIPTextCfg.sd15(), r=0)
+    ours.load_hf_state_dict(sd)
+    assert set(ours.hf_key_map().values()) == set(sd)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 49405, (2, 77), generator=g)
+    ids[:, 0] = 49406
+    ids[0, 9:] = 49407
+    ids[1, 30:] = 49407
+    ref = hf(input_ids=ids).last_hidden_state
+    got = ours.transformer(ids)
+    torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4)
+    w = hf.get_input_embeddings().weight
+    R = torch.randn(2, 77, 768, generator=g)
+    gr, = torch.autograd.grad((ref * R).sum(), w)
+    go, = torch.autograd.grad((got * R).sum(), ours.token_embedding.weight)
+    rows = ids.unique()
+    rel = ((go[rows] - gr[rows]).norm() / gr[rows].norm()).item()
+    mx = ((go[rows] - gr[rows]).abs().max() / gr[rows].abs().max()).item()
+    assert rel < 1e-4 and mx < 1e-3, (rel, mx)   # fp32 summation-order noise only

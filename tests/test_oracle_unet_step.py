@@ -137,3 +137,27 @@ def test_full_step_tiny_runs_and_respects_masks():
     assert not torch.equal(w[added[0]], w_before[added[0]])
     assert (w[added].norm(dim=-1) <= st.mean_norm * (1 + 1e-5)).all()
     assert any(p.abs().max() > 0 for n, p in te_l.named_parameters() if "lora_B" in n)
+
+
+def test_attention_block_equals_torch_sdpa_at_sd_dims():
+    """diffusers AttnProcessor2_0 calls F.scaled_dot_product_attention (no mask, default scale hd^-0.5): the oracle's explicit
+    softmax(QK^T / sqrt(hd)) V must equal the INSTALLED torch SDPA at the SD1.x head geometry (8 heads of 40 / 80 / 160) for self- and
+    cross-attention (77 text tokens), forward and gradients."""
+    from oracle.unet_sd import Attention
+    torch.manual_seed(0)
+    for C, S in ((320, 256), (640, 128), (1280, 64)):
+        for cross in (None, 768):
+            att = Attention(C, 8, cross)
+            x = torch.randn(2, S, C, requires_grad=True)
+            ctx = torch.randn(2, 77, cross) if cross else None
+            y = att(x, ctx)
+            hd = C // 8
+            q = att.to_q(x).view(2, S, 8, hd).transpose(1, 2)
+            src = x if ctx is None else ctx
+            k = att.to_k(src).view(2, -1, 8, hd).transpose(1, 2)
+            v = att.to_v(src).view(2, -1, 8, hd).transpose(1, 2)
+            ref = att.to_out[0](F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2, S, C))
+            torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+            g1, = torch.autograd.grad(y.square().sum(), x, retain_graph=True)
+            g2, = torch.autograd.grad(ref.square().sum(), x)
+            torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-5)
