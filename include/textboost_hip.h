@@ -134,6 +134,8 @@ typedef struct tb_attn_desc {
 } tb_attn_desc;
 int tb_attention_fwd(const tb_attn_desc* d, tb_stream_t stream);
 int tb_attention_bwd(const tb_attn_desc* d, tb_stream_t stream);
+/* A/B knob: bit 0 = LDS-DMA staged forward kernel for the hd = 40 / 80 self-attention shapes (default on); returns the previous value */
+int tb_attention_set_variant(int bits);
 
 /* ---- scheduler / boundary / loss / misc streaming kernels ------------------------------------------ */
 /* noise_scheduler.add_noise (:1052) [+ get_velocity (:1073) when velocity != NULL]; fp32 NCHW in, fp16 noisy out */

@@ -13,7 +13,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"] or "conv" in r["Kernel_Name"]:
+        if any(x in r["Kernel_Name"] for x in ("gemm", "conv", "attn")):
             agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in agg.items():
     print(k)

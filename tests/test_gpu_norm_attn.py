@@ -148,3 +148,31 @@ def test_attention_online_softmax_rescale_branch():
     ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd)
     oref, _ = ref_attention(q.float().view(B, S, C), k.float().view(B, S, C), v.float().view(B, S, C), H, False)
     assert (o.float().view(B, S, C) - oref).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,hd", [(1, 2, 128, 64, 40), (1, 2, 128, 128, 40), (2, 3, 256, 192, 40), (1, 8, 1024, 1024, 40),
+                                            (1, 2, 128, 64, 80), (2, 3, 256, 320, 80), (1, 8, 1024, 1024, 80)])
+def test_attention_fwd_lds_dma_kernel(B, H, Sq, Skv, hd):
+    """the LDS-DMA staged forward kernel (hd = 40 / 80, Sq % 128 == 0, Skv % 64 == 0): 1, 2, 3 and many KV tiles (the 3-slot ring wraps),
+    bit-comparable statistics with the register-staged kernel, and the forced re-base branch (cdna guide rule 26)."""
+    from textboost_amd import _lib as L
+    ops = _ops()
+    torch.manual_seed(4)
+    C = H * hd
+    qkv = torch.randn(B * max(Sq, Skv), 3 * C, device="cuda").half()
+    q, k, v = qkv[:B * Sq, :C], qkv[:B * Skv, C:2 * C].clone(), qkv[:B * Skv, 2 * C:]
+    if Skv >= 192:
+        k.view(B, Skv, C)[0, 150, :hd] = q.view(B, Sq, C)[0, 7, :hd] * 4  # key 150 (3rd tile) dominates query 7 of head 0: re-base at a late tile
+    outs = []
+    for variant in (1, 0):
+        L.lib().tb_attention_set_variant(variant)
+        o = torch.empty(B * Sq, C, device="cuda", dtype=torch.float16)
+        lse = torch.empty(B, H, Sq, device="cuda")
+        ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd)
+        outs.append((o, lse))
+    L.lib().tb_attention_set_variant(1)
+    oref, lref = ref_attention(q.float().reshape(B, Sq, C), k.float().reshape(B, Skv, C), v.float().reshape(B, Skv, C), H, False)
+    for o, lse in outs:
+        assert rel_err(o.view(B, Sq, C), oref) < 2e-3
+        assert (o.float().view(B, Sq, C) - oref).abs().max().item() < 1e-2
+        assert ((lse - lref).abs() / lref.abs().clamp_min(1.0)).max().item() < 2e-3

@@ -66,6 +66,7 @@ _SIGS = {
     "tb_last_hip_error": ([], C.c_char_p),
     "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_gemm_last_config": ([_VP], None),
+    "tb_attention_set_variant": ([_I], C.c_int),
     "tb_gemm8_set": ([_I], C.c_int),
     "tb_gemm8_last": ([_VP], C.c_int),
     "tb_gemm8_debug": ([_VP], C.c_int),

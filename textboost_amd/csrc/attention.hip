@@ -44,6 +44,29 @@ __device__ __attribute__((aligned(16))) const f16 g_zero8[8] = {};  // out-of-ra
 // single v_exp_f32 (no denormal-range fixup: softmax probabilities below 2^-126 may flush to 0)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Workgroup -> (x block, head, batch).  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so with the plain
+// (x, h, b) grid the x blocks of ONE (batch, head) -- which all stream the same K / V (or Q / dO) rows -- land on 8 different L2s and every
+// XCD sees every head's operands (42 MB at 64x64 maps against 4 MB of L2): the tile loads then run at the ~6.5 TB/s of the fabric.  With
+// remap, XCD i owns the (batch, head) pairs i, i + 8, ..: all x blocks of a pair share one L2.  Only speed depends on the placement.
+struct AttnBlk {
+  int x, h, b;
+};
+__device__ __forceinline__ AttnBlk attn_block(int remap) {
+  AttnBlk r;
+  const int gx = gridDim.x, H = gridDim.y, B = gridDim.z;
+  if (remap && ((H * B) & 7) == 0) {
+    const int lin = blockIdx.x + gx * (blockIdx.y + H * blockIdx.z);
+    const int xcd = lin & 7, k = lin >> 3;
+    const int pair = (k / gx) * 8 + xcd;
+    r.x = k - (k / gx) * gx;
+    r.h = pair % H;
+    r.b = pair / H;
+  } else {
+    r.x = blockIdx.x, r.h = blockIdx.y, r.b = blockIdx.z;
+  }
+  return r;
+}
+
 template <int WD>
 struct RM {  // row-major [64][WD] tile, rows padded by 16 B
   static constexpr int LD = WD + 8;
@@ -223,15 +246,16 @@ __device__ __forceinline__ void scale_frags(f16x8* f, float c) {
 // inline constant 0: no 16-register -m tuple (the 168-VGPR kernel spilled with it) and no 32 accumulator-init moves per tile (PMC: 32 of the
 // ~115 non-MFMA VALU ops per wave-tile).
 template <int DT, int KS, bool ONES, bool FOLDM>
-__global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p) {  // 3 blocks/CU only where 168 VGPRs hold without spills
+__global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <= 4 ? 2 : 1))) void attn_fwd_kernel(const tb_attn_desc p, int remap) {  // 3 blocks/CU only where 168 VGPRs hold without spills
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
   f16* Vt = Ks + RM<WD>::SIZE;
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR): the mask tests below become scalar branches
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128;
+  const AttnBlk blk = attn_block(remap);
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.x * 128;
   const int q = qblk + wave * 32 + l31;
   const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
   const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
@@ -409,6 +433,279 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, LDS-DMA staged
+// Same arithmetic as attn_fwd_kernel (swapped S^T = K Q^T, FOLDM / ONES tricks, lazy re-base), different operand path -- the register-staged
+// kernel issues ~380 instructions per 14 MFMAs (tile loads into VGPRs, address arithmetic, f16 permutes and 12 LDS stores per thread for
+// the transposed V image, exec-mask bookkeeping for the half-idle staging threads) and is bound by instruction issue, not by the matrix
+// pipe (28 % busy) nor by the softmax VALU work alone:
+//   * K and V tiles go HBM -> LDS by global_load_lds_dwordx4 (no staging registers, no LDS stores), BOTH row-major, 3-deep ring with
+//     counted vmcnt (loads two tiles ahead of the multiplication);
+//   * V^T fragments for O^T = V^T P^T are read with ds_read_b64_tr_b16 (the hardware transposing read) straight from the row-major
+//     tile: lane j of a 16-lane group points at key row (j >> 2), columns 4 (j & 3) .. +3 and receives 4 consecutive keys of column j;
+//   * rows are padded by ONE 16-byte chunk [1, 0, .. 0] (written once per stage; the DMA's pad lanes are switched off), which is the
+//     all-ones column hd that FOLDM (K) and ONES (V) need.
+// Requirements (else the register-staged kernel runs): non-causal, Sq % 128 == 0, Skv % 64 == 0, hd % 8 == 0, hd < 32 DT.
+template <int OFF>
+__device__ __forceinline__ f16x4 lds_tr_read_off(uint32_t addr) {
+  f16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void attn_wait_vmcnt(int n) {  // n wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+  }
+}
+typedef const __attribute__((address_space(1))) void* attn_gptr_t;
+typedef __attribute__((address_space(3))) void* attn_lptr_t;
+
+// QG: 32-query groups per wave (block = 4 waves x QG x 32 queries).  With QG = 2 every K / V fragment read from LDS, every DMA
+// instruction, barrier and loop-control instruction serves two score tiles: the kernels are bound by instruction ISSUE (PMC: the waves of a
+// SIMD are "active" -- issuing -- ~100 % of the time at ~4.6 cycles per instruction; MFMA busy 30 %), so what counts is instructions per MFMA.
+template <int DT, int KS, int PC, bool FOLDM, int NST, int QG>
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc p, int remap) {
+  constexpr int PCB = PC * 16;                      // row pitch (bytes): hd / 8 data chunks + the pad chunk
+  constexpr int TILE_B = KVT * PCB;                 // one 64-row tile
+  constexpr int STAGE_B = 2 * TILE_B + 64;          // K tile, V tile, slack for the V fragment reads past the last row's pad chunk
+  static_assert(NST >= 3, "loads run two tiles ahead of the multiplication");
+  constexpr int NI = 2 * PC;                        // load instructions per stage (64 lanes x 16 B each)
+  constexpr int WI = (NI + 3) / 4;                  // ... per wave
+  constexpr int QB = 128 * QG;                      // queries per block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlk blk = attn_block(remap & 1);
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.x * QB;
+  const int hd = p.hd, Skv = p.Skv;
+  const int64_t ldk = p.ldk, ldv = p.ldv;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * hd;
+  const char* Kg = (const char*)((const f16*)p.K + (int64_t)b * Skv * ldk + h * hd);
+  const char* Vg = (const char*)((const f16*)p.V + (int64_t)b * Skv * ldv + h * hd);
+  f16x8 qf[QG][KS];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    load_row_frags<KS>(qf[g], Qg, p.ldq, qblk + (wave * QG + g) * 32 + l31, p.Sq, hd, hi);
+    scale_frags<KS>(qf[g], p.scale * LOG2E);
+  }
+  // ---- this lane's part of a stage's loads: instruction t = wave + 4 i covers flat chunks t' * 64 + lane of tensor t / PC
+  uint32_t g_off[WI];   // byte offset of the source chunk inside the tile's 64 rows (row * ld * 2 + c * 16)
+  bool g_on[WI];        // false: pad chunk (keeps its constant) or no such instruction for this wave
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave + 4 * i;
+    const int tensor = t >= PC ? 1 : 0;
+    const int f = (t - tensor * PC) * 64 + lane;
+    const int row = f / PC, c = f - row * PC;
+    g_on[i] = t < NI && c < PC - 1;
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + c * 16);
+  }
+  int n_issued = 0;  // loads this wave issues per stage (wave-uniform): for the counted waits
+#pragma unroll
+  for (int i = 0; i < WI; ++i) n_issued += (wave + 4 * i < NI) ? 1 : 0;
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * STAGE_B;
+    const char* kb = Kg + (int64_t)tile * KVT * ldk * 2;
+    const char* vb = Vg + (int64_t)tile * KVT * ldv * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave + 4 * i;
+      if (t < NI) {
+        const char* src = (t >= PC ? vb : kb) + g_off[i];
+        if (g_on[i]) __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + t * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // pad chunks [1, 0, .., 0] of every row of every stage (K and V): 2 * 64 * NST chunks (the first barrier of the loop publishes them)
+  for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {
+    const int st = u / (2 * KVT), r = u - st * 2 * KVT;  // r < 64: K row r, else V row r - 64
+    f16x8 one = {(f16)1.f, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = one;
+  }
+  const int ntiles = Skv / KVT;
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < ntiles) stage_loads(st, st);
+
+  f32x16 o[QG][DT];
+#pragma unroll
+  for (int g = 0; g < QG; ++g)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ZERO16(o[g][d]);
+  float m[QG], l[QG];
+  f32x16 negm[QG];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    m[g] = 0.f, l[g] = 0.f;
+    ZERO16(negm[g]);  // FOLDM: stays the zero tuple (the compiler feeds the inline constant 0 as the first MFMA's accumulator input)
+  }
+  const int fj = hd >> 4;
+  const bool fold_lane = FOLDM && hi == ((hd >> 3) & 1);
+  // fragment addressing: K row-major (lane = key row l31, chunk 2 j + hi); V transposing reads (lane group g = lane >> 4: d sub-block
+  // 16 (g & 1), key offset 4 (g >> 1), lane j: key row j >> 2, columns 4 (j & 3))
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lptr_t)smem_raw;
+  const uint32_t k_lane = l31 * PCB + hi * 16;
+  const int g4 = lane >> 4, j16 = lane & 15;
+  const uint32_t v_lane = TILE_B + (4 * (g4 >> 1) + (j16 >> 2)) * PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
+  int slot = 0, lslot = NST - 1;
+#ifdef TB_ATTN_PROF
+  unsigned long long pf_[5] = {0, 0, 0, 0, 0}, pt_ = __builtin_amdgcn_s_memtime();
+#define TB_PF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
+#else
+#define TB_PF(k)
+#endif
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed once at most the stages issued after it are outstanding (this wave's part); the barrier extends that to every
+    // wave and frees the slot of tile t - 1 (its fragment reads were consumed by MFMAs of the previous iteration)
+    {
+      int later = ntiles - 1 - t;
+      later = later > NST - 2 ? NST - 2 : later;
+      attn_wait_vmcnt(later * n_issued);
+    }
+    TB_PF(3)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TB_PF(4)
+    if (t + NST - 1 < ntiles && !(remap & 16)) stage_loads((remap & 8) ? 0 : t + NST - 1, lslot);
+    const unsigned char* Ks = smem_raw + slot * STAGE_B;
+    f32x16 s[QG][2];
+    {
+      f16x8 kf[2][KS];
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[kt][j] = *(const f16x8*)(Ks + k_lane + kt * 32 * PCB + j * 32);
+#pragma unroll
+      for (int g = 0; g < QG; ++g)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          s[g][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][0], qf[g][0], negm[g], 0, 0, 0);
+#pragma unroll
+          for (int j = 1; j < KS; ++j) s[g][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][j], qf[g][j], s[g][kt], 0, 0, 0);
+        }
+    }
+    // V^T fragments of the whole tile (shared by the query groups): issued now, they arrive under the softmax arithmetic below
+    f16x4 vt[2][2][DT][2];
+    {
+      const uint32_t va = lds0 + slot * STAGE_B + v_lane;
+      __builtin_amdgcn_sched_barrier(0);
+#define TB_VTR(KT, JJ, D, HH) vt[KT][JJ][D][HH] = lds_tr_read_off<((KT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(va);
+#define TB_VTR_D(KT, JJ, HH)                      \
+  TB_VTR(KT, JJ, 0, HH)                           \
+  if (DT > 1) { TB_VTR(KT, JJ, (DT > 1 ? 1 : 0), HH) } \
+  if (DT > 2) { TB_VTR(KT, JJ, (DT > 2 ? 2 : 0), HH) }
+      TB_VTR_D(0, 0, 0) TB_VTR_D(0, 0, 1) TB_VTR_D(0, 1, 0) TB_VTR_D(0, 1, 1)
+      TB_VTR_D(1, 0, 0) TB_VTR_D(1, 0, 1) TB_VTR_D(1, 1, 0) TB_VTR_D(1, 1, 1)
+#undef TB_VTR_D
+#undef TB_VTR
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool first = t == 0;
+    TB_PF(0)
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      float mx0 = s[g][0][0], mx1 = s[g][1][0];
+#pragma unroll
+      for (int r = 1; r < 15; r += 2) {
+        mx0 = max3f(mx0, s[g][0][r], s[g][0][r + 1]);
+        mx1 = max3f(mx1, s[g][1][r], s[g][1][r + 1]);
+      }
+      float mx = max3f(mx0, mx1, fmaxf(s[g][0][15], s[g][1][15]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (first || __any(mx > TB_ATTN_REBASE)) {
+        float d = first ? mx : fmaxf(mx, 0.f);
+        if (FOLDM) d = (float)(f16)(m[g] + d) - m[g];
+        if (!first) {
+          const float alpha = fast_exp2(-d);
+          l[g] *= alpha;
+#pragma unroll
+          for (int dd = 0; dd < DT; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[g][dd][r] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[g][kt][r] -= d;
+        m[g] += d;
+        if (FOLDM) {
+#pragma unroll
+          for (int j = 0; j < KS; ++j)
+            if (j == fj && fold_lane) qf[g][j][0] = (f16)(-m[g]);
+        } else {
+          FILL16(negm[g], -m[g]);
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[g][kt][r] = fast_exp2(s[g][kt][r]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the V^T fragments (inline-asm reads: not counted by the compiler)
+    __builtin_amdgcn_sched_barrier(0);
+    TB_PF(1)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        f16x8 a[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[d][e] = vt[kt][jj][d][0][e];
+            a[d][4 + e] = vt[kt][jj][d][1][e];
+          }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+          const f16x8 pf = pack8(s[g][kt], 8 * jj);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) o[g][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[d], pf, o[g][d], 0, 0, 0);
+        }
+      }
+    TB_PF(2)
+    slot = slot == NST - 1 ? 0 : slot + 1;
+    lslot = lslot == NST - 1 ? 0 : lslot + 1;
+  }
+#ifdef TB_ATTN_PROF
+  if (p.Delta && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)
+    for (int k = 0; k < 5; ++k) p.Delta[wave * 5 + k] = (float)pf_[k] / (float)ntiles;
+#endif
+#undef TB_PF
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    // the all-ones column hd of V made O^T row hd the row sum: register 4 k of the hi == 0 lane of tile hd / 32
+    float ls = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        if (d * 32 + k4 * 8 == hd) ls = o[g][d][4 * k4];
+    const float lsum = __shfl(ls, l31, 64);
+    const float inv = 1.f / lsum;
+    const int q = qblk + (wave * QG + g) * 32 + l31;
+    f16* Og = (f16*)p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < hd) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[g][d][4 * r4 + e] * inv);
+          *(f16x4*)(Og + col) = v;
+        }
+      }
+    if (p.LSE && hi == 0) p.LSE[((int64_t)b * p.H + h) * p.Sq + q] = m[g] * (1.f / LOG2E) + logf(lsum);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const tb_attn_desc p) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B*Sq*H
@@ -433,7 +730,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const tb_attn_desc p) {
 #define TB_DQ_OCC 2
 #endif
 template <int DT, int KS>
-__global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p) {
+__global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p, int remap) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
@@ -441,8 +738,9 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
   f16* Kt = Vs + RM<WD>::SIZE;
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR): the mask tests below become scalar branches
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128;
+  const AttnBlk blk = attn_block(remap);
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.x * 128;
   const int q = qblk + wave * 32 + l31;
   const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
   const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
@@ -567,7 +865,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
 // dK/dV in fp32 to ws32[slice][{K,V}][B*Skv][H*hd]; a finalize kernel sums the slices in a fixed order (deterministic)
 // and rounds to fp16.  Used when there are too few key blocks to fill the chip (cross-attention: 77 keys).
 template <int DT, int KS>
-__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(const tb_attn_desc p, int qsplit, int q_chunk, float* ws32) {
+__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(const tb_attn_desc p, int qsplit, int q_chunk, float* ws32, int remap) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Qs = reinterpret_cast<f16*>(smem_raw);
@@ -578,9 +876,10 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   float* del_s = lse_s + KVT;
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR): the mask tests below become scalar branches
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int kblk = (blockIdx.x / qsplit) * 128;
-  const int qslice = blockIdx.x % qsplit;
+  const AttnBlk blk = attn_block(remap);
+  const int b = blk.b, h = blk.h;
+  const int kblk = (blk.x / qsplit) * 128;
+  const int qslice = blk.x % qsplit;
   const int key = kblk + wave * 32 + l31;
   const bool kok = key < p.Skv;
   const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
@@ -745,17 +1044,50 @@ __global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __r
   dV[m * lddv + c] = (f16)b;
 }
 
+int g_attn_dma = 1;  // tb_attention_set_variant(bits): 1 = LDS-DMA staged forward kernel, 2 = also for hd 80, 4 = NO XCD-aware block remap,
+                     // 32 = one query group per wave, 64 = XCD remap also in the backward kernels (measured: forward +14 %, backward -5 %)
+                     // (A/B knobs; 8 / 16 = load-path ablations of the DMA kernel)
+
 template <int DT, int KS>
 int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
   size_t lds = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16) * (DT <= 3 ? 2 : 1);  // double-buffered K / V^T tiles
   dim3 grid((d.Sq + 127) / 128, d.H, d.B);
+  if ((g_attn_dma & 1) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 && d.hd % 8 == 0 && d.hd < WD && (d.hd == 40 || d.hd == 80) &&
+      d.ldk % 8 == 0 && d.ldv % 8 == 0 && (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31)) {
+    // LDS-DMA staged kernel (see attn_fwd_dma_kernel): the SD1.x self-attention shapes, hd = 40 (64x64 maps) and 80 (32x32 maps)
+    const int rm = ((g_attn_dma >> 2) & 1 ^ 1) | (g_attn_dma & 24);
+    if (DT == 2 && KS == 3 && d.hd == 40) {
+      constexpr int PC = 6, NST = 4;
+      const size_t lds = NST * (2 * KVT * PC * 16 + 64);
+      if (d.Sq % 256 == 0 && !(g_attn_dma & 32))
+        hipLaunchKernelGGL((attn_fwd_dma_kernel<2, 3, PC, true, NST, 2>), dim3(d.Sq / 256, d.H, d.B), dim3(256), lds, s, d, rm);
+      else
+        hipLaunchKernelGGL((attn_fwd_dma_kernel<2, 3, PC, true, NST, 1>), grid, dim3(256), lds, s, d, rm);
+      TB_CHECK_LAUNCH();
+      return TB_OK;
+    }
+    if (DT == 3 && KS == 5 && d.hd == 80 && (g_attn_dma & 2)) {
+      constexpr int PC = 11, NST = 3;
+      const size_t lds = NST * (2 * KVT * PC * 16 + 64);
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<3, 5, PC, false, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+          return TB_ELAUNCH;
+        attr_done = true;
+      }
+      hipLaunchKernelGGL((attn_fwd_dma_kernel<3, 5, PC, false, NST, 1>), grid, dim3(256), lds, s, d, rm);
+      TB_CHECK_LAUNCH();
+      return TB_OK;
+    }
+  }
   if (TB_ATTN_FOLDM && DT <= 2 && d.hd < WD && d.hd < 16 * KS && d.hd % 8 == 0)  // padding in the head dim of BOTH products: see FOLDM
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, (DT <= 2)>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, (DT <= 2)>), grid, dim3(256), lds, s, d, (g_attn_dma >> 2) & 1 ^ 1);
   else if (d.hd < WD)  // head-dim padding exists: the row sum rides on the PV product (all-ones row hd of V^T)
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, false>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, false>), grid, dim3(256), lds, s, d, (g_attn_dma >> 2) & 1 ^ 1);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false, false>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false, false>), grid, dim3(256), lds, s, d, (g_attn_dma >> 2) & 1 ^ 1);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
@@ -777,7 +1109,7 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
       attr_done = true;
     }
     dim3 grid((d.Sq + 127) / 128, d.H, d.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1);
   }
   {
     size_t lds = (2 * RM<WD>::SIZE + 2 * TR<WD>::SIZE) * sizeof(f16) + 2 * KVT * sizeof(float);
@@ -801,7 +1133,7 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     int q_chunk = ((d.Sq + qsplit - 1) / qsplit + KVT - 1) / KVT * KVT;
     if (qsplit > 1) qsplit = (d.Sq + q_chunk - 1) / q_chunk;
     dim3 grid(nkb * qsplit, d.H, d.B);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, KS>), grid, dim3(256), lds, s, d, qsplit, q_chunk, d.ws);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT, KS>), grid, dim3(256), lds, s, d, qsplit, q_chunk, d.ws, (g_attn_dma >> 6) & 1);
     if (qsplit > 1) {
       const int64_t rows = (int64_t)d.B * d.Skv;
       hipLaunchKernelGGL(attn_dkv_finalize_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, s, d.ws, (f16*)d.dK, d.lddk,
@@ -839,6 +1171,12 @@ int check_desc(const tb_attn_desc& d, bool bwd) {
   } while (0)
 
 }  // namespace
+
+extern "C" int tb_attention_set_variant(int bits) {
+  const int old = g_attn_dma;
+  g_attn_dma = bits;
+  return old;
+}
 
 extern "C" int tb_attention_fwd(const tb_attn_desc* dp, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
