@@ -195,3 +195,50 @@ def test_conv3x3_halo_kernel_fwd_and_dgrad(B, Cin, Cout, H, W):
     ops.gemm(nhwc(dy).view(B * H * W, Cout), pack_conv_w_dgrad(w), dx, conv=geo)
     refd = nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1))
     assert rel_err(dx.view(B, H, W, Cin), refd) < 2e-3
+
+
+@pytest.mark.parametrize("M,C", [(32768, 320), (8192, 640)])
+def test_geglu_forward_and_backward_epilogues_on_the_wide_tile_kernel(M, C):
+    """ff.net.0.proj + GEGLU (N = 8C a multiple of 640) and the GEGLU backward fused into the ff.net.2 dgrad GEMM (N = 4C a multiple of
+    320) at row counts that select gemm8_kernel's 128 x 320 tiles: against torch and against the 4-wave kernels' results."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(5)
+    A = torch.randn(M, C, device="cuda").half()
+    W = (torch.randn(8 * C, C, device="cuda") / C ** 0.5).half()
+    b = torch.randn(8 * C, device="cuda")
+    outs = []
+    for bits in (7, 0):
+        L.lib().tb_gemm8_set(bits)
+        out = torch.empty(M, 4 * C, device="cuda", dtype=torch.float16)
+        raw = torch.empty(M, 8 * C, device="cuda", dtype=torch.float16)
+        ops.gemm(A, pack_geglu(W), out, bias=pack_geglu(b), act=L.ACT_GEGLU, C2=raw)
+        used = L.lib().tb_gemm8_last(None)
+        assert bool(used) == (bits == 7)
+        outs.append((out, raw))
+    L.lib().tb_gemm8_set(7)
+    proj = A.float() @ W.float().T + b
+    h, g = proj.chunk(2, dim=-1)
+    ref = h * F.gelu(g)
+    for out, raw in outs:
+        assert rel_err(out, ref) < 3e-3 and rel_err(raw, pack_geglu(proj.T).T) < 2e-3
+    assert torch.equal(outs[0][1], outs[1][1]) or rel_err(outs[0][1], outs[1][1]) < 1e-3
+    # backward: d(gated) = dY @ Wd^T, then d(proj) through the gate
+    dY = torch.randn(M, C, device="cuda").half()
+    Wd = (torch.randn(4 * C, C, device="cuda") / C ** 0.5).half()
+    raw = outs[0][1]
+    res = []
+    for bits in (7, 0):
+        L.lib().tb_gemm8_set(bits)
+        dproj = torch.empty(M, 8 * C, device="cuda", dtype=torch.float16)
+        ops.gemm(dY, Wd, dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
+        assert bool(L.lib().tb_gemm8_last(None)) == (bits == 7)
+        res.append(dproj)
+    L.lib().tb_gemm8_set(7)
+    dgated = dY.float() @ Wd.float().T
+    unpack = lambda t: torch.cat([t.view(M, -1, 2, 32)[:, :, 0].reshape(M, -1), t.view(M, -1, 2, 32)[:, :, 1].reshape(M, -1)], dim=1)
+    pr = unpack(raw.float()).requires_grad_(True)
+    hh, gg = pr.chunk(2, dim=-1)
+    (hh * F.gelu(gg)).backward(dgated)
+    for dproj in res:
+        assert rel_err(unpack(dproj.float()), pr.grad) < 3e-3

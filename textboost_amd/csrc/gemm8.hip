@@ -394,6 +394,111 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + (CONV ? ((int64_t)(R - 1) * W + TW - 1) : BM - 1)) / p.rows_per_group);
   const bool fast = p.c_dtype == TB_F16 && ef.c_vec && (!p.R || (ef.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
                     !p.C2 && rb_uniform;
+  // GEGLU forward (ff.net.0.proj, packed [h32 | g32] column blocks): unit = (row, 8 gate outputs); stores the fp16 projections (C2, for the
+  // backward) and h * gelu(g).  Host guarantees: Linear tile (BN a multiple of 64), no residual / row bias, fp16 vector-aligned outputs.
+  if (!CONV && p.act == TB_ACT_GEGLU) {
+    constexpr int UG = BN / 16, TG = 512 / UG, NG = (PR + TG - 1) / TG;
+    const int og = t % UG, rs = t / UG;
+    const int hcol = (og >> 2) * 64 + (og & 3) * 8;           // tile-local packed column of h; g is + 32
+    const float alpha = p.alpha;
+    const int64_t nh = n0 + hcol, ldc = p.ldc, ldc2 = p.ldc2, Mtot = p.M;
+    float bh[8], bg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bh[e] = p.bias ? p.bias[nh + e] : 0.f;
+      bg[e] = p.bias ? p.bias[nh + 32 + e] : 0.f;
+    }
+    f16* const C2g = p.C2 ? (f16*)p.C2 + nh : nullptr;
+    f16* const Cg = (f16*)p.C + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int rp = pass * PR;
+      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            *(f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15 - rp) * LDC + (wn * NT + j) * 16 + 4 * lq) = acc[i][j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (rs < TG) {
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+          const int row = rs + it * TG;
+          const int64_t m = m0 + rp + row;
+          if (row < PR && m < Mtot) {
+            const float* cr = Cs + row * LDC + hcol;
+            const f32x4_t h0 = *(const f32x4_t*)cr, h1 = *(const f32x4_t*)(cr + 4), g0 = *(const f32x4_t*)(cr + 32), g1 = *(const f32x4_t*)(cr + 36);
+            f16x8 oh, og8, oo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              oh[e] = (f16)(alpha * (e < 4 ? h0[e] : h1[e - 4]) + bh[e]);
+              og8[e] = (f16)(alpha * (e < 4 ? g0[e] : g1[e - 4]) + bg[e]);
+              oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));  // gate on the fp16-rounded projections, as an fp16 module would
+            }
+            if (C2g) {
+              *(f16x8*)(C2g + m * ldc2) = oh;
+              *(f16x8*)(C2g + m * ldc2 + 32) = og8;
+            }
+            *(f16x8*)(Cg + m * ldc) = oo;
+          }
+        }
+      }
+      if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    return;
+  }
+  // GEGLU backward fused into the ff.net.2 dgrad GEMM: v = d(gated)[m, n..n+7]; C2 = packed pre-gate projections [M, 2N];
+  // C = d(proj) [M, 2N] in the same packing:  d h = v gelu(g),  d g = v h gelu'(g)
+  if (!CONV && p.act == TB_ACT_GEGLU_GRAD) {
+    const float alpha = p.alpha;
+    const int64_t pc = (n >> 5) * 64 + (n & 31), ldc = p.ldc, ldc2 = p.ldc2, Mtot = p.M;
+    const f16* const C2g = (const f16*)p.C2 + pc;
+    f16* const Cg = (f16*)p.C + pc;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int rp = pass * PR;
+      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            *(f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15 - rp) * LDC + (wn * NT + j) * 16 + 4 * lq) = acc[i][j];
+      }
+      f16x8 hv[NU], gv[NU];  // the pre-gate projections of the pass's units are in flight across the staging barrier
+      if (rslot < TPR) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const int64_t m = min((int64_t)(m0 + rp + min(rslot + it * TPR, PR - 1)), Mtot - 1);
+          hv[it] = *(const f16x8*)(C2g + m * ldc2);
+          gv[it] = *(const f16x8*)(C2g + m * ldc2 + 32);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (rslot < TPR) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const int row = rslot + it * TPR;
+          const int64_t m = m0 + rp + row;
+          if (row < PR && m < Mtot) {
+            const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+            f16x8 dh, dg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = (e < 4 ? c0[e] : c1[e - 4]) * alpha + b8[e];
+              const float g = (float)gv[it][e];
+              dh[e] = (f16)(v * gelu_erf_f(g));
+              dg[e] = (f16)(v * (float)hv[it][e] * gelu_erf_grad_f(g));
+            }
+            *(f16x8*)(Cg + m * ldc) = dh;
+            *(f16x8*)(Cg + m * ldc + 32) = dg;
+          }
+        }
+      }
+      if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    return;
+  }
   if (fast) {
     const float alpha = p.alpha;
     const bool silu = p.act == TB_ACT_SILU;
@@ -501,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 }
 
 unsigned long long* g8_dbg = nullptr;  // profiling aid (tb_gemm8_debug): s_memtime stamps of the first and the last block
-int g8_enable = 3;   // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers take the wide-tile path (0: A/B runs without it)
+int g8_enable = 7;   // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers, 4 = GEGLU / GEGLU-backward epilogues take the wide-tile path
 int g8_last[6] = {0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
 template <int WM, int WN, int MT, int NT, bool CONV, int NS>
@@ -561,7 +666,14 @@ extern "C" int tb_gemm8_last(int* out5) {
 int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   g8_last[0] = 0;
   if (!g8_enable) return 1;
-  if (d.A2 || d.W2 || d.act == TB_ACT_GEGLU || d.act == TB_ACT_GEGLU_GRAD) return 1;
+  if (d.A2 || d.W2) return 1;
+  if (d.act == TB_ACT_GEGLU || d.act == TB_ACT_GEGLU_GRAD) {  // lean fused epilogues exist for the aligned fp16 Linear case only
+    if (!(g8_enable & 4) || d.a_mode != TB_A_LINEAR || d.R || d.rowbias || d.c_dtype != TB_F16) return 1;
+    if (d.ldc % 8 || ((uintptr_t)d.C) % 16) return 1;
+    if (d.C2 && (d.ldc2 % 8 || ((uintptr_t)d.C2) % 16)) return 1;
+    if (d.act == TB_ACT_GEGLU && (d.N % 640 || ((uintptr_t)d.C) % 16)) return 1;       // whole [h32 | g32] blocks per 320-wide tile
+    if (d.act == TB_ACT_GEGLU_GRAD && (!d.C2 || d.N % 32 || d.bias)) return 1;
+  }
   if (d.K % 64 || d.N % 8) return 1;
   const int64_t lim = (int64_t)1 << 32;
   if (((d.N - 1) * d.ldw + d.K) * 2 >= lim) return 1;
