@@ -73,7 +73,7 @@ int tb_gemm_set_variant(int v);
 void tb_gemm_last_config(int* out5);
 /* 8-wave wide-tile path of tb_gemm (csrc/gemm8.hip; 256-pixel x 160-channel halo convolutions and 128 x 320 Linear tiles for the
  * 64x64 / 32x32 feature maps): tb_gemm8_set(bits) -- 1 = convolutions, 2 = Linear layers, 4 = fused GEGLU epilogues, default 7 -- returns the previous value;
- * tb_gemm8_last returns 1 when the most recent tb_gemm launched gemm8_kernel<WM, WN, MT, NT, CONV> and writes those five to out5 */
+ * tb_gemm8_last returns 1 when the most recent tb_gemm launched gemm8_kernel<WM, WN, MT, NT, CONV, NS> and writes those SIX ints to out5 */
 int tb_gemm8_set(int bits);
 int tb_gemm8_last(int* out5);
 /* profiling aid: device buffer of 16 x uint64 (NULL = off) that receives s_memtime stamps of the first / last workgroup of gemm8 launches */

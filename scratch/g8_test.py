@@ -14,7 +14,7 @@ def timeit(fn, n=20, warm=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e-3
 def used8():
-    c = (ctypes.c_int * 5)()
+    c = (ctypes.c_int * 6)()
     return lib.tb_gemm8_last(c), list(c)
 def rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm()).item()

@@ -89,10 +89,15 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
   const int64_t m_first = m0, m_last_ = m0 + (int64_t)((BM - 1) >> mshift) * mstride + ((BM - 1) & ((1 << mshift) - 1));
   const int64_t m_last = m_last_ < Mtot ? m_last_ : Mtot - 1;
   const bool rb_uniform = !p.rowbias || (m_first / p.rows_per_group == m_last / p.rows_per_group);
-  const bool fast = lean_ok && S == 1 && (p.N % 8 == 0) && ef.c_vec && (!p.R || ef.r_vec) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) && !p.C2 &&
-                    rb_uniform;
+  const bool act_gelu = p.act == TB_ACT_QUICK_GELU || p.act == TB_ACT_GELU;                 // C2 (optional) receives the fp16 pre-activation
+  const bool act_grad = p.act == TB_ACT_QUICK_GELU_GRAD || p.act == TB_ACT_GELU_GRAD;       // C2 holds the saved pre-activation
+  const bool fast = lean_ok && S == 1 && (p.N % 8 == 0) && ef.c_vec && (!p.R || ef.r_vec) && rb_uniform &&
+                    ((p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) ? !p.C2 : ((act_gelu && (!p.C2 || ef.c2_vec)) || (act_grad && ef.c2_vec)));
   const float alpha = p.alpha;
   const bool silu = p.act == TB_ACT_SILU, c_f32 = p.c_dtype == TB_F32, r_f32 = p.r_dtype == TB_F32;
+  const bool quick = p.act == TB_ACT_QUICK_GELU || p.act == TB_ACT_QUICK_GELU_GRAD;
+  f16* const C2b = (f16*)p.C2;
+  const int64_t ldc2 = p.ldc2;
   void* const Cb = p.C;
   const void* const Rb = p.R;
 #pragma unroll
@@ -213,6 +218,14 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
               for (int e = 0; e < 8; ++e) r8[it][e] = (float)x[e];
             }
           }
+          f16x8 aux[NU];
+          if (act_grad) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+              const int64_t m = m_of(row0 + it * RS);
+              aux[it] = *(const f16x8*)(C2b + (m < Mtot ? m : Mtot - 1) * ldc2 + n);
+            }
+          }
 #pragma unroll
           for (int it = 0; it < NU; ++it) {
             const int row = row0 + it * RS;
@@ -229,6 +242,18 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
             for (int e = 0; e < 8; ++e) {
               v[e] = v[e] * alpha + b8[e] + r8[it][e];
               if (silu) v[e] = silu_f(v[e]);
+            }
+            if (act_gelu) {  // the fp16-rounded linear output feeds the activation, as under autocast; it is what the backward re-reads
+              f16x8 pre;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                pre[e] = (f16)v[e];
+                v[e] = quick ? quick_gelu_f((float)pre[e]) : gelu_erf_f((float)pre[e]);
+              }
+              if (C2b) *(f16x8*)(C2b + m * ldc2 + n) = pre;
+            } else if (act_grad) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= quick ? quick_gelu_grad_f((float)aux[it][e]) : gelu_erf_grad_f((float)aux[it][e]);
             }
             if (c_f32) {
               f32x4 o0, o1;

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 
 unsigned long long* g8_dbg = nullptr;  // profiling aid (tb_gemm8_debug): s_memtime stamps of the first and the last block
 int g8_enable = 7;   // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers, 4 = GEGLU / GEGLU-backward epilogues take the wide-tile path
-int g8_last[6] = {0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
+int g8_last[7] = {0, 0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
 template <int WM, int WN, int MT, int NT, bool CONV, int NS>
 int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift) {
@@ -635,7 +635,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift) {
   hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), lds, s, d, tiles_m, tiles_n,
                      wshift, a_rows8, g8_dbg);
   TB_CHECK_LAUNCH();
-  g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV;
+  g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
   return TB_OK;
 }
 
@@ -656,9 +656,9 @@ extern "C" int tb_gemm8_debug(void* stamps16) {  // device buffer of 16 x u64 (o
   g8_dbg = (unsigned long long*)stamps16;       // epilogue passes done, for the first ([0..7]) and the last ([8..15]) workgroup
   return TB_OK;
 }
-extern "C" int tb_gemm8_last(int* out5) {
+extern "C" int tb_gemm8_last(int* out5 /* 6 ints */) {
   if (out5)
-    for (int i = 0; i < 5; ++i) out5[i] = g8_last[1 + i];
+    for (int i = 0; i < 6; ++i) out5[i] = g8_last[1 + i];
   return g8_last[0];
 }
 
@@ -693,7 +693,7 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   }
   if (!(g8_enable & 2)) return 1;
   if (d.N % 320) return 1;
-  if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
+  if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);
   return 1;
 }

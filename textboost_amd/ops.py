@@ -120,9 +120,9 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
             import ctypes
             cfg = (ctypes.c_int * 5)()
             L.lib().tb_gemm_last_config(cfg)
-            c8 = (ctypes.c_int * 5)()
+            c8 = (ctypes.c_int * 6)()
             if L.lib().tb_gemm8_last(c8):
-                r.name = f"gemm8_kernel<{c8[0]}, {c8[1]}, {c8[2]}, {c8[3]}, {'true' if c8[4] else 'false'}>"
+                r.name = f"gemm8_kernel<{c8[0]}, {c8[1]}, {c8[2]}, {c8[3]}, {'true' if c8[4] else 'false'}, {c8[5]}>"
             elif cfg[2] == 2:
                 r.name = f"conv_halo_kernel<{cfg[1]}>"
             else:
