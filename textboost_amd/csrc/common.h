@@ -53,9 +53,32 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   float s = 1.f / (1.f + __expf(-x));
   return s * (1.f + x * (1.f - s));
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// Exact (erf) GELU without libm's erff (a two-branch routine of ~120 VALU instructions: the GEGLU epilogues were VALU-bound on it, 8.6 us of a
+// 14.5 us tile).  Phi(x) = erfc(-x / sqrt 2) / 2 with the Chebyshev-fitted erfc(z) = t exp(-z^2 + P(t)), t = 1 / (1 + z / 2) of Numerical
+// Recipes 6.2 (fractional error < 1.2e-7 for every z >= 0, i.e. relative accuracy also in the tail where 1 + erf cancels): one rcp, one exp
+// and nine FMAs.  Against float64: relative error of gelu <= 3e-6 over |x| <= 12; after rounding to fp16 it differs in 158 of 2e6 inputs by 1 ulp.
+__device__ __forceinline__ float normal_cdf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.5f * z);
+  float q = 0.17087277f;
+  q = q * t - 0.82215223f;
+  q = q * t + 1.48851587f;
+  q = q * t - 1.13520398f;
+  q = q * t + 0.27886807f;
+  q = q * t - 0.18628806f;
+  q = q * t + 0.09678418f;
+  q = q * t + 0.37409196f;
+  q = q * t + 1.00002368f;
+  q = q * t - 1.26551223f;
+  const float half_erfc = 0.5f * t * __expf(q - z * z);
+  return x < 0.f ? half_erfc : 1.f - half_erfc;
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return x * normal_cdf_f(x); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) { return normal_cdf_f(x) + x * 0.3989422804014327f * __expf(-0.5f * x * x); }
+__device__ __forceinline__ void gelu_erf_both_f(float x, float& g, float& dg) {  // gelu(x) and gelu'(x) off one Phi(x)
+  const float c = normal_cdf_f(x);
+  g = x * c;
+  dg = c + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {

@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ 
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float g = (float)gg[e], dd = (float)d[e];
-    dh[e] = (f16)(dd * gelu_erf_f(g));
-    dg[e] = (f16)(dd * (float)hh[e] * gelu_erf_grad_f(g));
+    float ge, dge;
+    gelu_erf_both_f(g, ge, dge);
+    dh[e] = (f16)(dd * ge);
+    dg[e] = (f16)(dd * (float)hh[e] * dge);
   }
   *(f16x8*)(dproj + m * lddp + blk * 64 + j) = dh;
   *(f16x8*)(dproj + m * lddp + blk * 64 + 32 + j) = dg;

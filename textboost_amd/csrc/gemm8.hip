@@ -30,7 +30,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 template <int BM, int BN>
 struct G8Epi {
   static constexpr int LDC = BN + 4;                                           // padded fp32 staging pitch: conflict-free b128 stores
-  static constexpr int PASSES = (BM * LDC * 4 <= 96 * 1024) ? 1 : 2;           // stage the tile in halves when it does not fit
+  // stage the tile in halves when it does not fit; the small Linear tiles stay under 80 KB so that two workgroups share a CU
+  static constexpr int LIM = (BM * BN <= 128 * 192 ? 80 : 96) * 1024;
+  static constexpr int PASSES = (BM * LDC * 4 <= LIM) ? 1 : 2;
   static constexpr int PR = BM / PASSES;
   static constexpr size_t BYTES = (size_t)PR * LDC * 4;
 };
@@ -127,6 +129,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   }
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
   const int64_t n0 = (int64_t)tn * BN;
+  // Linear tiles: the BN bias values go through a small LDS array filled under the prologue loads.  Loaded at the point of use (after the main
+  // loop) they queued behind the CU's in-flight stores and operand loads: 8300 cycles of a 35000-cycle 128x128x320 GEGLU tile were this wait.
+  // (The conv tiles have no LDS to spare -- 160 KB exactly at 64-wide feature maps -- and amortise it over 45+ k-steps.)
+  constexpr int OPB = CONV ? 0 : NS * (BM + BN) * 128;
+  constexpr int EPB = (int)G8Epi<BM, BN>::BYTES;
+  float* const bias_s = reinterpret_cast<float*>(smem_raw + (OPB > EPB ? OPB : EPB));
+  float bias_v = 0.f;
+  if (!CONV && t < BN && p.bias) bias_v = p.bias[n0 + t];
+  // epilogue unit geometry (used early by the residual prefetch): a thread keeps ONE 8-column group and walks rows
+  using E = G8Epi<BM, BN>;
+  constexpr int LDC = E::LDC, PASSES = E::PASSES, PR = E::PR;
+  constexpr int UPR = BN / 8;            // 8-column groups per row
+  constexpr int TPR = 512 / UPR;         // rows covered per sweep (threads beyond UPR * TPR idle)
+  constexpr int NU = (PR + TPR - 1) / TPR;
+  const int cg = t % UPR, rslot = t / UPR;
+  const int64_t n = n0 + cg * 8;
 
   // ---- tile geometry
   const int TW = 1 << wshift, W = p.Wout, H = p.Hout;
@@ -144,6 +162,33 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     m0 = (int64_t)bimg * hw + (int64_t)y0 * W + x0;
   } else {
     m0 = (int64_t)tm * BM;
+  }
+  // Early epilogue operands (a global load issued after the main loop queues behind the CU's own stores and operand traffic for microseconds).
+  // conv: bias, plus the time-embedding row bias when it is constant over the tile, stay in 8 registers across the main loop;
+  // Linear: bias goes through bias_s (above) and the residual rows of the first staging pass are fetched now into NU x 4 registers.
+  constexpr bool PRE_R = !CONV && BM * BN > 128 * 128;  // (the 128x128 tile must stay under 128 registers: two workgroups per CU)
+  float b8[8];
+  f16x8 rv0[PRE_R ? NU : 1];
+  bool fast = false;
+  if (CONV) {
+    const EpiFlags ef0 = epi_flags(p);
+    const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + ((int64_t)(R - 1) * W + TW - 1)) / p.rows_per_group);
+    fast = p.c_dtype == TB_F16 && ef0.c_vec && (!p.R || (ef0.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
+           !p.C2 && rb_uniform;
+    epi_load_bias8(p, n, b8);
+    if (fast && p.rowbias) {
+      const float* rb = p.rowbias + (m0 / p.rows_per_group) * p.ldrb + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[e] += rb[e];
+    }
+  } else if (PRE_R) {
+    if (p.R && p.ldr % 8 == 0 && ((uintptr_t)p.R) % 16 == 0 && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) && rslot < TPR) {
+#pragma unroll
+      for (int it = 0; it < NU; ++it) {
+        const int64_t m = min(m0 + min(rslot + it * TPR, PR - 1), p.M - 1);
+        rv0[it] = *(const f16x8*)((const f16*)p.R + m * p.ldr + n);
+      }
+    }
   }
 
   const int cp = lane & 7, rl = lane >> 3;
@@ -258,6 +303,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   }
   if (NS == 2) cnt_prev = 0;
   wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
+  if (!CONV && t < BN) bias_s[t] = bias_v;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave
   G8_STAMP(1)
 
@@ -373,27 +419,27 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #endif
   G8_STAMP(2)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand buffers: the epilogue reuses the LDS
+  G8_STAMP(6)
 
   // ---- epilogue: accumulators -> padded fp32 tile in LDS -> (row, 8 columns) units with 16-byte global accesses.  A thread keeps ONE
   // column group (bias loaded once) and walks rows; all residual / auxiliary loads of its units are issued before the arithmetic.
-  using E = G8Epi<BM, BN>;
-  constexpr int LDC = E::LDC, PASSES = E::PASSES, PR = E::PR;
   float* Cs = reinterpret_cast<float*>(smem_raw);
   const EpiFlags ef = epi_flags(p);
-  constexpr int UPR = BN / 8;            // 8-column groups per row
-  constexpr int TPR = 512 / UPR;         // rows covered per sweep (threads beyond UPR * TPR idle)
-  constexpr int NU = (PR + TPR - 1) / TPR;
-  const int cg = t % UPR, rslot = t / UPR;
-  const int64_t n = n0 + cg * 8;
-  float b8[8];
-  epi_load_bias8(p, n, b8);
+  const bool pre_r = PRE_R && p.R && ef.r_vec && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU);
+  if (!CONV && p.act != TB_ACT_GEGLU) {
+    const f32x4_t u0 = *(const f32x4_t*)(bias_s + cg * 8), u1 = *(const f32x4_t*)(bias_s + cg * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b8[e] = u0[e], b8[4 + e] = u1[e];
+  }
   // Fast path (every UNet launch that reaches this kernel): fp16 output and residual with 16-byte accesses, activation none / SiLU, and a
   // row bias (time embedding) that is constant over the tile.  Everything it needs from the descriptor is copied into locals FIRST: read
   // through `p` inside the unit loop the fields were re-fetched from the kernarg segment (s_load + wait, a few hundred cycles each, ten per
   // unit) -- the generic epilogue8 path cost 8 us of a 23 us 32768x320x320 launch, against 3 us for the stores themselves.
-  const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + (CONV ? ((int64_t)(R - 1) * W + TW - 1) : BM - 1)) / p.rows_per_group);
-  const bool fast = p.c_dtype == TB_F16 && ef.c_vec && (!p.R || (ef.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
-                    !p.C2 && rb_uniform;
+  if (!CONV) {
+    const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + BM - 1) / p.rows_per_group);
+    fast = p.c_dtype == TB_F16 && ef.c_vec && (!p.R || (ef.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
+           !p.C2 && rb_uniform;
+  }
   // GEGLU forward (ff.net.0.proj, packed [h32 | g32] column blocks): unit = (row, 8 gate outputs); stores the fp16 projections (C2, for the
   // backward) and h * gelu(g).  Host guarantees: Linear tile (BN a multiple of 64), no residual / row bias, fp16 vector-aligned outputs.
   if (!CONV && p.act == TB_ACT_GEGLU) {
@@ -405,11 +451,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     float bh[8], bg[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      bh[e] = p.bias ? p.bias[nh + e] : 0.f;
-      bg[e] = p.bias ? p.bias[nh + 32 + e] : 0.f;
+      bh[e] = bias_s[hcol + e];
+      bg[e] = bias_s[hcol + 32 + e];
     }
     f16* const C2g = p.C2 ? (f16*)p.C2 + nh : nullptr;
     f16* const Cg = (f16*)p.C + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
+    G8_STAMP(7)
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rp = pass * PR;
@@ -420,7 +467,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           for (int j = 0; j < NT; ++j)
             *(f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15 - rp) * LDC + (wn * NT + j) * 16 + 4 * lq) = acc[i][j];
       }
+      if (pass == 0) { G8_STAMP(4) }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (pass == 0) { G8_STAMP(5) }
       if (rs < TG) {
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
@@ -434,8 +483,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
             for (int e = 0; e < 8; ++e) {
               oh[e] = (f16)(alpha * (e < 4 ? h0[e] : h1[e - 4]) + bh[e]);
               og8[e] = (f16)(alpha * (e < 4 ? g0[e] : g1[e - 4]) + bg[e]);
-              oo[e] = (f16)((float)oh[e] * gelu_erf_f((float)og8[e]));  // gate on the fp16-rounded projections, as an fp16 module would
+              oo[e] = (f16)((float)oh[e] * ((G8_ABL & 16) ? (float)og8[e] : gelu_erf_f((float)og8[e])));  // gate on the fp16-rounded projections, as an fp16 module would
             }
+            if ((G8_ABL & 8) && alpha != 12345.f) continue;  // profiling: no global stores
             if (C2g) {
               *(f16x8*)(C2g + m * ldc2) = oh;
               *(f16x8*)(C2g + m * ldc2 + 32) = og8;
@@ -446,6 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       }
       if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    G8_STAMP(3)
     return;
   }
   // GEGLU backward fused into the ff.net.2 dgrad GEMM: v = d(gated)[m, n..n+7]; C2 = packed pre-gate projections [M, 2N];
@@ -487,8 +538,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
             for (int e = 0; e < 8; ++e) {
               const float v = (e < 4 ? c0[e] : c1[e - 4]) * alpha + b8[e];
               const float g = (float)gv[it][e];
-              dh[e] = (f16)(v * gelu_erf_f(g));
-              dg[e] = (f16)(v * (float)hv[it][e] * gelu_erf_grad_f(g));
+              float ge, dge;
+              gelu_erf_both_f(g, ge, dge);
+              dh[e] = (f16)(v * ge);
+              dg[e] = (f16)(v * (float)hv[it][e] * dge);
             }
             *(f16x8*)(Cg + m * ldc) = dh;
             *(f16x8*)(Cg + m * ldc + 32) = dg;
@@ -505,12 +558,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     f16* const Cg = (f16*)p.C + n;
     const f16* const Rg = p.R ? (const f16*)p.R + n : nullptr;
     const int64_t ldc = p.ldc, ldr = p.ldr, Mtot = p.M;
-    if (p.rowbias) {
+    if (!CONV && p.rowbias) {  // (conv: folded into b8 before the main loop)
       const float* rb = p.rowbias + (m0 / p.rows_per_group) * p.ldrb + n;
 #pragma unroll
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
     }
-#pragma unroll 1
+    auto m_row = [&](int r) -> int64_t { return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r; };
+    f16x8 rv1[NU];  // second pass: its residual rows are requested before the first pass is staged
+    if (PASSES == 2 && Rg && rslot < TPR) {
+#pragma unroll
+      for (int it = 0; it < NU; ++it) {
+        const int64_t m = min(m_row(PR + min(rslot + it * TPR, PR - 1)), Mtot - 1);
+        rv1[it] = *(const f16x8*)(Rg + m * ldr);
+      }
+    }
+#pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rp = pass * PR;
       if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
@@ -527,8 +589,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         const int r = rp + row;
         return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r;
       };
-      f16x8 rv[NU];  // all residual loads of the pass are in flight across the staging barrier
-      if (Rg && rslot < TPR) {
+      f16x8 rv[NU];
+      if (pass == 1 || pre_r) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) rv[it] = pass ? rv1[it] : rv0[PRE_R ? it : 0];
+      } else if (Rg && rslot < TPR) {  // conv: not prefetched (no registers to spare across the main loop)
 #pragma unroll
         for (int it = 0; it < NU; ++it) {
           const int64_t m = min(m_of(min(rslot + it * TPR, PR - 1)), Mtot - 1);
@@ -552,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
               if (silu) x = silu_f(x);
               o[e] = (f16)x;
             }
-            *(f16x8*)(Cg + m * ldc) = o;
+            if (!(G8_ABL & 8) || alpha == 12345.f) *(f16x8*)(Cg + m * ldc) = o;
           }
         }
       }
@@ -624,6 +689,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift) {
   if (CONV && (a_rows8 >> 3) > 8 * 7) return 1;  // more panel load instructions than the kernel issues
   size_t lds = (size_t)(CONV ? 2 : NS) * a_rows8 * 128 + (size_t)NS * BN * 128;
   if (lds < G8Epi<BM, BN>::BYTES) lds = G8Epi<BM, BN>::BYTES;
+  if (!CONV) lds += BN * 4;  // the tile's bias values
   if (lds > 160 * 1024) return 1;
   static bool attr_done = false;
   if (!attr_done) {
@@ -692,6 +758,12 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     return 1;
   }
   if (!(g8_enable & 2)) return 1;
+  // GEGLU / GEGLU-backward layers (K = 320 .. 1280, N = 8 K or 4 K): 5 .. 20 k-steps in front of an epilogue that moves 3 .. 5 bytes per
+  // output, eight or more tiles per CU.  128x128 tiles at 64 KB of LDS put TWO workgroups on a CU, so one's epilogue (stores, gelu) runs
+  // under the other's main loop -- with one resident 128x320 tile per CU the two phases simply alternated (21 us per tile, 3 of them MFMA).
+  if ((d.act == TB_ACT_GEGLU || d.act == TB_ACT_GEGLU_GRAD) && !(g8_enable & 16) && d.N % 128 == 0 && d.M % 128 == 0 &&
+      (d.M / 128) * (d.N / 128) >= 512)
+    return launch8<2, 4, 4, 2, false, 2>(d, s, 30);
   if (d.N % 320) return 1;
   if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);

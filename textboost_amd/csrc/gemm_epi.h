@@ -153,8 +153,10 @@ __device__ __forceinline__ void epilogue8(const tb_gemm_desc& p, const EpiFlags&
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float g = (float)gg[e];
-      dh[e] = (f16)(v[e] * gelu_erf_f(g));
-      dg[e] = (f16)(v[e] * (float)hh[e] * gelu_erf_grad_f(g));
+      float ge, dge;
+      gelu_erf_both_f(g, ge, dge);
+      dh[e] = (f16)(v[e] * ge);
+      dg[e] = (f16)(v[e] * (float)hh[e] * dge);
     }
     if (f.c_vec) {
       *(f16x8*)c = dh;
