@@ -208,6 +208,7 @@ def test_geglu_forward_and_backward_epilogues_on_the_wide_tile_kernel(M, C):
     W = (torch.randn(8 * C, C, device="cuda") / C ** 0.5).half()
     b = torch.randn(8 * C, device="cuda")
     outs = []
+    default_bits = L.lib().tb_gemm8_set(7)
     for bits in (7, 0):
         L.lib().tb_gemm8_set(bits)
         out = torch.empty(M, 4 * C, device="cuda", dtype=torch.float16)
@@ -216,7 +217,7 @@ def test_geglu_forward_and_backward_epilogues_on_the_wide_tile_kernel(M, C):
         used = L.lib().tb_gemm8_last(None)
         assert bool(used) == (bits == 7)
         outs.append((out, raw))
-    L.lib().tb_gemm8_set(7)
+    L.lib().tb_gemm8_set(default_bits)
     proj = A.float() @ W.float().T + b
     h, g = proj.chunk(2, dim=-1)
     ref = h * F.gelu(g)
@@ -234,7 +235,7 @@ def test_geglu_forward_and_backward_epilogues_on_the_wide_tile_kernel(M, C):
         ops.gemm(dY, Wd, dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
         assert bool(L.lib().tb_gemm8_last(None)) == (bits == 7)
         res.append(dproj)
-    L.lib().tb_gemm8_set(7)
+    L.lib().tb_gemm8_set(default_bits)
     dgated = dY.float() @ Wd.float().T
     unpack = lambda t: torch.cat([t.view(M, -1, 2, 32)[:, :, 0].reshape(M, -1), t.view(M, -1, 2, 32)[:, :, 1].reshape(M, -1)], dim=1)
     pr = unpack(raw.float()).requires_grad_(True)
@@ -242,3 +243,38 @@ def test_geglu_forward_and_backward_epilogues_on_the_wide_tile_kernel(M, C):
     (hh * F.gelu(gg)).backward(dgated)
     for dproj in res:
         assert rel_err(unpack(dproj.float()), pr.grad) < 3e-3
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(8, 640, 640, 16), (8, 1280, 1280, 16), (8, 2560, 1280, 16), (4, 1280, 640, 32)])
+def test_conv3x3_wide_tile_split_k(B, Cin, Cout, H):
+    """16x16 / small-batch maps give too few 256 x 160 tiles for the chip: gemm8_kernel splits the channel chunks over S workgroups per tile
+    (fp32 partials + splitk_reduce_kernel).  Forward with bias, SiLU-free residual epilogue and dgrad, against F.conv2d and the 4-wave path."""
+    ops, L = _ops()
+    torch.manual_seed(11)
+    x = torch.randn(B, Cin, H, H, device="cuda").half()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    res = torch.randn(B * H * H, Cout, device="cuda").half()
+    xn = nhwc(x).view(B * H * H, Cin)
+    geo = dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+    default_bits = L.lib().tb_gemm8_set(39)
+    outs = []
+    for bits in (39, 7, 0):
+        L.lib().tb_gemm8_set(bits)
+        out = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.float16)
+        ops.gemm(xn, pack_conv_w(w), out, bias=bias, R=res, conv=geo)
+        if bits == 39:
+            assert L.lib().tb_gemm8_last(None), "the split-K wide-tile path did not take this shape"
+        outs.append(out)
+    ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * H, Cout) + res.float()
+    for o in outs:
+        assert rel_err(o, ref) < 2e-3
+    assert rel_err(outs[0], outs[2]) < 1e-3
+    dy = torch.randn(B, Cout, H, H, device="cuda").half()
+    geo = dict(B=B, Hin=H, Win=H, Cin=Cout, Hout=H, Wout=H, stride=1, sign=-1, upsample=0, transposed=0)
+    L.lib().tb_gemm8_set(39)
+    dx = torch.empty(B * H * H, Cin, device="cuda", dtype=torch.float16)
+    ops.gemm(nhwc(dy).view(B * H * H, Cout), pack_conv_w_dgrad(w), dx, conv=geo)
+    L.lib().tb_gemm8_set(default_bits)
+    refd = nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1))
+    assert rel_err(dx.view(B, H, H, Cin), refd) < 2e-3

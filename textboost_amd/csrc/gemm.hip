@@ -949,6 +949,7 @@ extern "C" int tb_gemm_set_variant(int v) {
 }
 
 int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s);  // gemm8.hip: 8-wave wide tiles for the large-M levels; 1 = shape not covered
+int tb_gemm8_last_split();                                // ... k-slices of that launch (> 1: fp32 partials in d.ws)
 
 extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
@@ -985,6 +986,13 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   }
   {
     const int r8 = tb_gemm8_try(d, s);
+    if (r8 == TB_OK && tb_gemm8_last_split() > 1) {
+      const int64_t npad = (d.N + 7) & ~(int64_t)7;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws,
+                         tb_gemm8_last_split(), npad);
+      TB_CHECK_LAUNCH();
+      return TB_OK;
+    }
     if (r8 != 1) return r8;
   }
   if (d.act == TB_ACT_GEGLU) {

@@ -100,7 +100,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 // WM x WN waves (WM * WN == 8), each wave (16 MT) x (16 NT) outputs; CONV: 3x3 stride-1 halo convolution, else A rows linear
 template <int WM, int WN, int MT, int NT, bool CONV, int NS>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int a_rows8,
-                                                          unsigned long long* dbg) {
+                                                          unsigned long long* dbg, int S, float* __restrict__ ws, int64_t npad, int xn) {
   static_assert(WM * WN == 8, "8 waves");
 #define G8_STAMP(k)                                                                                  \
   if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                  \
@@ -121,13 +121,34 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   const int a_elems = a_rows8 * BK;
   f16* const Ws = As + NA * a_elems;
 
-  const int nwg = tiles_m * tiles_n;
-  int tile;
-  {
+  // S > 1 (conv only): split-K over the 64-channel chunks -- the S slices of a tile are separate workgroups that store raw fp32 partials to
+  // ws[slice][M][npad]; gemm.hip's splitk_reduce_kernel sums them and applies the epilogue.  For the 16x16 maps (M = 2048: 64 tiles of 256 x 160)
+  // Workgroup -> tile, XCD-aware (workgroup b runs on XCD b & 7, each XCD has its own L2).  xn > 0: the tile grid is cut into (8 / xn) x xn
+  // rectangles, one per XCD, so an XCD fetches 1 / (8 / xn) of the activations and 1 / xn of the weights (host: launch8 picks the cut with the
+  // least fabric traffic -- with row panels per XCD, the 16x16-map layers pulled the whole 26..30 MB weight matrix into every L2: 215 MB for a
+  // 31 MB GEGLU projection).  xn == 0: contiguous runs of row panels (grids that do not divide evenly).
+  int tm, tn, slice = 0;
+  if (xn > 0) {
+    const int bid = blockIdx.x, xcd = bid & 7;
+    int j = bid >> 3;
+    if (S > 1) {
+      slice = j % S;
+      j /= S;
+    }
+    const int rn = tiles_n / xn, rm = tiles_m / (8 / xn);
+    const int jm = j / rn;
+    tm = (xcd / xn) * rm + jm;
+    tn = (xcd % xn) * rn + (j - jm * rn);
+  } else {
+    const int nwg = tiles_m * tiles_n * S;
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (S > 1) {
+      slice = tile % S;
+      tile /= S;
+    }
+    tm = tile / tiles_n, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
   }
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
   const int64_t n0 = (int64_t)tn * BN;
   // Linear tiles: the BN bias values go through a small LDS array filled under the prologue loads.  Loaded at the point of use (after the main
   // loop) they queued behind the CU's in-flight stores and operand loads: 8300 cycles of a 35000-cycle 128x128x320 GEGLU tile were this wait.
@@ -222,7 +243,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     w_off[i] = (uint32_t)((n * p.ldw + ((cp ^ (row & 7)) << 3)) * 2);
   }
   const int kpt = CONV ? p.Cin / BK : 1;                 // k-tiles per tap
-  const int nchunk = CONV ? kpt : (int)(p.K / BK);
+  const int nchunk_all = CONV ? kpt : (int)(p.K / BK);
+  const int c_begin = S > 1 ? nchunk_all * slice / S : 0;
+  const int nchunk = S > 1 ? nchunk_all * (slice + 1) / S : nchunk_all;  // end of this workgroup's chunk range [c_begin, nchunk)
 
   auto stage_a_piece = [&](int c, int i) {  // one load instruction of chunk c's panel
     const int j = wave + 8 * i;
@@ -291,11 +314,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   int cnt_prev = 0;
   if (CONV) {
 #pragma unroll
-    for (int i = 0; i < MAXHI; ++i) stage_a_piece(0, i);
+    for (int i = 0; i < MAXHI; ++i) stage_a_piece(c_begin, i);
   }
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st) {  // stages 0 .. NS-2; the youngest one's loads may stay in flight at step 0 (NS = 3)
-    const int lc = st / TAPS, ltap = st % TAPS;
+    const int lc = c_begin + st / TAPS, ltap = st % TAPS;
     cnt_prev = lc < nchunk ? n_w + (CONV ? 0 : n_a) : 0;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k)
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   if (group == 1) asm volatile("s_barrier" ::: "memory");  // phase shift of the second wave group
   const uint32_t as_addr = lds_addr(As), ws_addr = lds_addr(Ws);
   int lin_slot = 0, lin_lslot = (NS - 1) % NS;  // Linear: ring slots of the current / the loaded stage (conv: tap % NS, compile-time)
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = c_begin; c < nchunk; ++c) {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       constexpr int dummy_ = 0;
@@ -424,6 +447,36 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // ---- epilogue: accumulators -> padded fp32 tile in LDS -> (row, 8 columns) units with 16-byte global accesses.  A thread keeps ONE
   // column group (bias loaded once) and walks rows; all residual / auxiliary loads of its units are issued before the arithmetic.
   float* Cs = reinterpret_cast<float*>(smem_raw);
+  if (CONV && S > 1) {  // raw fp32 partial of this k-slice
+    float* const dst0 = ws + (int64_t)slice * p.M * npad + n;
+    const int64_t Mtot = p.M;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int rp = pass * PR;
+      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            *(f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15 - rp) * LDC + (wn * NT + j) * 16 + 4 * lq) = acc[i][j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (rslot < TPR) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const int row = rslot + it * TPR, r = rp + row;
+          const int64_t m = m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1));
+          if (row < PR && m < Mtot) {
+            float* dst = dst0 + m * npad;
+            *(f32x4_t*)dst = *(const f32x4_t*)(Cs + row * LDC + cg * 8);
+            *(f32x4_t*)(dst + 4) = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+          }
+        }
+      }
+      if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    return;
+  }
   const EpiFlags ef = epi_flags(p);
   const bool pre_r = PRE_R && p.R && ef.r_vec && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU);
   if (!CONV && p.act != TB_ACT_GEGLU) {
@@ -671,13 +724,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 }
 
 unsigned long long* g8_dbg = nullptr;  // profiling aid (tb_gemm8_debug): s_memtime stamps of the first and the last block
-int g8_enable = 7;   // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers, 4 = GEGLU / GEGLU-backward epilogues take the wide-tile path
+int g8_enable = 39;  // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers, 4 = GEGLU / GEGLU-backward epilogues take the wide-tile path
+int g8_split = 1;    // k-slices of the most recent launch: > 1 -> the caller (tb_gemm) runs splitk_reduce_kernel next
 int g8_last[7] = {0, 0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
 template <int WM, int WN, int MT, int NT, bool CONV, int NS>
-int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift) {
+int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
   const int tiles_m = (int)(d.M / BM), tiles_n = (int)(d.N / BN);
+  const int64_t npad = (d.N + 7) & ~(int64_t)7;
+  if (S > 1 && (!CONV || !d.ws || (size_t)S * (size_t)d.M * (size_t)npad * 4 > d.ws_bytes)) return 1;
   int a_rows;
   if (CONV) {
     const int TW = 1 << wshift, R = BM >> wshift;
@@ -698,9 +754,21 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift) {
       return TB_ELAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), lds, s, d, tiles_m, tiles_n,
-                     wshift, a_rows8, g8_dbg);
+  // XCD cut (see the kernel): fabric bytes = xn * A + (8 / xn) * W over the cuts that divide the tile grid
+  int xn = 0;
+  if (!(g8_enable & 64)) {
+    const double a_bytes = 2.0 * (double)d.M * (CONV ? d.Cin : d.K), w_bytes = 2.0 * (double)d.N * d.K;
+    double best = (a_bytes + 8 * w_bytes) / 1.5;  // row panels per XCD (xn = 0 / 1) unless a cut saves a third of the traffic: on the
+    for (int c = 2; c <= 8; c *= 2) {             // 32x32 maps, where the two operands are the same size, the 4 x 2 cut measured 8 % slower
+      if (tiles_n % c || tiles_m % (8 / c)) continue;
+      const double cost = c * a_bytes + (8 / c) * w_bytes;
+      if (cost < best) xn = c, best = cost;
+    }
+  }
+  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
+                     wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn);
   TB_CHECK_LAUNCH();
+  g8_split = S;
   g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
   return TB_OK;
 }
@@ -729,8 +797,11 @@ extern "C" int tb_gemm8_last(int* out5 /* 6 ints */) {
 }
 
 // returns TB_OK when the launch was taken, 1 when the shape is not covered (the caller falls back to gemm.hip), < 0 on error
+int tb_gemm8_last_split() { return g8_split; }  // k-slices of the launch tb_gemm8_try just made (> 1: partials are in d.ws, reducer due)
+
 int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   g8_last[0] = 0;
+  g8_split = 1;
   if (!g8_enable) return 1;
   if (d.A2 || d.W2) return 1;
   if (d.act == TB_ACT_GEGLU || d.act == TB_ACT_GEGLU_GRAD) {  // lean fused epilogues exist for the aligned fp16 Linear case only
@@ -754,6 +825,13 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     if (256 % TW == 0 && d.Hout % (256 / TW) == 0 && d.M % 256 == 0) {
       if (d.N % 160 == 0 && (d.M / 256) * (d.N / 160) >= 200) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift);
       if (d.N % 80 == 0 && (d.M / 256) * (d.N / 80) >= 200) return launch8<8, 1, 2, 5, true, 3>(d, s, wshift);
+      // too few tiles for the chip (16x16 maps: 8 x 8 tiles of 256 x 160): split the channel chunks over S workgroups per tile
+      if (d.N % 160 == 0 && (g8_enable & 32)) {
+        const int tiles = (int)((d.M / 256) * (d.N / 160)), kpt = d.Cin / 64;
+        int S = (230 + tiles - 1) / tiles;
+        while (S > 1 && kpt / S < 2) --S;
+        if (S > 1 && tiles * S >= 128) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift, S);
+      }
     }
     return 1;
   }
