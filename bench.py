@@ -30,8 +30,18 @@ def roofline_leg(step):
     torch.cuda.synchronize()
     world, force = step.world, step.force_dist
     step.world, step.force_dist = 1, False  # rank 0 runs this leg alone: no collective may be issued here
+    # The eager launches come out of Python ~20 us apart, shorter than most kernels' gaps: with an idle GPU an event pair would also time the
+    # host gap between `record` and the launch (a 17 us GEMM read 33 us).  A spin kernel queued first keeps the stream busy while the whole
+    # step is enqueued behind it, so every event pair brackets its kernel back to back on the device, as in the graph replay.
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    torch.cuda._sleep(2_000_000)
+    t1.record()
+    torch.cuda.synchronize()
+    cycles_per_ms = 2_000_000 / max(t0.elapsed_time(t1), 1e-3)
     ops.start_recording()
     try:
+        torch.cuda._sleep(int(cycles_per_ms * 600.0))  # ~0.6 s: an eager step with events is enqueued in ~0.2 s of host time
         step.step_eager()
         torch.cuda.synchronize()
     finally:

@@ -187,11 +187,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // Early epilogue operands (a global load issued after the main loop queues behind the CU's own stores and operand traffic for microseconds).
   // conv: bias, plus the time-embedding row bias when it is constant over the tile, stay in 8 registers across the main loop;
   // Linear: bias goes through bias_s (above) and the residual rows of the first staging pass are fetched now into NU x 4 registers.
-  constexpr bool PRE_R = !CONV && BM * BN > 128 * 128;  // (the 128x128 tile must stay under 128 registers: two workgroups per CU)
+  constexpr bool PRE_R = !CONV && BM * BN > 128 * 160;  // (the 128x128 tile must stay under 128 registers: two workgroups per CU)
+  constexpr bool PRE_B = CONV && MT < 4;  // (the 256x160 conv tile sits at 254 of 256 registers already: its bias is loaded in the epilogue)
   float b8[8];
   f16x8 rv0[PRE_R ? NU : 1];
   bool fast = false;
-  if (CONV) {
+  if (PRE_B) {
     const EpiFlags ef0 = epi_flags(p);
     const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + ((int64_t)(R - 1) * W + TW - 1)) / p.rows_per_group);
     fast = p.c_dtype == TB_F16 && ef0.c_vec && (!p.R || (ef0.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
@@ -488,10 +489,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // row bias (time embedding) that is constant over the tile.  Everything it needs from the descriptor is copied into locals FIRST: read
   // through `p` inside the unit loop the fields were re-fetched from the kernarg segment (s_load + wait, a few hundred cycles each, ten per
   // unit) -- the generic epilogue8 path cost 8 us of a 23 us 32768x320x320 launch, against 3 us for the stores themselves.
-  if (!CONV) {
-    const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + BM - 1) / p.rows_per_group);
+  if (!PRE_B) {
+    const int64_t m_last = CONV ? m0 + ((int64_t)(R - 1) * W + TW - 1) : m0 + BM - 1;
+    const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == m_last / p.rows_per_group);
     fast = p.c_dtype == TB_F16 && ef.c_vec && (!p.R || (ef.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
            !p.C2 && rb_uniform;
+    if (CONV) epi_load_bias8(p, n, b8);
   }
   // GEGLU forward (ff.net.0.proj, packed [h32 | g32] column blocks): unit = (row, 8 gate outputs); stores the fp16 projections (C2, for the
   // backward) and h * gelu(g).  Host guarantees: Linear tile (BN a multiple of 64), no residual / row bias, fp16 vector-aligned outputs.
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     f16* const Cg = (f16*)p.C + n;
     const f16* const Rg = p.R ? (const f16*)p.R + n : nullptr;
     const int64_t ldc = p.ldc, ldr = p.ldr, Mtot = p.M;
-    if (!CONV && p.rowbias) {  // (conv: folded into b8 before the main loop)
+    if (!PRE_B && p.rowbias) {  // (PRE_B: folded into b8 before the main loop)
       const float* rb = p.rowbias + (m0 / p.rows_per_group) * p.ldrb + n;
 #pragma unroll
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
@@ -842,6 +845,11 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   if ((d.act == TB_ACT_GEGLU || d.act == TB_ACT_GEGLU_GRAD) && !(g8_enable & 16) && d.N % 128 == 0 && d.M % 128 == 0 &&
       (d.M / 128) * (d.N / 128) >= 512)
     return launch8<2, 4, 4, 2, false, 2>(d, s, 30);
+  // short-K layers wider than one 320-column tile (qkv N = 3 C, K = C): several tiles per CU, each a handful of k-steps between a prologue and
+  // an epilogue -- 128x160 tiles at 72 KB keep two workgroups on the CU so those phases overlap (as for the GEGLU layers above)
+  if (!(g8_enable & 128) && d.act != TB_ACT_GEGLU && d.act != TB_ACT_GEGLU_GRAD && d.K <= 640 && (d.N > 320 || (g8_enable & 256)) && d.N % 160 == 0 && d.M % 128 == 0 &&
+      (d.M / 128) * (d.N / 160) >= 512)
+    return launch8<4, 2, 2, 5, false, 2>(d, s, 30);
   if (d.N % 320) return 1;
   if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);

@@ -113,7 +113,9 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
     d.ws, d.ws_bytes = L.ptr(ws), ws.numel() * 4
     # algorithmic bytes: every operand read once, the output written once (conv: the input image once, not once per tap)
     a_elems = M * conv["Cin"] if conv is not None else M * d.K
-    alg_bytes = 2.0 * (a_elems + N * d.K) + M * N * out.element_size() + (M * N * R.element_size() if R is not None else 0)
+    # GEGLU writes [M, N/2] gated values plus the [M, N] pre-gate projections (C2); GEGLU_GRAD reads those and writes [M, 2N]
+    alg_bytes = (2.0 * (a_elems + N * d.K) + M * out.shape[1] * out.element_size() + (M * N * R.element_size() if R is not None else 0)
+                 + (C2.shape[0] * C2.shape[1] * C2.element_size() if C2 is not None else 0))
     with _rec("gemm", 2.0 * M * N * d.K, alg_bytes) as r:
         L.check(L.lib().tb_gemm(d, L.stream()), "tb_gemm")
         if _REC is not None:  # name the launch exactly as rocprofv3 prints the kernel
