@@ -72,7 +72,9 @@ int tb_gemm_set_variant(int v);
 /* {BM, BN, a_mode, k_tile*10 + stages, split_k} of the most recent tb_gemm launch (profiling aid) */
 void tb_gemm_last_config(int* out5);
 /* 8-wave wide-tile path of tb_gemm (csrc/gemm8.hip; 256-pixel x 160-channel halo convolutions and 128 x 320 Linear tiles for the
- * 64x64 / 32x32 feature maps): tb_gemm8_set(bits) -- 1 = convolutions, 2 = Linear layers, 4 = fused GEGLU epilogues, default 7 -- returns the previous value;
+ * 64x64 / 32x32 / 16x16 feature maps): tb_gemm8_set(bits) -- 1 = convolutions, 2 = Linear layers, 4 = fused GEGLU epilogues, 32 = split-K for
+ * small conv grids (default 39); A/B switches: 8 = 64x320 instead of 128x320 Linear tiles, 16 = GEGLU layers on 128x320 tiles, 64 = no XCD rectangle
+ * cut, 128 = no 128x160 tiles, 256 = 128x160 tiles also for N = 320 -- returns the previous value;
  * tb_gemm8_last returns 1 when the most recent tb_gemm launched gemm8_kernel<WM, WN, MT, NT, CONV, NS> and writes those SIX ints to out5 */
 int tb_gemm8_set(int bits);
 int tb_gemm8_last(int* out5);
