@@ -242,3 +242,48 @@ def test_sd21_unet_at_96x96_latents_vs_oracle():
     parity("SD2.1 UNet pred @96x96", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
     d_ehs = hip.backward(dpred.to(dev))
     parity("SD2.1 UNet d_ehs @96x96", d_ehs.view(B, 77, 1024), ehs.grad, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
+
+
+def test_batch_16_equals_two_batches_of_8():
+    """BASELINE.json configs[4] batch (B=16, 64x64 latents, SD1.5): samples are independent, so the UNet forward and its dgrad backward at
+    B=16 must reproduce two B=8 runs on the halves -- with M doubled most layers select other tiles / split factors, so this is a parity
+    check of those kernels against the B=8 ones that the oracle tests pin (fp32 summation order differs: tolerance, not bit equality)."""
+    from textboost_amd import models
+    from textboost_amd.unet import HipUNet
+    torch.manual_seed(0)
+    dev = torch.device("cuda", 0)
+    sd = models.random_state_dict(models.unet_shapes(models.SD15_UNET), 78, device="cpu")
+    sd = {k: v.half().float() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 4, 64, 64, generator=g).half()
+    t = torch.randint(0, 1000, (16,), generator=g)
+    ehs = torch.randn(16 * 77, 768, generator=g).half()
+    dpred = torch.randn(16, 4, 64, 64, generator=g)
+    hip16 = HipUNet(models.SD15_UNET, {k: v.to(dev) for k, v in sd.items()}, 16, 64, 64, device=dev)
+    pred16 = hip16.forward(x.to(dev), t.to(dev), ehs.to(dev)).float().clone()
+    dehs16 = hip16.backward(dpred.to(dev)).float().clone()
+    del hip16
+    torch.cuda.empty_cache()
+    hip8 = HipUNet(models.SD15_UNET, {k: v.to(dev) for k, v in sd.items()}, 8, 64, 64, device=dev)
+    for h in range(2):
+        sl = slice(8 * h, 8 * h + 8)
+        pred8 = hip8.forward(x[sl].to(dev), t[sl].to(dev), ehs[8 * h * 77:(8 * h + 8) * 77].to(dev).contiguous()).float()
+        parity(f"B=16 vs B=8 pred, half {h}", pred16[sl], pred8, rel=1e-3, maxabs=2e-3, ch_dim=1, ch_rel=2e-3)
+        dehs8 = hip8.backward(dpred[sl].to(dev)).float()
+        parity(f"B=16 vs B=8 d_ehs, half {h}", dehs16[8 * h * 77:(8 * h + 8) * 77], dehs8, rel=2e-3, maxabs=4e-3)
+
+
+def test_step_invariants_at_batch_16():
+    """the whole step at B=16 (configs[4] batch): graph replay == eager bit for bit, finite losses, masked rows only decay."""
+    from textboost_amd.workload import build_step
+    torch.manual_seed(43)
+    step, added = build_step(batch=16, latent=64)
+    te = step.te
+    w0 = te.token_table.clone()
+    step.step_eager()
+    torch.cuda.synchronize()
+    sc = step.scalars()
+    assert sc["found_inf"] == 0.0 and sc["opt_steps"] == 1.0 and 0.5 < sc["loss_mse"] < 2.0
+    first = te.first_added
+    torch.testing.assert_close(te.token_table[:first], w0[:first] * (1 - 1e-3 * 1e-2), rtol=2e-6, atol=0)
+    assert torch.isfinite(te.token_table[first:]).all() and torch.isfinite(te.lora_B).all()
