@@ -219,6 +219,9 @@ def main():
                     help="secondary measurement (implies --vae): every step ALSO runs the reference's per-sample dataset work on the device -- "
                          "template draw, PairedAugmentation (p=0.8, inversion), Resize(512, LANCZOS), RandomCrop, normalise, tokenise "
                          "(textboost/dataset.py:353-381; SURVEY 8(f).3) -- from two resident synthetic 1536x2048 instance images")
+    ap.add_argument("--fp8-attn", action="store_true",
+                    help="BASELINE.json configs[4]: e4m3 P.V in the forward of the hd = 40 self-attention layers (secondary measurement; "
+                         "the metric's numerics are fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -253,7 +256,8 @@ def main():
         args.latent = 96 if sd21 else 64
     step, added = build_step(batch=args.batch, latent=args.latent, data_seed=1000 + rank, world_size=world,
                              device=torch.device("cuda", local), unet_geo=models.SD21_UNET if sd21 else models.SD15_UNET,
-                             clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4, with_vae=args.vae)
+                             clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4, with_vae=args.vae,
+                             attn_fp8=args.fp8_attn)
     step.force_dist = force_dist
     feed = None
     if args.feeder:
@@ -315,6 +319,9 @@ def main():
             metric = metric[:-1] + " + device feeder)"
             workload += ("; PLUS, every step, the dataset work of textboost/dataset.py:353-381 for the batch on the device: PairedAugmentation "
                          "(p=0.8, inversion), Lanczos resize 1536x2048 -> 512, RandomCrop, normalise, prompt tokenisation (word-hash stand-in, cached)")
+        if args.fp8_attn:
+            metric = metric[:-1] + ", fp8 P.V in the self-attention forward)"
+            workload += "; e4m3 P.V (v_mfma_scale_f32_32x32x64_f8f6f4) in the forward of the 64x64-map self-attention layers (BASELINE.json configs[4])"
         if sd21:  # secondary measurement; algorithmic FLOP taken from the recorded launches of the eager leg
             metric = "train steps/sec (batch=%d, SD2.1 shapes, %d^2 latents, LoRA r=8)" % (args.batch, args.latent)
             workload = ("SURVEY 8(d) config 4: SD2.x UNet (865.9M, Linear proj_in/out, head dim 64) + OpenCLIP-H text encoder (23 layers, "

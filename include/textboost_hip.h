@@ -133,7 +133,13 @@ typedef struct tb_attn_desc {
   float* ws; int64_t ws_floats;  /* optional scratch (n * 2*B*Skv*H*hd floats, n >= 2): lets the dK/dV kernel split the query
                                   * range over up to n blocks per key block (per-slice fp32 partials summed in a fixed order)
                                   * when Skv is too short to fill the chip (cross-attention) */
+  void* fp8_ws; int64_t fp8_ws_bytes;  /* forward only, opt-in (BASELINE.json configs[4]): non-NULL with >= tb_attention_fp8_ws_bytes(B, H, Skv)
+                                        * bytes makes the hd = 40 self-attention forward (Sq % 256 == 0, Skv % 256 == 0, non-causal) compute
+                                        * P V with e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (P rounded in registers, V through a
+                                        * per-(batch, head) scaled transposed image in this workspace); other shapes ignore it.  Tolerance
+                                        * against fp32 attention: rel-L2 <= 5e-2 on O (3.6e-2 measured on random data, tests/test_gpu_norm_attn.py) vs 2e-3 for the fp16 path */
 } tb_attn_desc;
+int64_t tb_attention_fp8_ws_bytes(int B, int H, int Skv);
 int tb_attention_fwd(const tb_attn_desc* d, tb_stream_t stream);
 int tb_attention_bwd(const tb_attn_desc* d, tb_stream_t stream);
 /* A/B knob: bit 0 = LDS-DMA staged forward kernel for the hd = 40 / 80 self-attention shapes (default on); returns the previous value */

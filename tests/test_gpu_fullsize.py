@@ -45,6 +45,17 @@ def test_sd15_unet_full_size_forward_backward_vs_oracle():
     parity("SD1.5 UNet pred", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
     d_ehs = hip.backward(dpred.to(dev))
     parity("SD1.5 UNet d_ehs", d_ehs.view(B, 77, 768), ehs.grad, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
+    # BASELINE.json configs[4]: the same UNet with e4m3 P.V in the forward of its five 64x64-map self-attention layers (opt-in).  The
+    # attention outputs themselves are 3.6e-2 off on random data (tests/test_gpu_norm_attn.py), but they enter a residual stream that
+    # dominates them: on the whole model the mode measures 1.13e-3 (fp16 path 1.09e-3) -- held to 4e-3 / 6e-3 here.
+    pred16 = pred.float().clone()
+    del hip
+    torch.cuda.empty_cache()
+    hip8 = HipUNet(models.SD15_UNET, {k: v.to(dev) for k, v in sd.items()}, B, 64, 64, device=dev, attn_fp8=True)
+    pred8 = hip8.forward(x.half().to(dev), t.to(dev), ehs.detach().half().view(B * 77, 768).to(dev).contiguous())
+    assert not torch.equal(pred8.float(), pred16), "the fp8 attention path did not run"
+    parity("SD1.5 UNet pred, fp8 P.V", pred8, pred_ref, rel=4e-3, maxabs=6e-3, ch_dim=1, ch_rel=6e-3)
+    parity("SD1.5 UNet d_ehs, fp8 P.V", hip8.backward(dpred.to(dev)).view(B, 77, 768), ehs.grad, rel=6e-3, maxabs=8e-3)
 
 
 def test_clip_l_full_size_forward_backward_vs_oracle():
@@ -247,7 +258,8 @@ def test_sd21_unet_at_96x96_latents_vs_oracle():
 def test_batch_16_equals_two_batches_of_8():
     """BASELINE.json configs[4] batch (B=16, 64x64 latents, SD1.5): samples are independent, so the UNet forward and its dgrad backward at
     B=16 must reproduce two B=8 runs on the halves -- with M doubled most layers select other tiles / split factors, so this is a parity
-    check of those kernels against the B=8 ones that the oracle tests pin (fp32 summation order differs: tolerance, not bit equality)."""
+    check of those kernels against the B=8 ones that the oracle tests pin.  Both sides are fp16-storage computations with independent
+    rounding (each is 1.2e-3 / 1.9e-3 from the fp32 oracle), so they agree to ~sqrt(2) of that, not bit for bit."""
     from textboost_amd import models
     from textboost_amd.unet import HipUNet
     torch.manual_seed(0)
@@ -268,9 +280,9 @@ def test_batch_16_equals_two_batches_of_8():
     for h in range(2):
         sl = slice(8 * h, 8 * h + 8)
         pred8 = hip8.forward(x[sl].to(dev), t[sl].to(dev), ehs[8 * h * 77:(8 * h + 8) * 77].to(dev).contiguous()).float()
-        parity(f"B=16 vs B=8 pred, half {h}", pred16[sl], pred8, rel=1e-3, maxabs=2e-3, ch_dim=1, ch_rel=2e-3)
+        parity(f"B=16 vs B=8 pred, half {h}", pred16[sl], pred8, rel=2.5e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
         dehs8 = hip8.backward(dpred[sl].to(dev)).float()
-        parity(f"B=16 vs B=8 d_ehs, half {h}", dehs16[8 * h * 77:(8 * h + 8) * 77], dehs8, rel=2e-3, maxabs=4e-3)
+        parity(f"B=16 vs B=8 d_ehs, half {h}", dehs16[8 * h * 77:(8 * h + 8) * 77], dehs8, rel=4e-3, maxabs=6e-3)
 
 
 def test_step_invariants_at_batch_16():

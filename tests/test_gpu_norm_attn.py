@@ -176,3 +176,34 @@ def test_attention_fwd_lds_dma_kernel(B, H, Sq, Skv, hd):
         assert rel_err(o.view(B, Sq, C), oref) < 2e-3
         assert (o.float().view(B, Sq, C) - oref).abs().max().item() < 1e-2
         assert ((lse - lref).abs() / lref.abs().clamp_min(1.0)).max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,H,S,spread", [(2, 8, 512, 1.0), (1, 8, 4096, 1.0), (2, 8, 1024, 4.0)])
+def test_attention_forward_fp8_pv(B, H, S, spread):
+    """BASELINE.json configs[4]: the opt-in e4m3 P.V forward of the hd = 40 self-attention shape (tb_attn_desc.fp8_ws) against fp32
+    attention.  Stated tolerance: rel-L2 <= 5e-2 on O; LSE (what the fp16 backward rebuilds the softmax from) within 2e-3, it is computed
+    from the exact fp32 row sum -- the fp16 kernel of the same shape is held to 2e-3 / 2e-3 above.  e4m3 keeps 3 mantissa bits: every probability and every scaled V entry carries a rounding error of
+    up to 2^-4 (3.6 % rms); on random V the sum over keys is itself a random sum, so the relative error of O does not average down
+    (measured 3.6e-2 on unit-normal data).  `spread` scales the logits: peaked rows (few keys carry the weight) are the worst case."""
+    ops = _ops()
+    torch.manual_seed(3)
+    hd, C = 40, H * 40
+    qkv = torch.randn(B * S, 3 * C, device="cuda")
+    qkv[:, :C] *= spread
+    qkv[:, 2 * C:] *= 3.0                       # V away from unit scale: exercises the per-(batch, head) scale
+    qkv = qkv.half()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    ws = ops.attention_fp8_workspace(B, H, S, "cuda")
+    o8 = torch.empty(B * S, C, device="cuda", dtype=torch.float16)
+    lse8 = torch.empty(B, H, S, device="cuda")
+    ops.attention_fwd(q, k, v, o8, lse8, B, H, S, S, hd, fp8_ws=ws)
+    o16 = torch.empty_like(o8)
+    lse16 = torch.empty_like(lse8)
+    ops.attention_fwd(q, k, v, o16, lse16, B, H, S, S, hd)
+    oref, lref = ref_attention(*[t.float().reshape(B, S, C) for t in (q, k, v)], H, False)
+    e8, e16 = rel_err(o8.view(B, S, C), oref), rel_err(o16.view(B, S, C), oref)
+    print(f"[fp8 attention] S={S} spread={spread}: rel-L2 fp8 {e8:.3e} (fp16 kernel {e16:.3e}), max |dLSE| {(lse8 - lref).abs().max().item():.3e}")
+    assert e16 < 2e-3
+    assert 1e-3 < e8 < 5e-2, "the fp8 path did not run (error equals the fp16 kernel's) or is outside its stated tolerance"
+    assert (lse8 - lref).abs().max().item() < 2e-3 * max(1.0, lref.abs().max().item())
+    assert torch.isfinite(o8).all()

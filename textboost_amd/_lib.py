@@ -55,6 +55,7 @@ class AttnDesc(C.Structure):
         ("dK", C.c_void_p), ("lddk", C.c_int64),
         ("dV", C.c_void_p), ("lddv", C.c_int64),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("fp8_ws", C.c_void_p), ("fp8_ws_bytes", C.c_int64),
     ]
 
 
@@ -67,6 +68,7 @@ _SIGS = {
     "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_gemm_last_config": ([_VP], None),
     "tb_attention_set_variant": ([_I], C.c_int),
+    "tb_attention_fp8_ws_bytes": ([_I, _I, _I], C.c_int64),
     "tb_gemm8_set": ([_I], C.c_int),
     "tb_gemm8_last": ([_VP], C.c_int),
     "tb_gemm8_debug": ([_VP], C.c_int),

@@ -468,13 +468,26 @@ typedef __attribute__((address_space(3))) void* attn_lptr_t;
 // QG: 32-query groups per wave (block = 4 waves x QG x 32 queries).  With QG = 2 every K / V fragment read from LDS, every DMA
 // instruction, barrier and loop-control instruction serves two score tiles: the kernels are bound by instruction ISSUE (PMC: the waves of a
 // SIMD are "active" -- issuing -- ~100 % of the time at ~4.6 cycles per instruction; MFMA busy 30 %), so what counts is instructions per MFMA.
-template <int DT, int KS, int PC, bool FOLDM, int NST, int QG>
+// FP8 (BASELINE.json configs[4], opt-in through tb_attn_desc.fp8_ws): O^T = V^T P^T runs on v_mfma_scale_f32_32x32x64_f8f6f4 -- ONE matrix
+// instruction per (query group, 32 head-dim rows) and 64-key tile instead of four fp16 ones.  P is rounded to e4m3 in registers
+// (v_cvt_pk_fp8_f32; p <= 2^8 under the lazy re-base, e4m3 max 448), V arrives as the per-(batch, head) scaled, TRANSPOSED e4m3 image
+// V8T[bh][48 rows: hd data rows, the all-ones row hd, zeros][Skv] that attn_v8t_kernel writes with the keys of every 64-key tile in the
+// order the matrix instruction's k index meets them in the P registers (A and B fragments only have to agree on the k order), so a
+// V^T fragment is 32 contiguous bytes per lane: two ds_read_b128, no transposing reads.  The row sum still rides on the all-ones row
+// (it is the sum of the ROUNDED p: the output is normalised by what was actually accumulated); QK^T, the softmax and LSE stay fp16 / fp32.
+constexpr int V8_ROWS = 48, V8_PITCH = 80;           // LDS image of a V8T tile: 64 rows (48 loaded, 16 zero) of 64 data bytes + a 16-byte pad chunk
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int DT, int KS, int PC, bool FOLDM, int NST, int QG, bool FP8 = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc p, int remap) {
   constexpr int PCB = PC * 16;                      // row pitch (bytes): hd / 8 data chunks + the pad chunk
   constexpr int TILE_B = KVT * PCB;                 // one 64-row tile
-  constexpr int STAGE_B = 2 * TILE_B + 64;          // K tile, V tile, slack for the V fragment reads past the last row's pad chunk
+  constexpr int V8_B = 64 * V8_PITCH;
+  constexpr int STAGE_B = FP8 ? TILE_B + V8_B : 2 * TILE_B + 64;  // K tile, V tile, slack for the V fragment reads past the last row's pad chunk
   static_assert(NST >= 3, "loads run two tiles ahead of the multiplication");
-  constexpr int NI = 2 * PC;                        // load instructions per stage (64 lanes x 16 B each)
+  static_assert(!FP8 || DT == 2, "fp8 path: hd = 40");
+  constexpr int NV8 = (V8_ROWS * 5 + 63) / 64;      // fp8: load instructions of the V8T tile (48 rows x 5 chunks, the pad chunk's lanes off)
+  constexpr int NI = FP8 ? PC + NV8 : 2 * PC;       // load instructions per stage (64 lanes x 16 B each)
   constexpr int WI = (NI + 3) / 4;                  // ... per wave
   constexpr int QB = 128 * QG;                      // queries per block
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
   const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * hd;
   const char* Kg = (const char*)((const f16*)p.K + (int64_t)b * Skv * ldk + h * hd);
   const char* Vg = (const char*)((const f16*)p.V + (int64_t)b * Skv * ldv + h * hd);
+  const char* V8g = FP8 ? (const char*)p.fp8_ws + ((int64_t)b * p.H + h) * V8_ROWS * Skv : nullptr;
   f16x8 qf[QG][KS];
 #pragma unroll
   for (int g = 0; g < QG; ++g) {
@@ -502,9 +516,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
     const int t = wave + 4 * i;
     const int tensor = t >= PC ? 1 : 0;
     const int f = (t - tensor * PC) * 64 + lane;
-    const int row = f / PC, c = f - row * PC;
-    g_on[i] = t < NI && c < PC - 1;
-    g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + c * 16);
+    if (FP8 && tensor) {  // V8T tile: row = head-dim row (pitch Skv bytes in HBM), 4 data chunks of 16 keys + the pad chunk
+      const int row = f / 5, c = f - row * 5;
+      g_on[i] = t < NI && row < V8_ROWS && c < 4;
+      g_off[i] = (uint32_t)((int64_t)row * Skv + c * 16);
+    } else {
+      const int row = f / PC, c = f - row * PC;
+      g_on[i] = t < NI && c < PC - 1;
+      g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + c * 16);
+    }
   }
   int n_issued = 0;  // loads this wave issues per stage (wave-uniform): for the counted waits
 #pragma unroll
@@ -512,13 +532,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
   auto stage_loads = [&](int tile, int slot) {
     unsigned char* dst = smem_raw + slot * STAGE_B;
     const char* kb = Kg + (int64_t)tile * KVT * ldk * 2;
-    const char* vb = Vg + (int64_t)tile * KVT * ldv * 2;
+    const char* vb = FP8 ? V8g + (int64_t)tile * KVT : Vg + (int64_t)tile * KVT * ldv * 2;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int t = wave + 4 * i;
       if (t < NI) {
         const char* src = (t >= PC ? vb : kb) + g_off[i];
-        if (g_on[i]) __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + t * 1024), 16, 0, 0);
+        unsigned char* d_ = FP8 && t >= PC ? dst + TILE_B + (t - PC) * 1024 : dst + t * 1024;
+        if (g_on[i]) __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)d_, 16, 0, 0);
       }
     }
   };
@@ -526,7 +547,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
   for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {
     const int st = u / (2 * KVT), r = u - st * 2 * KVT;  // r < 64: K row r, else V row r - 64
     f16x8 one = {(f16)1.f, 0, 0, 0, 0, 0, 0, 0};
-    *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = one;
+    if (FP8 && r >= KVT) {  // V8T image: zero the pad chunk of the loaded rows and the 16 rows that are never loaded
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned char* row = smem_raw + st * STAGE_B + TILE_B + (r - KVT) * V8_PITCH;
+      *(f16x8*)(row + 64) = z;
+      if (r - KVT >= V8_ROWS)
+        for (int c = 0; c < 4; ++c) *(f16x8*)(row + c * 16) = z;
+    } else {
+      *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = one;
+    }
   }
   const int ntiles = Skv / KVT;
 #pragma unroll
@@ -591,7 +620,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
     }
     // V^T fragments of the whole tile (shared by the query groups): issued now, they arrive under the softmax arithmetic below
     f16x4 vt[2][2][DT][2];
-    {
+    i32x8 v8[DT];
+    if (FP8) {  // row d 32 + l31, bytes 32 hi .. +31: the lane's 32 k values of the whole tile
+      const unsigned char* Vs8 = smem_raw + slot * STAGE_B + TILE_B + l31 * V8_PITCH + hi * 32;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const i32x4 a0 = *(const i32x4*)(Vs8 + d * 32 * V8_PITCH), a1 = *(const i32x4*)(Vs8 + d * 32 * V8_PITCH + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v8[d][e] = a0[e], v8[d][4 + e] = a1[e];
+      }
+    } else {
       const uint32_t va = lds0 + slot * STAGE_B + v_lane;
       __builtin_amdgcn_sched_barrier(0);
 #define TB_VTR(KT, JJ, D, HH) vt[KT][JJ][D][HH] = lds_tr_read_off<((KT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(va);
@@ -645,10 +683,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[g][kt][r] = fast_exp2(s[g][kt][r]);
+      if (FP8) {  // LSE (the backward's softmax) from the exact row sum; O is normalised by the sum of the ROUNDED p (the all-ones row)
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0 += s[g][0][r], a1 += s[g][1][r];
+        l[g] += a0 + a1;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the V^T fragments (inline-asm reads: not counted by the compiler)
     __builtin_amdgcn_sched_barrier(0);
     TB_PF(1)
+    if (FP8) {
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        i32x8 p8;  // byte 16 kt + r of the lane = register r of score tile kt: the k order attn_v8t_kernel stored the keys in
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          const int kt = w >> 2, r = (w & 3) * 4;
+          int x = 0;
+          x = __builtin_amdgcn_cvt_pk_fp8_f32(s[g][kt][r], s[g][kt][r + 1], x, false);
+          x = __builtin_amdgcn_cvt_pk_fp8_f32(s[g][kt][r + 2], s[g][kt][r + 3], x, true);
+          p8[w] = x;
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          o[g][d] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8[d], p8, o[g][d], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+    } else
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -687,7 +748,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
       for (int k4 = 0; k4 < 4; ++k4)
         if (d * 32 + k4 * 8 == hd) ls = o[g][d][4 * k4];
     const float lsum = __shfl(ls, l31, 64);
-    const float inv = 1.f / lsum;
+    float inv = 1.f / lsum;
+    if (FP8) inv *= ((const float*)((const char*)p.fp8_ws + (int64_t)p.B * p.H * V8_ROWS * Skv))[b * p.H + h];  // 1 / (scale of this head's V image)
     const int q = qblk + (wave * QG + g) * 32 + l31;
     f16* Og = (f16*)p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * hd;
 #pragma unroll
@@ -702,8 +764,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
           *(f16x4*)(Og + col) = v;
         }
       }
-    if (p.LSE && hi == 0) p.LSE[((int64_t)b * p.H + h) * p.Sq + q] = m[g] * (1.f / LOG2E) + logf(lsum);
+    const float lexact = FP8 ? l[g] + __shfl_xor(l[g], 32, 64) : lsum;  // (each half-wave holds half of a query's keys)
+    if (p.LSE && hi == 0) p.LSE[((int64_t)b * p.H + h) * p.Sq + q] = m[g] * (1.f / LOG2E) + logf(lexact);
   }
+}
+
+// ------------------------------------------------------------------------------------------------ fp8 image of V for attn_fwd_dma_kernel<.., FP8>
+// workspace (tb_attn_desc.fp8_ws, tb_attention_fp8_ws_bytes): [B*H][48][Skv] e4m3 | [B*H] fp32 1/scale | [B*H][Skv/256] fp32 partial max
+// pass 1: max |v| per (batch, head) and 256-key block; pass 2: scale = 384 / max (e4m3 max 448), V8T[bh][d][tile*64 + pos(key)] with
+// pos = 32 hi + 16 kt + 4 q + e for key = 32 kt + 8 q + 4 hi + e -- the order in which a lane of the 32x32 score tile S^T holds its keys.
+__global__ __launch_bounds__(256) void attn_v8t_kernel(const tb_attn_desc p, int pass) {
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, nb = gridDim.x;
+  const int key = blockIdx.x * 256 + threadIdx.x;
+  const int64_t BH = (int64_t)p.B * p.H;
+  unsigned char* v8 = (unsigned char*)p.fp8_ws + (int64_t)bh * V8_ROWS * p.Skv;
+  float* inv_scale = (float*)((char*)p.fp8_ws + BH * V8_ROWS * p.Skv);
+  float* partial = inv_scale + BH;
+  const f16* vrow = (const f16*)p.V + ((int64_t)b * p.Skv + key) * p.ldv + h * p.hd;
+  __shared__ float red[4];
+  if (pass == 0) {
+    float mx = 0.f;
+    for (int c = 0; c < p.hd; c += 8) {
+      const f16x8 v = *(const f16x8*)(vrow + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf((float)v[e]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)bh * nb + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    return;
+  }
+  float mx = 0.f;
+  for (int i = 0; i < nb; ++i) mx = fmaxf(mx, partial[(int64_t)bh * nb + i]);
+  const float scale = mx > 0.f ? 384.f / mx : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[bh] = 1.f / scale;
+  const int kk = key & 63, kt = kk >> 5, rem = kk & 31;
+  const int pos = (key & ~63) + 32 * ((rem >> 2) & 1) + 16 * kt + 4 * (rem >> 3) + (rem & 3);
+  for (int c = 0; c < p.hd; c += 8) {
+    const f16x8 v = *(const f16x8*)(vrow + c);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const int x = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[e] * scale, (float)v[e + 1] * scale, 0, false);
+      v8[(int64_t)(c + e) * p.Skv + pos] = (unsigned char)(x & 0xff);
+      v8[(int64_t)(c + e + 1) * p.Skv + pos] = (unsigned char)((x >> 8) & 0xff);
+    }
+  }
+  v8[(int64_t)p.hd * p.Skv + pos] = 0x38;  // 1.0 in e4m3: the all-ones row that makes O^T row hd the row sum
+  for (int d = p.hd + 1; d < V8_ROWS; ++d) v8[(int64_t)d * p.Skv + pos] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
@@ -1048,6 +1157,13 @@ int g_attn_dma = 1;  // tb_attention_set_variant(bits): 1 = LDS-DMA staged forwa
                      // 32 = one query group per wave, 64 = XCD remap also in the backward kernels (measured: forward +14 %, backward -5 %)
                      // (A/B knobs; 8 / 16 = load-path ablations of the DMA kernel)
 
+}  // namespace
+extern "C" int64_t tb_attention_fp8_ws_bytes(int B, int H, int Skv) {
+  const int64_t BH = (int64_t)B * H;
+  return BH * V8_ROWS * Skv + BH * 4 + BH * ((Skv + 255) / 256) * 4;
+}
+namespace {
+
 template <int DT, int KS>
 int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
@@ -1057,6 +1173,16 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
       d.ldk % 8 == 0 && d.ldv % 8 == 0 && (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31)) {
     // LDS-DMA staged kernel (see attn_fwd_dma_kernel): the SD1.x self-attention shapes, hd = 40 (64x64 maps) and 80 (32x32 maps)
     const int rm = ((g_attn_dma >> 2) & 1 ^ 1) | (g_attn_dma & 24);
+    if (DT == 2 && KS == 3 && d.hd == 40 && d.fp8_ws && d.Sq % 256 == 0 && d.Skv % 256 == 0 &&
+        d.fp8_ws_bytes >= tb_attention_fp8_ws_bytes(d.B, d.H, d.Skv) && (int64_t)V8_ROWS * d.Skv < ((int64_t)1 << 31)) {
+      constexpr int PC = 6, NST = 4;
+      const size_t lds8 = NST * (KVT * PC * 16 + 64 * V8_PITCH);
+      hipLaunchKernelGGL(attn_v8t_kernel, dim3(d.Skv / 256, d.B * d.H), dim3(256), 0, s, d, 0);
+      hipLaunchKernelGGL(attn_v8t_kernel, dim3(d.Skv / 256, d.B * d.H), dim3(256), 0, s, d, 1);
+      hipLaunchKernelGGL((attn_fwd_dma_kernel<2, 3, PC, true, NST, 2, true>), dim3(d.Sq / 256, d.H, d.B), dim3(256), lds8, s, d, rm);
+      TB_CHECK_LAUNCH();
+      return TB_OK;
+    }
     if (DT == 2 && KS == 3 && d.hd == 40) {
       constexpr int PC = 6, NST = 4;
       const size_t lds = NST * (2 * KVT * PC * 16 + 64);

@@ -184,9 +184,17 @@ def _attn_desc(q, k, v, o, lse, B, H, Sq, Skv, hd, scale, causal):
     return d
 
 
-def attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd, scale=None, causal=False):
-    """q,o: [B*Sq, H*hd]; k,v: [B*Skv, H*hd] fp16 (column slices allowed). lse fp32 [B,H,Sq]."""
+def attention_fp8_workspace(B, H, Skv, device):
+    """uint8 scratch for the fp8 P.V forward (tb_attn_desc.fp8_ws): the scaled transposed e4m3 image of V, its scales and partial maxima"""
+    return torch.empty(int(L.lib().tb_attention_fp8_ws_bytes(B, H, Skv)), device=device, dtype=torch.uint8)
+
+
+def attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd, scale=None, causal=False, fp8_ws=None):
+    """q,o: [B*Sq, H*hd]; k,v: [B*Skv, H*hd] fp16 (column slices allowed). lse fp32 [B,H,Sq].
+    fp8_ws (attention_fp8_workspace): opt-in e4m3 P.V for the hd = 40 self-attention shape (other shapes ignore it)."""
     d = _attn_desc(q, k, v, o, lse, B, H, Sq, Skv, hd, scale if scale is not None else hd ** -0.5, causal)
+    if fp8_ws is not None:
+        d.fp8_ws, d.fp8_ws_bytes = L.ptr(fp8_ws), fp8_ws.numel()
     with _rec("attn_fwd_kernel", 4.0 * B * H * Sq * Skv * hd):
         L.check(L.lib().tb_attention_fwd(d, L.stream()), "tb_attention_fwd")
     return o

@@ -86,9 +86,12 @@ class HipUNet:
     `backward(dpred[B,4,h,w] fp32) -> d_ehs[B*77, D] fp32` (gradient of the scaled loss)."""
 
     def __init__(self, geo: UNetGeometry, state_dict: Dict[str, torch.Tensor], batch: int, height: int, width: int,
-                 text_len: int = 77, device="cuda"):
+                 text_len: int = 77, device="cuda", attn_fp8: bool = False):
         self.geo, self.B, self.H, self.W, self.T, self.dev = geo, batch, height, width, text_len, device
         self.dtype = torch.float16
+        # BASELINE.json configs[4]: e4m3 P.V in the forward of the hd = 40 self-attention layers (opt-in; fp16 everywhere else and in the backward)
+        self.attn_fp8 = attn_fp8
+        self._fp8_ws = None
         self._bufs: Dict[str, torch.Tensor] = {}
         self.tape: List = []
         self._pack(state_dict)
@@ -290,7 +293,12 @@ class HipUNet:
         ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
         o1 = self.buf(prefix + ".o1", M, C)
         lse1 = self.buf(prefix + ".lse1", B * heads, HW, torch.float32)
-        ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, B, heads, HW, HW, hd)
+        fp8_ws = None
+        if self.attn_fp8 and hd == 40 and HW % 256 == 0:
+            if self._fp8_ws is None:
+                self._fp8_ws = ops.attention_fp8_workspace(B, heads, HW, self.dev)  # one scratch, reused by every such layer (stream order)
+            fp8_ws = self._fp8_ws
+        ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, B, heads, HW, HW, hd, fp8_ws=fp8_ws)
         t1 = self.buf(prefix + ".t1", M, C)
         ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
         # --- cross attention (K/V hoisted)

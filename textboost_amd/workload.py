@@ -34,12 +34,12 @@ def synthetic_ids(B, added_ids, gen: torch.Generator, prior=False, null_prob=0.1
 
 def build_step(batch=8, latent=64, unet_geo: UNetGeometry = models.SD15_UNET, clip_geo: CLIPGeometry = models.SD15_CLIP,
                lora_rank=4, n_added=18, hyper: StepHyper | None = None, weight_seed=1234, data_seed=1000, device="cuda",
-               world_size=1, with_vae=False):
+               world_size=1, with_vae=False, attn_fp8=False):
     """Config 2 of BASELINE.json by default: SD1.5 UNet + CLIP-L, per-GPU batch 8, 512^2 (64^2 latents), LoRA r=4, KPL on,
     18 added token vectors (2 placeholder + 16 augmentation vectors)."""
     hyper = hyper or StepHyper()
     usd = models.random_state_dict(models.unet_shapes(unet_geo), weight_seed, device=device)
-    unet = HipUNet(unet_geo, usd, batch, latent, latent, text_len=clip_geo.max_pos, device=device)
+    unet = HipUNet(unet_geo, usd, batch, latent, latent, text_len=clip_geo.max_pos, device=device, attn_fp8=attn_fp8)
     del usd
     csd = models.random_state_dict(models.clip_shapes(clip_geo), weight_seed + 1, device=device)
     teacher = HipTextEncoder(clip_geo, csd, batch, mode="half", device=device)
