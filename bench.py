@@ -308,7 +308,7 @@ def main():
         flop_per_image = FLOP_PER_IMAGE
         metric = "train steps/sec (batch=%d, 512^2, SD1.5, LoRA r=4)" % args.batch  # BASELINE.json's metric at the default batch 8
         workload = ("BASELINE.json configs[1]: SD1.5 UNet (859.5M, frozen, fwd + dgrad bwd) + CLIP-L text encoder LoRA r=4 on "
-                    "q/k/v (fwd x2 + bwd x2) + fp16 KPL teacher fwd, per-GPU batch %d, %dx%d latents (512^2), 18 added token vectors, "
+                    "q/k/v (fwd x2 + bwd x2) + frozen KPL teacher fwd (its rows ride in the student's launches), per-GPU batch %d, %dx%d latents (512^2), 18 added token vectors, "
                     "MSE + 0.1*KPL(cos), GradScaler + clip + AdamW + renorm on device; random-init weights; step as one HIP graph"
                     % (args.batch, args.latent, args.latent))
         if args.vae:

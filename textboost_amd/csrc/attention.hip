@@ -1172,7 +1172,7 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
   if ((g_attn_dma & 1) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 && d.hd % 8 == 0 && d.hd < WD && (d.hd == 40 || d.hd == 80) &&
       d.ldk % 8 == 0 && d.ldv % 8 == 0 && (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31)) {
     // LDS-DMA staged kernel (see attn_fwd_dma_kernel): the SD1.x self-attention shapes, hd = 40 (64x64 maps) and 80 (32x32 maps)
-    const int rm = ((g_attn_dma >> 2) & 1 ^ 1) | (g_attn_dma & 24);
+    const int rm = (((g_attn_dma >> 2) & 1) ^ 1) | (g_attn_dma & 24);
     if (DT == 2 && KS == 3 && d.hd == 40 && d.fp8_ws && d.Sq % 256 == 0 && d.Skv % 256 == 0 &&
         d.fp8_ws_bytes >= tb_attention_fp8_ws_bytes(d.B, d.H, d.Skv) && (int64_t)V8_ROWS * d.Skv < ((int64_t)1 << 31)) {
       constexpr int PC = 6, NST = 4;
@@ -1209,11 +1209,11 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
     }
   }
   if (TB_ATTN_FOLDM && DT <= 2 && d.hd < WD && d.hd < 16 * KS && d.hd % 8 == 0)  // padding in the head dim of BOTH products: see FOLDM
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, (DT <= 2)>), grid, dim3(256), lds, s, d, (g_attn_dma >> 2) & 1 ^ 1);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, (DT <= 2)>), grid, dim3(256), lds, s, d, ((g_attn_dma >> 2) & 1) ^ 1);
   else if (d.hd < WD)  // head-dim padding exists: the row sum rides on the PV product (all-ones row hd of V^T)
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, false>), grid, dim3(256), lds, s, d, (g_attn_dma >> 2) & 1 ^ 1);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, false>), grid, dim3(256), lds, s, d, ((g_attn_dma >> 2) & 1) ^ 1);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false, false>), grid, dim3(256), lds, s, d, (g_attn_dma >> 2) & 1 ^ 1);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, false, false>), grid, dim3(256), lds, s, d, ((g_attn_dma >> 2) & 1) ^ 1);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

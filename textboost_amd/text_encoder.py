@@ -125,11 +125,13 @@ class HipTextEncoder:
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name, rows, cols, dtype):
+        """named, zero-initialised activation buffer.  A buffer that already exists with MORE rows is returned as its leading row slice:
+        the forward with a frozen extra batch (`extra_ids`) sizes everything for student + extra rows, the backward walks the student rows."""
         t = self._bufs.get(name)
-        if t is None or t.shape != (rows, cols) or t.dtype != dtype:
+        if t is None or t.shape[1] != cols or t.dtype != dtype or t.shape[0] < rows:
             t = torch.zeros(rows, cols, device=self.dev, dtype=dtype)
             self._bufs[name] = t
-        return t
+        return t if t.shape[0] == rows else t[:rows]
 
     def pack_lora(self):
         """refresh the fp16 K-extension operands from the fp32 LoRA masters (once per optimizer step)."""
@@ -140,25 +142,37 @@ class HipTextEncoder:
         ops.lora_pack(self.lora_A, self.lora_B, self.w2_fwd, self.w2_dgrad, D, D, self.r, 3, self.scaling, layers=self.geo.num_layers)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids, slot=0, pins=True):
+    def forward(self, input_ids, slot=0, pins=True, extra_ids=None, extra_table=None):
+        """extra_ids [Be, T] (+ extra_table, the ORIGINAL fp32 token table): a frozen batch that rides along in the same launches -- its rows
+        get no LoRA term (their K-extension operand rows stay zero) and are embedded from `extra_table`; used for the KPL teacher
+        (train_textboost.py:1096-1100: the un-adapted encoder on the prior prompts), whose separate M = 616 pass was pure launch latency.
+        Returns [(B + Be) * T, D]: student rows first.  backward() only ever walks the student rows."""
         geo, B, T = self.geo, input_ids.shape[0], self.T
         D, I, H = geo.hidden_size, geo.intermediate_size, geo.num_heads
         hd = D // H
+        Bs, Ms = B, B * T                # student sequences / rows (LoRA, trainable table)
+        if extra_ids is not None:
+            B = B + extra_ids.shape[0]
         M = B * T
         rdt, f16, f32 = self.res_dtype, torch.float16, torch.float32
         ids = input_ids.reshape(-1).contiguous()
         s = f"s{slot}."
         self._bufs[s + "ids"] = ids
         h = self.buf(s + "h0", M, D, rdt)
-        ops.embed_fwd(ids, self.token_table, self.pos_table, h, T)
+        ops.embed_fwd(ids, self.token_table, self.pos_table, h[:Ms], T)
+        if extra_ids is not None:
+            eids = extra_ids.reshape(-1).contiguous()
+            ops.embed_fwd(eids, extra_table, self.pos_table, h[Ms:], T)
         for i, W in enumerate(self.Wl):
             p = f"{s}l{i}."
             x1 = self.buf(p + "x1", M, D, f16)
             ls1 = self.buf(p + "ls1", M, 2, f32)
             qkv = self.buf(p + "qkv", M, 3 * D, f16)
             if self.r:
-                t = self.buf(p + "t", M, 64, f16)  # columns >= 3r stay zero (K-extension operand of the qkv GEMM)
-                ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps, lora_A=self.lora_A[i], t=t)
+                t = self.buf(p + "t", M, 64, f16)  # columns >= 3r (and the frozen extra rows) stay zero (K-extension operand of the qkv GEMM)
+                ops.layernorm_fwd(h[:Ms], x1[:Ms], W["ln1.g"], W["ln1.b"], ls1[:Ms], geo.eps, lora_A=self.lora_A[i], t=t[:Ms])
+                if M > Ms:
+                    ops.layernorm_fwd(h[Ms:], x1[Ms:], W["ln1.g"], W["ln1.b"], ls1[Ms:], geo.eps)
                 ops.gemm(x1, W["qkv.w"], qkv, A2=t, W2=self.w2_fwd[i], bias=W["qkv.b"])
             else:
                 ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
@@ -181,7 +195,9 @@ class HipTextEncoder:
         lsf = self.buf(s + "lsf", M, 2, f32)
         ops.layernorm_fwd(h, out, self.lnf_g, self.lnf_b, lsf, geo.eps)
         if pins:
-            ops.pin_fwd(out, ids, self.null_embedding, B, T, self.use_fixed_special_embedding, EOS_ID)
+            ops.pin_fwd(out[:Ms], ids, self.null_embedding, Bs, T, self.use_fixed_special_embedding, EOS_ID)
+            if M > Ms:
+                ops.pin_fwd(out[Ms:], eids, self.null_embedding, B - Bs, T, self.use_fixed_special_embedding, EOS_ID)
         return out
 
     # ------------------------------------------------------------------ backward (autocast mode only)
@@ -206,7 +222,7 @@ class HipTextEncoder:
         f16, f32 = torch.float16, torch.float32
         if pins:
             ops.pin_bwd(d_out, ids, B, T, self.use_fixed_special_embedding, EOS_ID)
-        h_last = self._bufs[f"{s}l{geo.num_layers - 1}.h3"]
+        h_last = self._bufs[f"{s}l{geo.num_layers - 1}.h3"][:M]
         dh = self.buf("g.dh_a", M, D, f32)
         dh16 = self.buf("g.dh16", M, D, f16)  # fp16 copy of the running residual gradient, written by the LayerNorm backward
         ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh, dx16=dh16)
@@ -214,9 +230,11 @@ class HipTextEncoder:
         for i in reversed(range(geo.num_layers)):
             W = self.Wl[i]
             p = f"{s}l{i}."
-            h_in = self._bufs[f"{s}l{i - 1}.h3"] if i > 0 else self._bufs[s + "h0"]
-            h2, pre, qkv, o, lse = (self._bufs[p + n] for n in ("h2", "pre", "qkv", "o", "lse"))
-            x1 = self._bufs[p + "x1"]
+            # saved activations: the leading M rows (the forward may have carried a frozen extra batch behind them)
+            h_in = (self._bufs[f"{s}l{i - 1}.h3"] if i > 0 else self._bufs[s + "h0"])[:M]
+            h2, pre, qkv, o = (self._bufs[p + n][:M] for n in ("h2", "pre", "qkv", "o"))
+            lse = self._bufs[p + "lse"][:B * H]
+            x1 = self._bufs[p + "x1"][:M]
             dpre = self.buf("g.dpre", M, I, f16)
             ops.gemm(dh16, W["fc2.wd"], dpre, act=self.act_bwd, C2=pre)
             dx2 = self.buf("g.dx", M, D, f16)
@@ -232,7 +250,7 @@ class HipTextEncoder:
             dx1 = self.buf("g.dx", M, D, f16)
             if self.r:
                 dt = self.buf("g.dt", M, 64, f16)
-                ops.lora_bwd(dqkv, x1, self._bufs[p + "t"], self.lora_B[i], dt, self.grad_A[i], self.grad_B[i], D, D, self.r, 3,
+                ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, self.grad_A[i], self.grad_B[i], D, D, self.r, 3,
                              self.scaling)
                 ops.gemm(dqkv, W["qkv.wd"], dx1, A2=dt, W2=self.w2_dgrad[i])
             else:

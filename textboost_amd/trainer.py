@@ -11,6 +11,8 @@ Scalars (loss, loss scale, grad norm, found_inf, step count) stay on the device 
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -182,6 +184,12 @@ class TextBoostStep:
         self.graph = None
         self.external_noise = False
         self.side = torch.cuda.Stream(device=device) if self.kpl else None
+        # The KPL teacher is the un-adapted encoder on the prior prompts (:1096-1100).  As its own M = 616 pass it was ~90 launches of pure launch
+        # latency (0.87 ms); merged, its rows ride along in the student's launches with a zero LoRA operand and the original token table.
+        # Arithmetic: the student's autocast path (fp32 residual stream) instead of the fp16 module's -- closer to the fp32 oracle, not bit-equal
+        # to the separate pass (TB_SEPARATE_TEACHER=1 keeps that pass).
+        self.merge_teacher = self.kpl and text_encoder.r > 0 and os.environ.get("TB_SEPARATE_TEACHER", "0") != "1"
+        self.teacher_table32 = teacher.token_table.float().contiguous() if self.merge_teacher else None
         self.vae = None  # attach_vae(): the step then starts from pixels (:1027-1037) instead of latents
         self.lr_table = None  # set_lr_table(): lambda(k) of --lr_scheduler on the device, indexed by the successful-step count
 
@@ -211,13 +219,18 @@ class TextBoostStep:
             self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))                  # :1027-1037
         ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
         te.pack_lora()
-        self.h_all = te.forward(self.ids_all, slot=0)                              # :1054-1059 and :1099 in one batch
+        if self.merge_teacher:
+            nb = self.ids_all.shape[0]
+            out = te.forward(self.ids_all, slot=0, extra_ids=self.prior_ids, extra_table=self.teacher_table32)
+            self.h_all, self.h_teacher = out[:nb * te.T], out[nb * te.T:]
+        else:
+            self.h_all = te.forward(self.ids_all, slot=0)                          # :1054-1059 and :1099 in one batch
         ops.convert(self.h_all[:B * te.T], self.ehs16)                             # .to(unet.dtype) :1066
 
     def _phase_teacher(self):
         """:1096-1106 -- the frozen fp16 teacher + the KPL loss; depends only on the student's hidden states."""
         hp, st = self.hp, self.state
-        h0 = self.teacher.forward(self.prior_ids, slot=0)
+        h0 = self.h_teacher if self.merge_teacher else self.teacher.forward(self.prior_ids, slot=0)
         kpl = ops.kpl_cos if hp.kpl_type == "cos" else ops.kpl_mse
         kpl(self.h_all[self.B * self.te.T:], h0, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
 
@@ -246,7 +259,9 @@ class TextBoostStep:
             fork = torch.cuda.Event()
             fork.record(main)
         self._phase_unet_forward()
-        if self.kpl:
+        if self.kpl and self.merge_teacher:
+            self._phase_teacher()  # only the KPL loss kernel is left of it
+        elif self.kpl:
             # the teacher is issued on a side stream (a fork/join inside the HIP graph) after the UNet forward.  ROCm 7 serialises a graph's
             # branches at replay (same steps/s with and without the second stream); the teacher as its OWN graph on the side stream, which
             # does run concurrently with the UNet graph, measured the same steps/s too (26.0 vs 26.0 / 26.1): the UNet's kernels already
@@ -255,7 +270,7 @@ class TextBoostStep:
             with torch.cuda.stream(self.side), ops.workspace_slot(1):
                 self._phase_teacher()
         self._phase_unet_backward()
-        if self.kpl:
+        if self.kpl and not self.merge_teacher:
             main.wait_stream(self.side)
         self._phase_encoder_backward()
 
