@@ -207,3 +207,39 @@ def test_attention_forward_fp8_pv(B, H, S, spread):
     assert 1e-3 < e8 < 5e-2, "the fp8 path did not run (error equals the fp16 kernel's) or is outside its stated tolerance"
     assert (lse8 - lref).abs().max().item() < 2e-3 * max(1.0, lref.abs().max().item())
     assert torch.isfinite(o8).all()
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 8, 1024), (8, 8, 512), (1, 8, 4096)])
+def test_attention_backward_dma_staged_dkv(B, H, S):
+    """the hd = 40 self-attention backward with a ws of 2 * B * H * S floats takes attn_bwd_dkv_dma_kernel (>= 512 key blocks): against fp32
+    autograd and against the register-staged kernel (bit 128 of tb_attention_set_variant switches the DMA kernel off)."""
+    ops = _ops()
+    from textboost_amd import _lib as L
+    torch.manual_seed(4)
+    hd, C = 40, H * 40
+    qkv = torch.randn(B * S, 3 * C, device="cuda").half()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o = torch.empty(B * S, C, device="cuda", dtype=torch.float16)
+    lse = torch.empty(B, H, S, device="cuda")
+    ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd)
+    do = torch.randn(B * S, C, device="cuda").half()
+    qr, kr, vr = [t.float().reshape(B, S, C).requires_grad_(True) for t in (q, k, v)]
+    oref, _ = ref_attention(qr, kr, vr, H, False)
+    oref.backward(do.float().view(B, S, C))
+    res = []
+    old = L.lib().tb_attention_set_variant(1)
+    for bits in (1, 1 | 128):
+        L.lib().tb_attention_set_variant(bits)
+        delta = torch.empty(B, H, S, device="cuda")
+        dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16)
+        ws = torch.empty(2 * B * H * S, device="cuda")
+        ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws)
+        res.append(dqkv)
+    L.lib().tb_attention_set_variant(old)
+    for dqkv in res:
+        assert rel_err(dqkv[:, :C].reshape(B, S, C), qr.grad) < 4e-3
+        assert rel_err(dqkv[:, C:2 * C].reshape(B, S, C), kr.grad) < 4e-3
+        assert rel_err(dqkv[:, 2 * C:].reshape(B, S, C), vr.grad) < 4e-3
+    if (S // 128) * H * B >= 512:
+        assert not torch.equal(res[0][:, C:], res[1][:, C:]), "the DMA-staged dK/dV kernel did not run"
+    assert rel_err(res[0][:, C:], res[1][:, C:]) < 2e-3

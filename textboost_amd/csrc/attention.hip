@@ -459,7 +459,9 @@ __device__ __forceinline__ void attn_wait_vmcnt(int n) {  // n wave-uniform
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
   }
 }
 typedef const __attribute__((address_space(1))) void* attn_gptr_t;
@@ -769,6 +771,188 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dK, dV with LDS-DMA staging
+// The dK/dV kernel for the SD1.x self-attention shape (hd = 40, Sq % 64 == 0, Skv % 128 == 0, non-causal), built like attn_fwd_dma_kernel:
+// the streamed Q and dO tiles go HBM -> LDS by global_load_lds_dwordx4, ROW-MAJOR only, through an NST-slot ring with counted vmcnt (one
+// barrier per tile instead of two); the fragments of S^T = Q K^T and dP^T = dO V^T are ds_read_b128 from those rows, the Q^T / dO^T fragments
+// of dK += dS^T Q and dV += P^T dO come from the SAME rows through the transposing read ds_read_b64_tr_b16 -- no second (transposed) LDS
+// image, no register staging, no packing VALU (the register-staged kernel spends 32 v_perm + 24 LDS stores + the tile address math per
+// tile and wave on it; beside the matrix pipe every plain VALU instruction is paid in full).  The per-query -lse log2(e) and -delta that
+// enter the two products as accumulator inputs are DMA'd raw (dword loads) from the two [B, H, Sq] arrays the dQ kernel publishes in
+// tb_attn_desc.ws: no arithmetic on them here.
+template <int DT, int KS, int PC, int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const tb_attn_desc p, int remap) {
+  constexpr int PCB = PC * 16, TILE_B = KVT * PCB;
+  constexpr int STAGE_B = 2 * TILE_B + 2 * KVT * 4 + 64;  // Q tile, dO tile, -lse2[64], -delta[64], slack for the tr reads past the last pad chunk
+  constexpr int NI = 2 * PC + 2, WI = (NI + 3) / 4;
+  static_assert(NST >= 3, "loads run two tiles ahead");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlk blk = attn_block(remap);
+  const int b = blk.b, h = blk.h, hd = p.hd;
+  const int kblk = blk.x * 128;
+  const int key = kblk + wave * 32 + l31;
+  const int64_t ldq = p.ldq, lddo = p.lddo;
+  const char* Qg = (const char*)((const f16*)p.Q + (int64_t)b * p.Sq * ldq + h * hd);
+  const char* dOg = (const char*)((const f16*)p.dO + (int64_t)b * p.Sq * lddo + h * hd);
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * hd;
+  const int64_t BHS = (int64_t)p.B * p.H * p.Sq;
+  const char* NLg = (const char*)(p.ws + ((int64_t)b * p.H + h) * p.Sq);        // -lse * log2(e), written by the dQ kernel
+  const char* NDg = (const char*)(p.ws + BHS + ((int64_t)b * p.H + h) * p.Sq);  // -delta
+  f16x8 kf[KS], vf[KS];
+  load_row_frags<KS>(kf, Kg, p.ldk, key, p.Skv, hd, hi);
+  load_row_frags<KS>(vf, Vg, p.ldv, key, p.Skv, hd, hi);
+  scale_frags<KS>(kf, p.scale * LOG2E);
+  // ---- this lane's part of a stage's loads: instruction t = wave + 4 i; t < PC: Q rows, t < 2 PC: dO rows, then the two stat rows
+  uint32_t g_off[WI];
+  bool g_on[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave + 4 * i;
+    const int tensor = t >= PC ? 1 : 0;
+    const int f = (t - tensor * PC) * 64 + lane;
+    const int row = f / PC, c = f - row * PC;
+    g_on[i] = t < 2 * PC && c < PC - 1;
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? lddo : ldq) * 2 + c * 16);
+  }
+  int n_issued = 0;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) n_issued += (wave + 4 * i < NI) ? 1 : 0;
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * STAGE_B;
+    const char* qb = Qg + (int64_t)tile * KVT * ldq * 2;
+    const char* ob = dOg + (int64_t)tile * KVT * lddo * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave + 4 * i;
+      if (t < 2 * PC) {
+        const char* src = (t >= PC ? ob : qb) + g_off[i];
+        if (g_on[i]) __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + t * 1024), 16, 0, 0);
+      } else if (t < NI) {  // 64 floats = one dword per lane
+        const char* src = (t == 2 * PC ? NLg : NDg) + ((int64_t)tile * KVT + lane) * 4;
+        __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + 2 * TILE_B + (t - 2 * PC) * 256), 4, 0, 0);
+      }
+    }
+  };
+  // pad chunks of every row of every stage: zeros (they meet the zero padding of the lane-owned K / V fragments, but must be finite)
+  for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {
+    const int st = u / (2 * KVT), r = u - st * 2 * KVT;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = z;
+  }
+  const int ntiles = p.Sq / KVT;
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < ntiles) stage_loads(st, st);
+  f32x16 dk[DT], dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    ZERO16(dk[d]);
+    ZERO16(dv[d]);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lptr_t)smem_raw;
+  const uint32_t rm_lane = l31 * PCB + hi * 16;   // row-major fragment: row l31 (+ 32 qt), chunk 2 j + hi
+  const int g4 = lane >> 4, j16 = lane & 15;
+  const uint32_t tr_lane = (4 * (g4 >> 1) + (j16 >> 2)) * PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;  // as the forward kernel's V^T reads
+  int slot = 0, lslot = NST - 1;
+  for (int t = 0; t < ntiles; ++t) {
+    {
+      int later = ntiles - 1 - t;
+      later = later > NST - 2 ? NST - 2 : later;
+      attn_wait_vmcnt(later * n_issued);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + NST - 1 < ntiles) stage_loads(t + NST - 1, lslot);
+    const unsigned char* Qs = smem_raw + slot * STAGE_B;
+    const float* lse_s = (const float*)(Qs + 2 * TILE_B);
+    const float* del_s = lse_s + KVT;
+    const uint32_t qa = lds0 + slot * STAGE_B + tr_lane;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 s, dp;  // start from -lse2 / -delta of the tile's queries: rows of register quad g are 8 g + 4 hi + {0..3}
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 lq = *(const f32x4*)(lse_s + qt * 32 + 8 * q4 + 4 * hi);
+        const f32x4 dq4 = *(const f32x4*)(del_s + qt * 32 + 8 * q4 + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[4 * q4 + e] = lq[e];
+          dp[4 * q4 + e] = dq4[e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const f16x8 qfr = *(const f16x8*)(Qs + rm_lane + qt * 32 * PCB + j * 32);
+        const f16x8 dofr = *(const f16x8*)(Qs + TILE_B + rm_lane + qt * 32 * PCB + j * 32);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[j], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[j], dp, 0, 0, 0);
+      }
+      // transposed fragments of this 32-query half: issued behind the score products, they arrive under the exponentials
+      f16x4 qtf[2][DT][2], dotf[2][DT][2];
+      __builtin_amdgcn_sched_barrier(0);
+#define TB_TR(ARR, BASE, QT, JJ, D, HH) ARR[JJ][D][HH] = lds_tr_read_off<(BASE) + ((QT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(qa);
+#define TB_TR_ALL(QT)                                                                                   \
+  TB_TR(qtf, 0, QT, 0, 0, 0) TB_TR(qtf, 0, QT, 0, 0, 1) TB_TR(qtf, 0, QT, 1, 0, 0) TB_TR(qtf, 0, QT, 1, 0, 1) \
+  TB_TR(qtf, 0, QT, 0, 1, 0) TB_TR(qtf, 0, QT, 0, 1, 1) TB_TR(qtf, 0, QT, 1, 1, 0) TB_TR(qtf, 0, QT, 1, 1, 1) \
+  TB_TR(dotf, TILE_B, QT, 0, 0, 0) TB_TR(dotf, TILE_B, QT, 0, 0, 1) TB_TR(dotf, TILE_B, QT, 1, 0, 0) TB_TR(dotf, TILE_B, QT, 1, 0, 1) \
+  TB_TR(dotf, TILE_B, QT, 0, 1, 0) TB_TR(dotf, TILE_B, QT, 0, 1, 1) TB_TR(dotf, TILE_B, QT, 1, 1, 0) TB_TR(dotf, TILE_B, QT, 1, 1, 1)
+      static_assert(DT == 2, "hd = 40 instantiation");
+      if (qt == 0) { TB_TR_ALL(0) } else { TB_TR_ALL(1) }
+#undef TB_TR_ALL
+#undef TB_TR
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(s[r]);
+        s[r] = pv;            // P
+        dp[r] = pv * dp[r];   // dS / scale
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed fragments (inline-asm reads: not counted by the compiler)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f16x8 pf = pack8(s, 8 * jj);
+        const f16x8 dsf = pack8(dp, 8 * jj);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          f16x8 a, c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = dotf[jj][d][0][e], a[4 + e] = dotf[jj][d][1][e];
+            c[e] = qtf[jj][d][0][e], c[4 + e] = qtf[jj][d][1][e];
+          }
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c, dsf, dk[d], 0, 0, 0);
+        }
+      }
+    }
+    slot = slot == NST - 1 ? 0 : slot + 1;
+    lslot = lslot == NST - 1 ? 0 : lslot + 1;
+  }
+  if (key < p.Skv) {
+    f16* dKg = (f16*)p.dK + ((int64_t)b * p.Skv + key) * p.lddk + h * hd;
+    f16* dVg = (f16*)p.dV + ((int64_t)b * p.Skv + key) * p.lddv + h * hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < hd) {
+          f16x4 a, bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = (f16)(dk[d][4 * r4 + e] * p.scale);
+            bb[e] = (f16)dv[d][4 * r4 + e];
+          }
+          *(f16x4*)(dKg + col) = a;
+          *(f16x4*)(dVg + col) = bb;
+        }
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ fp8 image of V for attn_fwd_dma_kernel<.., FP8>
 // workspace (tb_attn_desc.fp8_ws, tb_attention_fp8_ws_bytes): [B*H][48][Skv] e4m3 | [B*H] fp32 1/scale | [B*H][Skv/256] fp32 partial max
 // pass 1: max |v| per (batch, head) and 256-key block; pass 2: scale = 384 / max (e4m3 max 448), V8T[bh][d][tile*64 + pos(key)] with
@@ -839,7 +1023,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const tb_attn_desc p) {
 #define TB_DQ_OCC 2
 #endif
 template <int DT, int KS>
-__global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p, int remap) {
+__global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_kernel(const tb_attn_desc p, int remap, int publish) {
   constexpr int WD = DT * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16* Ks = reinterpret_cast<f16*>(smem_raw);
@@ -878,6 +1062,10 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
     }
     delta = a + __shfl_xor(a, 32, 64);
     if (qok && hi == 0) p.Delta[sidx] = delta;
+  }
+  if (publish && qok && hi == 0) {  // accumulator inputs of attn_bwd_dkv_dma_kernel, which DMAs them raw: -lse log2(e) | -delta in p.ws
+    p.ws[sidx] = -lse2;
+    p.ws[(int64_t)p.B * p.H * p.Sq + sidx] = -delta;
   }
 #else
   const float delta = p.Delta[sidx];
@@ -1220,6 +1408,11 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
 template <int DT, int KS>
 int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
+  // LDS-DMA staged dK/dV kernel: the SD1.x 64x64-map self-attention shape; needs 2 * B * H * Sq floats of ws for the statistics the dQ
+  // kernel publishes for it (else, and for every other shape, the register-staged kernel runs)
+  const bool dkv_dma = DT == 2 && KS == 3 && d.hd == 40 && !d.causal && d.Sq % KVT == 0 && d.Skv % 128 == 0 && !(g_attn_dma & 128) &&
+                       d.ws && d.ws_floats >= 2 * (int64_t)d.B * d.H * d.Sq && (int64_t)(d.Skv / 128) * d.H * d.B >= 512 &&
+                       d.ldq % 8 == 0 && d.lddo % 8 == 0 && (int64_t)KVT * (d.ldq > d.lddo ? d.ldq : d.lddo) * 2 < ((int64_t)1 << 31);
 #ifndef TB_ATTN_FUSED_DELTA
   {
     int64_t total = (int64_t)d.B * d.Sq * d.H;
@@ -1235,7 +1428,16 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
       attr_done = true;
     }
     dim3 grid((d.Sq + 127) / 128, d.H, d.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
+  }
+  if (dkv_dma) {
+    if constexpr (DT == 2 && KS == 3) {
+      constexpr int PC = 6, NST = 4;
+      const size_t lds = NST * (2 * KVT * PC * 16 + 2 * KVT * 4 + 64);
+      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<2, 3, PC, NST>), dim3(d.Skv / 128, d.H, d.B), dim3(256), lds, s, d, (g_attn_dma >> 6) & 1);
+    }
+    TB_CHECK_LAUNCH();
+    return TB_OK;
   }
   {
     size_t lds = (2 * RM<WD>::SIZE + 2 * TR<WD>::SIZE) * sizeof(f16) + 2 * KVT * sizeof(float);
