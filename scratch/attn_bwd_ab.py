@@ -10,7 +10,7 @@ ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd)
 do = torch.randn(B * S, C, device="cuda").half(); delta = torch.empty(B, H, S, device="cuda")
 dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16); ws = torch.empty(2 * B * H * S, device="cuda")
 def run(): ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws)
-for name, bits in [("dma dkv", 1), ("register-staged", 1 | 128), ("dma dkv + remap", 1 | 64), ("dma dkv", 1)]:
+for name, bits in [("warm-up", 1), ("dma dq + dkv", 1), ("register-staged", 1 | 128 | 256), ("dma dkv only", 1 | 256), ("dma dq only", 1 | 128), ("dma + remap", 1 | 64), ("dma dq + dkv", 1)]:
     L.lib().tb_attention_set_variant(bits)
     for _ in range(3): run()
     torch.cuda.synchronize()

@@ -212,7 +212,7 @@ def test_attention_forward_fp8_pv(B, H, S, spread):
 @pytest.mark.parametrize("B,H,S", [(2, 8, 1024), (8, 8, 512), (1, 8, 4096)])
 def test_attention_backward_dma_staged_dkv(B, H, S):
     """the hd = 40 self-attention backward with a ws of 2 * B * H * S floats takes attn_bwd_dkv_dma_kernel (>= 512 key blocks): against fp32
-    autograd and against the register-staged kernel (bit 128 of tb_attention_set_variant switches the DMA kernel off)."""
+    autograd and against the register-staged kernels (bits 128 / 256 of tb_attention_set_variant switch the DMA dK/dV / dQ kernels off)."""
     ops = _ops()
     from textboost_amd import _lib as L
     torch.manual_seed(4)
@@ -228,7 +228,7 @@ def test_attention_backward_dma_staged_dkv(B, H, S):
     oref.backward(do.float().view(B, S, C))
     res = []
     old = L.lib().tb_attention_set_variant(1)
-    for bits in (1, 1 | 128):
+    for bits in (1, 1 | 128 | 256):
         L.lib().tb_attention_set_variant(bits)
         delta = torch.empty(B, H, S, device="cuda")
         dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16)
@@ -242,4 +242,5 @@ def test_attention_backward_dma_staged_dkv(B, H, S):
         assert rel_err(dqkv[:, 2 * C:].reshape(B, S, C), vr.grad) < 4e-3
     if (S // 128) * H * B >= 512:
         assert not torch.equal(res[0][:, C:], res[1][:, C:]), "the DMA-staged dK/dV kernel did not run"
-    assert rel_err(res[0][:, C:], res[1][:, C:]) < 2e-3
+    assert not torch.equal(res[0][:, :C], res[1][:, :C]), "the DMA-staged dQ kernel did not run"
+    assert rel_err(res[0], res[1]) < 2e-3

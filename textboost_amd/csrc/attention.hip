@@ -771,6 +771,166 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ with LDS-DMA staging
+// Same construction for dQ (hd = 40, Sq % 128 == 0, Skv % 64 == 0, non-causal): K and V tiles by LDS-DMA, row-major, NST-slot ring; the
+// fragments of S^T = K Q^T and dP^T = V dO^T are ds_read_b128 of those rows, the K^T fragments of dQ^T += K^T dS^T come from the same K rows
+// through the transposing read.  Also computes delta = rowsum(dO * O) and publishes -lse log2(e) / -delta for attn_bwd_dkv_dma_kernel.
+template <int DT, int KS, int PC, int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_desc p, int remap, int publish) {
+  constexpr int PCB = PC * 16, TILE_B = KVT * PCB;
+  constexpr int STAGE_B = 2 * TILE_B + 64;
+  constexpr int NI = 2 * PC, WI = (NI + 3) / 4;
+  static_assert(NST >= 3 && DT == 2, "hd = 40 instantiation; loads run two tiles ahead");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlk blk = attn_block(remap);
+  const int b = blk.b, h = blk.h, hd = p.hd, Skv = p.Skv;
+  const int q = blk.x * 128 + wave * 32 + l31;
+  const int64_t ldk = p.ldk, ldv = p.ldv;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * hd;
+  const f16* dOg = (const f16*)p.dO + (int64_t)b * p.Sq * p.lddo + h * hd;
+  const char* Kg = (const char*)((const f16*)p.K + (int64_t)b * Skv * ldk + h * hd);
+  const char* Vg = (const char*)((const f16*)p.V + (int64_t)b * Skv * ldv + h * hd);
+  f16x8 qf[KS], dof[KS];
+  load_row_frags<KS>(qf, Qg, p.ldq, q, p.Sq, hd, hi);
+  load_row_frags<KS>(dof, dOg, p.lddo, q, p.Sq, hd, hi);
+  scale_frags<KS>(qf, p.scale * LOG2E);
+  const int64_t sidx = ((int64_t)b * p.H + h) * p.Sq + q;
+  const float lse2 = p.LSE[sidx] * LOG2E;
+  float delta;
+  {
+    const f16* Og = (const f16*)p.O + (int64_t)b * p.Sq * p.ldo + h * hd;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int col = 16 * j + 8 * hi;
+      if (col < hd) {
+        const f16x8 ov = *(const f16x8*)(Og + (int64_t)q * p.ldo + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)ov[e] * (float)dof[j][e];
+      }
+    }
+    delta = a + __shfl_xor(a, 32, 64);
+    if (hi == 0) {
+      p.Delta[sidx] = delta;
+      if (publish) {
+        p.ws[sidx] = -lse2;
+        p.ws[(int64_t)p.B * p.H * p.Sq + sidx] = -delta;
+      }
+    }
+  }
+  f32x16 neg_lse, neg_delta;  // accumulator inputs of the two products
+  FILL16(neg_lse, -lse2);
+  FILL16(neg_delta, -delta);
+  uint32_t g_off[WI];
+  bool g_on[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave + 4 * i;
+    const int tensor = t >= PC ? 1 : 0;
+    const int f = (t - tensor * PC) * 64 + lane;
+    const int row = f / PC, c = f - row * PC;
+    g_on[i] = t < NI && c < PC - 1;
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + c * 16);
+  }
+  int n_issued = 0;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) n_issued += (wave + 4 * i < NI) ? 1 : 0;
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * STAGE_B;
+    const char* kb = Kg + (int64_t)tile * KVT * ldk * 2;
+    const char* vb = Vg + (int64_t)tile * KVT * ldv * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave + 4 * i;
+      if (t < NI) {
+        const char* src = (t >= PC ? vb : kb) + g_off[i];
+        if (g_on[i]) __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + t * 1024), 16, 0, 0);
+      }
+    }
+  };
+  for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {  // pad chunks: zeros (finite)
+    const int st = u / (2 * KVT), r = u - st * 2 * KVT;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = z;
+  }
+  const int ntiles = Skv / KVT;
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < ntiles) stage_loads(st, st);
+  f32x16 dq[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) ZERO16(dq[d]);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lptr_t)smem_raw;
+  const uint32_t rm_lane = l31 * PCB + hi * 16;
+  const int g4 = lane >> 4, j16 = lane & 15;
+  const uint32_t tr_lane = (4 * (g4 >> 1) + (j16 >> 2)) * PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
+  int slot = 0, lslot = NST - 1;
+  for (int t = 0; t < ntiles; ++t) {
+    {
+      int later = ntiles - 1 - t;
+      later = later > NST - 2 ? NST - 2 : later;
+      attn_wait_vmcnt(later * n_issued);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + NST - 1 < ntiles) stage_loads(t + NST - 1, lslot);
+    const unsigned char* Ks = smem_raw + slot * STAGE_B;
+    const uint32_t ka = lds0 + slot * STAGE_B + tr_lane;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s = neg_lse, dp = neg_delta;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const f16x8 kfr = *(const f16x8*)(Ks + rm_lane + kt * 32 * PCB + j * 32);
+        const f16x8 vfr = *(const f16x8*)(Ks + TILE_B + rm_lane + kt * 32 * PCB + j * 32);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, qf[j], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr, dof[j], dp, 0, 0, 0);
+      }
+      f16x4 ktf[2][DT][2];  // K^T fragments of this 32-key half: issued behind the score products, they arrive under the exponentials
+      __builtin_amdgcn_sched_barrier(0);
+#define TB_TR(KT, JJ, D, HH) ktf[JJ][D][HH] = lds_tr_read_off<((KT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(ka);
+#define TB_TR_ALL(KT)                                                                       \
+  TB_TR(KT, 0, 0, 0) TB_TR(KT, 0, 0, 1) TB_TR(KT, 1, 0, 0) TB_TR(KT, 1, 0, 1) \
+  TB_TR(KT, 0, 1, 0) TB_TR(KT, 0, 1, 1) TB_TR(KT, 1, 1, 0) TB_TR(KT, 1, 1, 1)
+      if (kt == 0) { TB_TR_ALL(0) } else { TB_TR_ALL(1) }
+#undef TB_TR_ALL
+#undef TB_TR
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];  // dS^T / scale
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f16x8 dsf = pack8(s, 8 * jj);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          f16x8 a;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = ktf[jj][d][0][e], a[4 + e] = ktf[jj][d][1][e];
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, dsf, dq[d], 0, 0, 0);
+        }
+      }
+    }
+    slot = slot == NST - 1 ? 0 : slot + 1;
+    lslot = lslot == NST - 1 ? 0 : lslot + 1;
+  }
+  f16* dQg = (f16*)p.dQ + ((int64_t)b * p.Sq + q) * p.lddq + h * hd;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int col = d * 32 + 8 * r4 + 4 * hi;
+      if (col < hd) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(dq[d][4 * r4 + e] * p.scale);
+        *(f16x4*)(dQg + col) = v;
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dK, dV with LDS-DMA staging
 // The dK/dV kernel for the SD1.x self-attention shape (hd = 40, Sq % 64 == 0, Skv % 128 == 0, non-causal), built like attn_fwd_dma_kernel:
 // the streamed Q and dO tiles go HBM -> LDS by global_load_lds_dwordx4, ROW-MAJOR only, through an NST-slot ring with counted vmcnt (one
@@ -1428,7 +1588,17 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
       attr_done = true;
     }
     dim3 grid((d.Sq + 127) / 128, d.H, d.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
+    bool dq_dma = false;
+    if constexpr (DT == 2 && KS == 3) {
+      dq_dma = d.hd == 40 && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 && !(g_attn_dma & 256) && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
+               (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31) && d.Skv >= 512;
+      if (dq_dma) {
+        constexpr int PC = 6, NST = 4;
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<2, 3, PC, NST>), grid, dim3(256), NST * (2 * KVT * PC * 16 + 64), s, d,
+                           (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
+      }
+    }
+    if (!dq_dma) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
   }
   if (dkv_dma) {
     if constexpr (DT == 2 && KS == 3) {
