@@ -191,6 +191,8 @@ int tb_geglu_bwd(const void* dout, int64_t lddo, const void* raw, int64_t ldr, v
                  int inner, tb_stream_t stream);
 /* backward of F.interpolate(scale 2, nearest): dx[b,y,x,:] = sum of the 2x2 block of du (NHWC fp16) */
 int tb_pool2x2_sum(const void* du, int64_t ldu, void* dx, int64_t ldx, int B, int H, int W, int C, tb_stream_t stream);
+/* F.interpolate(scale_factor=2, mode="nearest") of diffusers Upsample2D, materialised: u[B, 2H, 2W, C] from x[B, H, W, C] (NHWC fp16) */
+int tb_upsample2x(const void* x, int64_t ldx, void* u, int64_t ldu, int B, int H, int W, int C, tb_stream_t stream);
 int tb_add_f16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t M, int C, tb_stream_t stream);
 int tb_convert(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int64_t M, int C, float scale,
                tb_stream_t stream);

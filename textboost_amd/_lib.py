@@ -95,6 +95,7 @@ _SIGS = {
     "tb_kpl_mse": ([_VP, _I64, _VP, _I64, _I, _VP, _I64, _VP, _VP, _VP, _F, _I64, _I, _VP], C.c_int),
     "tb_geglu_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_pool2x2_sum": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_upsample2x": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
     "tb_add_f16": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_convert": ([_VP, _I64, _I, _VP, _I64, _I, _I64, _I, _F, _VP], C.c_int),
     "tb_embed_fwd": ([_VP, _VP, _VP, _I, _VP, _I, _I64, _I, _I, _VP], C.c_int),

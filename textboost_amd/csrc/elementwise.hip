@@ -226,6 +226,24 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ 
   *(f16x8*)(dproj + m * lddp + blk * 64 + 32 + j) = dg;
 }
 
+// ---- F.interpolate(nearest, x2) materialised: U[b, y, x, :] = X[b, y >> 1, x >> 1, :] (NHWC fp16, H x W = the INPUT map).  tb_gemm can fold
+// the upsampling into its 3x3 gather, but only the 4-wave kernel does (0.8 PFLOP/s); writing the 4x map (42 MB at 64x64 x 640) costs 12 us and
+// lets the halo-resident wide-tile kernel (1.3 PFLOP/s) take the convolution.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ U, int64_t ldu, int B, int H,
+                                                         int W, int C) {
+  const int vecs = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t M = (int64_t)B * 4 * H * W;
+  if (idx >= M * vecs) return;
+  const int64_t m = idx / vecs;
+  const int v = (int)(idx - m * vecs);
+  const int b = (int)(m / (4 * H * W));
+  const int rem = (int)(m - (int64_t)b * 4 * H * W);
+  const int y = rem / (2 * W), x = rem - y * 2 * W;
+  const int64_t src = ((int64_t)b * H + (y >> 1)) * W + (x >> 1);
+  *(f16x8*)(U + m * ldu + v * 8) = *(const f16x8*)(X + src * ldx + v * 8);
+}
+
 // ---- backward of F.interpolate(nearest, x2): dX[b,y,x,:] = sum of the 2x2 block of dU (NHWC fp16)
 __global__ __launch_bounds__(256) void pool2x2_sum_kernel(const f16* __restrict__ dU, int64_t ldu, f16* __restrict__ dX, int64_t ldx,
                                                           int B, int H, int W, int C) {
@@ -506,6 +524,15 @@ extern "C" int tb_pool2x2_sum(const void* du, int64_t ldu, void* dx, int64_t ldx
   if (!du || !dx || C % 8 || ldu % 8 || ldx % 8) return TB_EINVAL;
   hipLaunchKernelGGL(pool2x2_sum_kernel, GRID1D((int64_t)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)du, ldu,
                      (f16*)dx, ldx, B, H, W, C);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_upsample2x(const void* x, int64_t ldx, void* u, int64_t ldu, int B, int H, int W, int C, tb_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
+  if (!x || !u || C % 8 || ldu % 8 || ldx % 8) return TB_EINVAL;
+  hipLaunchKernelGGL(upsample2x_kernel, GRID1D((int64_t)B * 4 * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, (f16*)u,
+                     ldu, B, H, W, C);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

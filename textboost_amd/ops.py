@@ -292,6 +292,11 @@ def geglu_bwd(dout, raw, dproj):
                                  L.stream()), "tb_geglu_bwd")
 
 
+def upsample2x(x, u, B, H, W, C):
+    """u[B*2H*2W, C] = nearest x2 of x[B*H*W, C] (NHWC fp16)"""
+    L.check(L.lib().tb_upsample2x(L.ptr(x), x.stride(0), L.ptr(u), u.stride(0), B, H, W, C, L.stream()), "tb_upsample2x")
+
+
 def pool2x2_sum(du, dx, B, H, W, C):
     L.check(L.lib().tb_pool2x2_sum(L.ptr(du), du.stride(0), L.ptr(dx), dx.stride(0), B, H, W, C, L.stream()), "tb_pool2x2_sum")
 

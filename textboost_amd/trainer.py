@@ -186,7 +186,7 @@ class TextBoostStep:
         self.side = torch.cuda.Stream(device=device) if self.kpl else None
         # The KPL teacher is the un-adapted encoder on the prior prompts (:1096-1100).  As its own M = 616 pass it was ~90 launches of pure launch
         # latency (0.87 ms); merged, its rows ride along in the student's launches with a zero LoRA operand and the original token table.
-        # Arithmetic: the student's autocast path (fp32 residual stream) instead of the fp16 module's -- closer to the fp32 oracle, not bit-equal
+        # Arithmetic: the student's autocast path (fp32 residual stream) instead of the fp16 module's -- closer to fp32 arithmetic, not bit-equal
         # to the separate pass (TB_SEPARATE_TEACHER=1 keeps that pass).
         self.merge_teacher = self.kpl and text_encoder.r > 0 and os.environ.get("TB_SEPARATE_TEACHER", "0") != "1"
         self.teacher_table32 = teacher.token_table.float().contiguous() if self.merge_teacher else None

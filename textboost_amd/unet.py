@@ -30,6 +30,7 @@ import os as _os
 # GEGLU backward fused into the ff.net.2 dgrad GEMM's epilogue: with the lean wide-tile epilogue it saves the d(gated) round trip
 # (A/B in one process: 35.23 -> 35.06 ms per step); through the 4-wave kernels' generic epilogue it was slower than the streaming kernel
 FUSE_GEGLU_BWD = _os.environ.get("TB_FUSE_GEGLU_BWD", "1") == "1"
+MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  # A/B switch (see the up-block forward)
 
 
 @dataclass
@@ -478,7 +479,14 @@ class HipUNet:
                 nb, nhc = cats[(i + 1, 0)]
                 dst = nb[:, :nhc]
                 name = f"up_blocks.{i}.upsamplers.0.conv"
-                self._conv(x, name, dst, B, hw[lvl][0], hw[lvl][1], hw[lvl - 1][0], hw[lvl - 1][1], upsample=1, bias=P[name + ".b"])
+                if MATERIALIZE_UPSAMPLE and hw[lvl - 1][1] % 16 == 0:
+                    # nearest x2 written out (12 us for the largest map), so that the halo-resident wide-tile kernel takes the convolution
+                    # instead of the 4-wave gather with the upsampling folded in (311 -> ~205 us at 64x64 x 640 channels)
+                    xu = self.scratch("up2x", Ms[lvl - 1], x.shape[1])
+                    ops.upsample2x(x, xu, B, hw[lvl][0], hw[lvl][1], x.shape[1])
+                    self._conv(xu, name, dst, B, hw[lvl - 1][0], hw[lvl - 1][1], hw[lvl - 1][0], hw[lvl - 1][1], bias=P[name + ".b"])
+                else:
+                    self._conv(x, name, dst, B, hw[lvl][0], hw[lvl][1], hw[lvl - 1][0], hw[lvl - 1][1], upsample=1, bias=P[name + ".b"])
                 up_records.append(("up", (name, lvl), x, dst, None))
                 x = dst
         # ---- head
