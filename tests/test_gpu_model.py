@@ -145,6 +145,15 @@ def test_text_encoder_forward_backward_match_oracle():
         t_ref = teacher(pids)
     t_out = hip_teacher.forward(pids.to(dev), slot=0)
     parity("tiny fp16 teacher hidden states", t_out.view(B, 77, D), t_ref, rel=1.5e-3, maxabs=5e-3)
+    # the same teacher rows riding along in the student's launches (extra_ids: zero LoRA operand rows, original token table): the student rows
+    # must be bit-identical to the pass without them, the extra rows equal to the frozen encoder, and the backward must not see them
+    merged = hip.forward(ids.to(dev), slot=0, extra_ids=pids.to(dev), extra_table=hip_teacher.token_table.float())
+    assert torch.equal(merged[:B * 77], out)
+    parity("teacher rows inside the student pass", merged[B * 77:].view(B, 77, D), t_ref, rel=5e-4, maxabs=1e-3)
+    gA0, gB0, gE0 = hip.grad_A.clone(), hip.grad_B.clone(), hip.grad_added.clone()
+    hip.zero_grad()
+    hip.backward(R.view(B * 77, D).to(dev).contiguous(), slot=0)
+    assert torch.equal(hip.grad_A, gA0) and torch.equal(hip.grad_B, gB0) and torch.equal(hip.grad_added, gE0)
 
 
 def build_step(B=2, hw=16, D=64, use_scaler=True, sd2=False, kpl_type="cos", mixing=None, prediction_type="epsilon"):

@@ -111,6 +111,11 @@ def test_geglu_bwd_pool_add_convert():
     ops.pool2x2_sum(du, dx, B, H, W, C)
     ref = F.avg_pool2d(du.float().view(B, 2 * H, 2 * W, C).permute(0, 3, 1, 2), 2) * 4
     assert rel_err(dx.view(B, H, W, C), ref.permute(0, 2, 3, 1)) < 2e-3
+    # nearest x2 (diffusers Upsample2D's F.interpolate), bit exact, also into a column slice of a wider buffer
+    xs = torch.randn(B * H * W, C, device=dev).half(); wide = torch.zeros(B * 4 * H * W, C + 16, device=dev, dtype=torch.float16)
+    ops.upsample2x(xs, wide[:, 8:8 + C], B, H, W, C)
+    refu = F.interpolate(xs.float().view(B, H, W, C).permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(wide[:, 8:8 + C].float().view(B, 2 * H, 2 * W, C), refu) and wide[:, :8].abs().max() == 0 and wide[:, 8 + C:].abs().max() == 0
     a = torch.randn(50, 128, device=dev).half(); bb = torch.randn(50, 256, device=dev).half(); o = torch.empty(50, 128, device=dev, dtype=torch.float16)
     ops.add_f16(a, bb[:, 64:192], o)
     torch.testing.assert_close(o.float(), a.float() + bb[:, 64:192].float(), rtol=2e-3, atol=2e-3)
