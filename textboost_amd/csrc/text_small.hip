@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 // One kernel per slab of LORA_RS rows does all three: (a) lands in LDS (and in dt for the dgrad GEMM), (b)/(c) are per-slab
 // partial sums written to a workspace; blockIdx.y = 0 takes the (b) units, 1 the (c) units so that M / LORA_RS * 2 blocks fill the
 // chip.  A second kernel adds the partials in slab order (deterministic).
-constexpr int LORA_RS = 8;
+#ifndef TB_LORA_RS
+#define TB_LORA_RS 8
+#endif
+constexpr int LORA_RS = TB_LORA_RS;
 constexpr int LORA_MAXR = 24;  // P * r
 template <int RR>  // RR = r when r is 4 or 8 (16-byte vector loads of the B rows, fully unrolled), 0 = generic r <= 8
 __global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ x, int64_t ldx,
@@ -144,8 +147,8 @@ __global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restri
   const int R = P * r;
   const int64_t m0 = (int64_t)blockIdx.x * LORA_RS;
   const int rows = (int)(M - m0 < LORA_RS ? M - m0 : LORA_RS);
-  if (tid < LORA_RS * LORA_MAXR) {
-    const int i = tid / LORA_MAXR, j = tid - i * LORA_MAXR;
+  for (int u = tid; u < LORA_RS * LORA_MAXR; u += 256) {
+    const int i = u / LORA_MAXR, j = u - i * LORA_MAXR;
     ts[i][j] = (i < rows && j < R) ? (float)t[(m0 + i) * ldt + j] : 0.f;
     dts[i][j] = 0.f;  // columns >= R stay zero for (c)'s 4-row units
   }
