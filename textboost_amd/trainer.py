@@ -333,6 +333,11 @@ class TextBoostStep:
         cap = lambda g, **kw: torch.cuda.graph(g, capture_error_mode="thread_local", **kw)  # noqa: E731  (thread_local: the RCCL watchdog
         #                                                                      thread keeps polling its events while this thread captures)
         if dist and single_graph:
+            import torch.distributed as tdist
+            # only RCCL collectives can be captured; with any other backend (gloo in the tests) a failed capture attempt would also leave
+            # torch's CUDA generator registered to the dead graph, so it is not attempted
+            single_graph = tdist.is_initialized() and tdist.get_backend() == "nccl"
+        if dist and single_graph:
             # RCCL collectives are stream-ordered and capturable: the whole step, exchange included, is ONE graph (no host involvement
             # between backward and optimizer).  Falls back to two graphs around an eager all-reduce if the capture is refused.
             try:
