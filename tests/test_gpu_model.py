@@ -302,6 +302,54 @@ def test_collective_paths_with_one_rank_group():
             dist.destroy_process_group()
 
 
+def test_capture_recovers_when_the_collective_cannot_be_captured():
+    """capture(single_graph=True) with a collective that breaks the capture (here: one that synchronises the host) must fall back to the two
+    graphs around an eager exchange and still train -- the failed attempt leaves torch's CUDA generator flagged as capturing, which the
+    fallback has to repair before it can capture again."""
+    import os
+    import torch.distributed as dist
+    from oracle import train_step as ts
+    B, hw, D = 2, 16, 64
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        outs = []
+        for broken in (False, True):
+            st_ref, step, added = build_step(B, hw, D)
+            step.force_dist = True
+            g = torch.Generator().manual_seed(8)
+            step.input_ids.copy_(ts.synthetic_ids(B, added, g)); step.prior_ids.copy_(ts.synthetic_ids(B, added, g, prior=True))
+            step.x0.copy_(torch.randn(B, 4, hw, hw, generator=g))
+            step.external_noise = False      # draw() uses the CUDA generator inside the graph: the state the failed capture leaves behind
+            torch.cuda.manual_seed(1234)
+            if broken:
+                good = step.all_reduce
+                calls = {"n": 0}
+
+                def bad():
+                    calls["n"] += 1
+                    if calls["n"] == 1:      # the captured attempt: a host synchronisation is illegal inside a capture
+                        step.flat_grad.sum().item()
+                    good()
+                step.all_reduce = bad
+            with pytest.warns(UserWarning) if broken else __import__("contextlib").nullcontext():
+                step.capture(warmup=0)
+            assert step.graph_mode == ("two+eager-rccl" if broken else "single+rccl")
+            step.replay(); step.replay()
+            torch.cuda.synchronize()
+            assert step.scalars()["opt_steps"] == 2.0
+            outs.append((step.te.lora_A.clone(), step.te.lora_B.clone(), step.te.token_table[49408:].clone()))
+        for a, b in zip(*outs):          # same seed, same noise stream: the repaired generator continues where the snapshot was taken
+            torch.testing.assert_close(a, b, rtol=0, atol=0)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_sd2_style_models_kpl_mse_and_mixing_match_oracle():
     """BASELINE config 4 structure at small size: Linear proj_in/out + hd 64 UNet, erf-GELU text MLP, plus --kpl_type mse and
     --mixing (object): gradients and updated weights vs the oracle."""

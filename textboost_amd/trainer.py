@@ -340,6 +340,8 @@ class TextBoostStep:
         if dist and single_graph:
             # RCCL collectives are stream-ordered and capturable: the whole step, exchange included, is ONE graph (no host involvement
             # between backward and optimizer).  Falls back to two graphs around an eager all-reduce if the capture is refused.
+            gens = [torch.cuda.default_generators[torch.cuda.current_device()]] + ([self.gen] if self.gen is not None else [])
+            snaps = [g_.get_state() for g_ in gens]
             try:
                 g = G()
                 with cap(g):
@@ -353,7 +355,14 @@ class TextBoostStep:
             except Exception as e:  # noqa: BLE001 -- capture refused by this RCCL / torch build
                 import warnings
                 warnings.warn(f"RCCL all-reduce could not be captured in the step graph ({e}); using two graphs around an eager collective")
+                g = None
                 torch.cuda.synchronize()
+                # a capture that died leaves torch's CUDA generator states flagged "capturing" (capture_end never ran their epilogue) and
+                # the next capture_begin refuses to register them: swap in fresh state objects carrying the pre-capture seed / offset
+                for g_, snap in zip(gens, snaps):
+                    fresh = torch.Generator(device=g_.device)
+                    fresh.set_state(snap)
+                    g_.graphsafe_set_state(fresh.graphsafe_get_state())
         if dist:
             # the collective outside the graphs: two graphs around one eager RCCL call
             self.g1, self.g2 = G(), G()
