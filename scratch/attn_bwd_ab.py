@@ -2,7 +2,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textboost_amd import ops, _lib as L
-B, H, S, hd = 8, 8, 4096, 40; C = H * hd
+B, H, S, hd = 8, 8, int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 40; C = H * hd
 qkv = torch.randn(B * S, 3 * C, device="cuda").half()
 q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
 o = torch.empty(B * S, C, device="cuda", dtype=torch.float16); lse = torch.empty(B, H, S, device="cuda")

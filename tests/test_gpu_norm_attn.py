@@ -209,14 +209,14 @@ def test_attention_forward_fp8_pv(B, H, S, spread):
     assert torch.isfinite(o8).all()
 
 
-@pytest.mark.parametrize("B,H,S", [(2, 8, 1024), (8, 8, 512), (1, 8, 4096)])
-def test_attention_backward_dma_staged_dkv(B, H, S):
-    """the hd = 40 self-attention backward with a ws of 2 * B * H * S floats takes attn_bwd_dkv_dma_kernel (>= 512 key blocks): against fp32
+@pytest.mark.parametrize("B,H,S,hd", [(2, 8, 1024, 40), (8, 8, 512, 40), (1, 8, 4096, 40), (8, 8, 1024, 80), (2, 8, 1024, 80)])
+def test_attention_backward_dma_staged_dkv(B, H, S, hd):
+    """the hd = 40 / 80 self-attention backward with a ws of 2 * B * H * S floats takes attn_bwd_dkv_dma_kernel (>= 512 key blocks): against fp32
     autograd and against the register-staged kernels (bits 128 / 256 of tb_attention_set_variant switch the DMA dK/dV / dQ kernels off)."""
     ops = _ops()
     from textboost_amd import _lib as L
     torch.manual_seed(4)
-    hd, C = 40, H * 40
+    C = H * hd
     qkv = torch.randn(B * S, 3 * C, device="cuda").half()
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     o = torch.empty(B * S, C, device="cuda", dtype=torch.float16)

@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
   constexpr int PCB = PC * 16, TILE_B = KVT * PCB;
   constexpr int STAGE_B = 2 * TILE_B + 64;
   constexpr int NI = 2 * PC, WI = (NI + 3) / 4;
-  static_assert(NST >= 3 && DT == 2, "hd = 40 instantiation; loads run two tiles ahead");
+  static_assert(NST >= 3 && (DT == 2 || DT == 3), "hd = 40 / 80 instantiations; loads run two tiles ahead");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -890,10 +890,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
       f16x4 ktf[2][DT][2];  // K^T fragments of this 32-key half: issued behind the score products, they arrive under the exponentials
       __builtin_amdgcn_sched_barrier(0);
 #define TB_TR(KT, JJ, D, HH) ktf[JJ][D][HH] = lds_tr_read_off<((KT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(ka);
-#define TB_TR_ALL(KT)                                                                       \
-  TB_TR(KT, 0, 0, 0) TB_TR(KT, 0, 0, 1) TB_TR(KT, 1, 0, 0) TB_TR(KT, 1, 0, 1) \
-  TB_TR(KT, 0, 1, 0) TB_TR(KT, 0, 1, 1) TB_TR(KT, 1, 1, 0) TB_TR(KT, 1, 1, 1)
+#define TB_TR_D(KT, D) TB_TR(KT, 0, D, 0) TB_TR(KT, 0, D, 1) TB_TR(KT, 1, D, 0) TB_TR(KT, 1, D, 1)
+#define TB_TR_ALL(KT)                              \
+  TB_TR_D(KT, 0)                                   \
+  TB_TR_D(KT, 1)                                   \
+  if (DT > 2) { TB_TR_D(KT, (DT > 2 ? 2 : 0)) }
       if (kt == 0) { TB_TR_ALL(0) } else { TB_TR_ALL(1) }
+#undef TB_TR_D
 #undef TB_TR_ALL
 #undef TB_TR
       __builtin_amdgcn_sched_barrier(0);
@@ -1053,13 +1056,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const tb_attn_
       f16x4 qtf[2][DT][2], dotf[2][DT][2];
       __builtin_amdgcn_sched_barrier(0);
 #define TB_TR(ARR, BASE, QT, JJ, D, HH) ARR[JJ][D][HH] = lds_tr_read_off<(BASE) + ((QT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(qa);
-#define TB_TR_ALL(QT)                                                                                   \
-  TB_TR(qtf, 0, QT, 0, 0, 0) TB_TR(qtf, 0, QT, 0, 0, 1) TB_TR(qtf, 0, QT, 1, 0, 0) TB_TR(qtf, 0, QT, 1, 0, 1) \
-  TB_TR(qtf, 0, QT, 0, 1, 0) TB_TR(qtf, 0, QT, 0, 1, 1) TB_TR(qtf, 0, QT, 1, 1, 0) TB_TR(qtf, 0, QT, 1, 1, 1) \
-  TB_TR(dotf, TILE_B, QT, 0, 0, 0) TB_TR(dotf, TILE_B, QT, 0, 0, 1) TB_TR(dotf, TILE_B, QT, 1, 0, 0) TB_TR(dotf, TILE_B, QT, 1, 0, 1) \
-  TB_TR(dotf, TILE_B, QT, 0, 1, 0) TB_TR(dotf, TILE_B, QT, 0, 1, 1) TB_TR(dotf, TILE_B, QT, 1, 1, 0) TB_TR(dotf, TILE_B, QT, 1, 1, 1)
-      static_assert(DT == 2, "hd = 40 instantiation");
+#define TB_TR_D(ARR, BASE, QT, D) TB_TR(ARR, BASE, QT, 0, D, 0) TB_TR(ARR, BASE, QT, 0, D, 1) TB_TR(ARR, BASE, QT, 1, D, 0) TB_TR(ARR, BASE, QT, 1, D, 1)
+#define TB_TR_ALL(QT)                                                                   \
+  TB_TR_D(qtf, 0, QT, 0) TB_TR_D(qtf, 0, QT, 1)                                         \
+  if (DT > 2) { TB_TR_D(qtf, 0, QT, (DT > 2 ? 2 : 0)) }                                 \
+  TB_TR_D(dotf, TILE_B, QT, 0) TB_TR_D(dotf, TILE_B, QT, 1)                             \
+  if (DT > 2) { TB_TR_D(dotf, TILE_B, QT, (DT > 2 ? 2 : 0)) }
+      static_assert(DT == 2 || DT == 3, "hd = 40 / 80 instantiations");
       if (qt == 0) { TB_TR_ALL(0) } else { TB_TR_ALL(1) }
+#undef TB_TR_D
 #undef TB_TR_ALL
 #undef TB_TR
       __builtin_amdgcn_sched_barrier(0);
@@ -1570,7 +1575,7 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
   // LDS-DMA staged dK/dV kernel: the SD1.x 64x64-map self-attention shape; needs 2 * B * H * Sq floats of ws for the statistics the dQ
   // kernel publishes for it (else, and for every other shape, the register-staged kernel runs)
-  const bool dkv_dma = DT == 2 && KS == 3 && d.hd == 40 && !d.causal && d.Sq % KVT == 0 && d.Skv % 128 == 0 && !(g_attn_dma & 128) &&
+  const bool dkv_dma = ((DT == 2 && KS == 3 && d.hd == 40) || (DT == 3 && KS == 5 && d.hd == 80 && !(g_attn_dma & 512))) && !d.causal && d.Sq % KVT == 0 && d.Skv % 128 == 0 && !(g_attn_dma & 128) &&
                        d.ws && d.ws_floats >= 2 * (int64_t)d.B * d.H * d.Sq && (int64_t)(d.Skv / 128) * d.H * d.B >= 512 &&
                        d.ldq % 8 == 0 && d.lddo % 8 == 0 && (int64_t)KVT * (d.ldq > d.lddo ? d.ldq : d.lddo) * 2 < ((int64_t)1 << 31);
 #ifndef TB_ATTN_FUSED_DELTA
@@ -1589,22 +1594,37 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     }
     dim3 grid((d.Sq + 127) / 128, d.H, d.B);
     bool dq_dma = false;
-    if constexpr (DT == 2 && KS == 3) {
-      dq_dma = d.hd == 40 && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 && !(g_attn_dma & 256) && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
+    if constexpr ((DT == 2 && KS == 3) || (DT == 3 && KS == 5)) {
+      constexpr int PC = DT == 2 ? 6 : 11, NST = DT == 2 ? 4 : 3;  // hd = 40: 6-chunk rows, 4 slots; hd = 80: 11-chunk rows, 3 slots (68 KB)
+      dq_dma = d.hd == (DT == 2 ? 40 : 80) && !(DT == 3 && (g_attn_dma & 512)) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 &&
+               !(g_attn_dma & 256) && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
                (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31) && d.Skv >= 512;
       if (dq_dma) {
-        constexpr int PC = 6, NST = 4;
-        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<2, 3, PC, NST>), grid, dim3(256), NST * (2 * KVT * PC * 16 + 64), s, d,
-                           (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
+        const size_t ldsq = NST * (2 * KVT * PC * 16 + 64);
+        static bool attr_q = false;
+        if (!attr_q && ldsq > 65536) {
+          if (hipFuncSetAttribute((const void*)attn_bwd_dq_dma_kernel<DT, KS, PC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) !=
+              hipSuccess)
+            return TB_ELAUNCH;
+          attr_q = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DT, KS, PC, NST>), grid, dim3(256), ldsq, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
       }
     }
     if (!dq_dma) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
   }
   if (dkv_dma) {
-    if constexpr (DT == 2 && KS == 3) {
-      constexpr int PC = 6, NST = 4;
+    if constexpr ((DT == 2 && KS == 3) || (DT == 3 && KS == 5)) {
+      constexpr int PC = DT == 2 ? 6 : 11, NST = DT == 2 ? 4 : 3;
       const size_t lds = NST * (2 * KVT * PC * 16 + 2 * KVT * 4 + 64);
-      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<2, 3, PC, NST>), dim3(d.Skv / 128, d.H, d.B), dim3(256), lds, s, d, (g_attn_dma >> 6) & 1);
+      static bool attr_kv = false;
+      if (!attr_kv && lds > 65536) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_dkv_dma_kernel<DT, KS, PC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+          return TB_ELAUNCH;
+        attr_kv = true;
+      }
+      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<DT, KS, PC, NST>), dim3(d.Skv / 128, d.H, d.B), dim3(256), lds, s, d, (g_attn_dma >> 6) & 1);
     }
     TB_CHECK_LAUNCH();
     return TB_OK;
