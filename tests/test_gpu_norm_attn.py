@@ -209,9 +209,9 @@ def test_attention_forward_fp8_pv(B, H, S, spread):
     assert torch.isfinite(o8).all()
 
 
-@pytest.mark.parametrize("B,H,S,hd", [(2, 8, 1024, 40), (8, 8, 512, 40), (1, 8, 4096, 40), (8, 8, 1024, 80), (2, 8, 1024, 80)])
+@pytest.mark.parametrize("B,H,S,hd", [(2, 8, 1024, 40), (8, 8, 512, 40), (1, 8, 4096, 40), (8, 8, 1024, 80), (2, 8, 1024, 80), (1, 5, 9216, 64), (8, 10, 1024, 64)])
 def test_attention_backward_dma_staged_dkv(B, H, S, hd):
-    """the hd = 40 / 80 self-attention backward with a ws of 2 * B * H * S floats takes attn_bwd_dkv_dma_kernel (>= 512 key blocks): against fp32
+    """the hd = 40 / 64 / 80 self-attention backward with a ws of 2 * B * H * S floats takes attn_bwd_dkv_dma_kernel (>= 512 key blocks): against fp32
     autograd and against the register-staged kernels (bits 128 / 256 of tb_attention_set_variant switch the DMA dK/dV / dQ kernels off)."""
     ops = _ops()
     from textboost_amd import _lib as L

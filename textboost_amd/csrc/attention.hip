@@ -1575,7 +1575,8 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
   // LDS-DMA staged dK/dV kernel: the SD1.x 64x64-map self-attention shape; needs 2 * B * H * Sq floats of ws for the statistics the dQ
   // kernel publishes for it (else, and for every other shape, the register-staged kernel runs)
-  const bool dkv_dma = ((DT == 2 && KS == 3 && d.hd == 40) || (DT == 3 && KS == 5 && d.hd == 80 && !(g_attn_dma & 512))) && !d.causal && d.Sq % KVT == 0 && d.Skv % 128 == 0 && !(g_attn_dma & 128) &&
+  const bool dkv_dma = ((DT == 2 && KS == 3 && d.hd == 40) || (DT == 2 && KS == 4 && d.hd == 64 && !(g_attn_dma & 512)) ||
+                        (DT == 3 && KS == 5 && d.hd == 80 && !(g_attn_dma & 512))) && !d.causal && d.Sq % KVT == 0 && d.Skv % 128 == 0 && !(g_attn_dma & 128) &&
                        d.ws && d.ws_floats >= 2 * (int64_t)d.B * d.H * d.Sq && (int64_t)(d.Skv / 128) * d.H * d.B >= 512 &&
                        d.ldq % 8 == 0 && d.lddo % 8 == 0 && (int64_t)KVT * (d.ldq > d.lddo ? d.ldq : d.lddo) * 2 < ((int64_t)1 << 31);
 #ifndef TB_ATTN_FUSED_DELTA
@@ -1594,9 +1595,10 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     }
     dim3 grid((d.Sq + 127) / 128, d.H, d.B);
     bool dq_dma = false;
-    if constexpr ((DT == 2 && KS == 3) || (DT == 3 && KS == 5)) {
-      constexpr int PC = DT == 2 ? 6 : 11, NST = DT == 2 ? 4 : 3;  // hd = 40: 6-chunk rows, 4 slots; hd = 80: 11-chunk rows, 3 slots (68 KB)
-      dq_dma = d.hd == (DT == 2 ? 40 : 80) && !(DT == 3 && (g_attn_dma & 512)) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 &&
+    if constexpr ((DT == 2 && KS == 3) || (DT == 2 && KS == 4) || (DT == 3 && KS == 5)) {
+      // hd = 40: 6-chunk rows, 4 slots; hd = 64 (SD2.x): 9-chunk rows, 4 slots (74 KB); hd = 80: 11-chunk rows, 3 slots (68 KB)
+      constexpr int PC = KS == 3 ? 6 : (KS == 4 ? 9 : 11), NST = DT == 2 ? 4 : 3;
+      dq_dma = d.hd == (KS == 3 ? 40 : (KS == 4 ? 64 : 80)) && !(KS != 3 && (g_attn_dma & 512)) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 &&
                !(g_attn_dma & 256) && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
                (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31) && d.Skv >= 512;
       if (dq_dma) {
@@ -1614,8 +1616,8 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     if (!dq_dma) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
   }
   if (dkv_dma) {
-    if constexpr ((DT == 2 && KS == 3) || (DT == 3 && KS == 5)) {
-      constexpr int PC = DT == 2 ? 6 : 11, NST = DT == 2 ? 4 : 3;
+    if constexpr ((DT == 2 && KS == 3) || (DT == 2 && KS == 4) || (DT == 3 && KS == 5)) {
+      constexpr int PC = KS == 3 ? 6 : (KS == 4 ? 9 : 11), NST = DT == 2 ? 4 : 3;
       const size_t lds = NST * (2 * KVT * PC * 16 + 2 * KVT * 4 + 64);
       static bool attr_kv = false;
       if (!attr_kv && lds > 65536) {

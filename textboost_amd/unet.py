@@ -359,7 +359,7 @@ class HipUNet:
             dqkv = self.scratch("gq", M, 3 * C)
             # ws: 2 x [B, heads, HW] floats -- lets the hd = 40 / 64x64-map layers take the LDS-DMA staged dK/dV kernel (the dQ kernel
             # publishes -lse log2 e and -delta there for it); other shapes ignore it
-            sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 80) and HW % 128 == 0 else None
+            sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 64, 80) and HW % 128 == 0 else None
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, do1, delta, dqkv[:, :C], dqkv[:, C:2 * C],
                               dqkv[:, 2 * C:], B, heads, HW, HW, hd, ws=sws)
             dl1 = self.scratch("g2", M, C)
