@@ -19,6 +19,8 @@ for g in big[-4:]:
     gs = sorted(gaps)
     print(f"replay: {n} kernels, sum of durations {dur/1e6:.3f} ms, span {span/1e6:.3f} ms, idle between kernels {sum(gaps)/1e6:.3f} ms "
           f"(median gap {gs[n//2]/1e3:.2f} us, p90 {gs[int(n*0.9)]/1e3:.2f} us, max {gs[-1]/1e3:.1f} us), overlap {ov/1e6:.3f} ms")
+for a, b in zip(big[-5:], big[-4:]):
+    print(f"between replays: {(b[0][1] - a[-1][2]) / 1e3:.1f} us idle (first kernel of the next replay: {b[0][0][:40]})")
 g = big[-1]
 after = collections.defaultdict(lambda: [0, 0.0])
 for a, b in zip(g, g[1:]):
