@@ -132,7 +132,10 @@ typedef struct tb_attn_desc {
   void* dV; int64_t lddv;
   float* ws; int64_t ws_floats;  /* optional scratch (n * 2*B*Skv*H*hd floats, n >= 2): lets the dK/dV kernel split the query
                                   * range over up to n blocks per key block (per-slice fp32 partials summed in a fixed order)
-                                  * when Skv is too short to fill the chip (cross-attention) */
+                                  * when Skv is too short to fill the chip (cross-attention).  With >= 2*B*H*Sq floats it also enables the
+                                  * LDS-DMA staged dK/dV kernel of the hd = 40 / 64 / 80 self-attention shapes (Sq % 64 == 0, Skv % 128 == 0,
+                                  * >= 512 key blocks): the dQ kernel publishes -lse*log2(e) and -delta there for it.  The two uses exclude
+                                  * each other (the split needs < 512 key blocks) */
   void* fp8_ws; int64_t fp8_ws_bytes;  /* forward only, opt-in (BASELINE.json configs[4]): non-NULL with >= tb_attention_fp8_ws_bytes(B, H, Skv)
                                         * bytes makes the hd = 40 self-attention forward (Sq % 256 == 0, Skv % 256 == 0, non-causal) compute
                                         * P V with e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (P rounded in registers, V through a
@@ -142,7 +145,9 @@ typedef struct tb_attn_desc {
 int64_t tb_attention_fp8_ws_bytes(int B, int H, int Skv);
 int tb_attention_fwd(const tb_attn_desc* d, tb_stream_t stream);
 int tb_attention_bwd(const tb_attn_desc* d, tb_stream_t stream);
-/* A/B knob: bit 0 = LDS-DMA staged forward kernel for the hd = 40 / 80 self-attention shapes (default on); returns the previous value */
+/* A/B knob (default 1): bit 0 = LDS-DMA staged forward kernel for the hd = 40 self-attention shape, 2 = also hd = 80, 4 = no XCD block remap in
+ * the forward, 64 = XCD remap in the backward, 128 / 256 = register-staged dK/dV / dQ kernels instead of the DMA ones, 512 = DMA backward only
+ * for hd = 40; returns the previous value */
 int tb_attention_set_variant(int bits);
 
 /* ---- scheduler / boundary / loss / misc streaming kernels ------------------------------------------ */
