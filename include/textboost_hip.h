@@ -90,6 +90,8 @@ const char* tb_last_hip_error(void);
  * the input gradient is produced.  stats = [B, G, 2] (mean, rstd) written by fwd, read by bwd.
  * ws = tb_groupnorm_ws_floats(...) floats of scratch.  bwd: dx = GN'(dy) (+ add). */
 int64_t tb_groupnorm_ws_floats(int B, int HW, int C, int G);
+/* A/B knob: 1 (default) = small maps with 8-aligned groups run one-pass per-(image, group) kernels, 0 = always the two-pass kernels */
+int tb_groupnorm_set_variant(int fused);
 int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                      float* stats, float* ws, int B, int HW, int C, int G, float eps, int silu, tb_stream_t stream);
 int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,

@@ -12,6 +12,7 @@ def apply(codes):
     for c in codes:
         if c.startswith("g8:"): lib.tb_gemm8_set(int(c[3:]))
         elif c.startswith("attn:"): lib.tb_attention_set_variant(int(c[5:]))
+        elif c.startswith("gn:"): lib.tb_groupnorm_set_variant(int(c[3:]))
         else: lib.tb_gemm_set_variant(int(c))
 configs = []
 for a in sys.argv[1:]:

@@ -17,7 +17,9 @@ def rel_err(a, b):
 
 @pytest.mark.parametrize("B,HW,C,silu,extra", [(2, 256, 320, True, 0), (3, 100, 640, False, 64), (1, 64, 1280, True, 0),
                                                (2, 1024, 960, True, 0), (2, 64, 2560, True, 0), (2, 256, 1920, False, 0),
-                                               (2, 144, 64, True, 0)])
+                                               (2, 144, 64, True, 0),
+                                               # >= 128 (image, group) slices with 8-aligned groups: the one-pass per-slice kernels
+                                               (8, 256, 1280, True, 0), (4, 64, 2560, True, 0), (8, 256, 2560, False, 64), (8, 64, 1280, True, 0)])
 def test_groupnorm_fwd_bwd(B, HW, C, silu, extra):
     ops = _ops()
     torch.manual_seed(0)
@@ -42,6 +44,15 @@ def test_groupnorm_fwd_bwd(B, HW, C, silu, extra):
     ref.backward(dy.float().view(B, HW, C).permute(0, 2, 1))
     gref = xr.grad.permute(0, 2, 1).reshape(M, C) + add.float()
     assert rel_err(dx, gref) < 3e-3
+    if B * 32 >= 128 and (C // 32) % 8 == 0:  # the fused kernels ran: the two-pass kernels must agree (same fp32 arithmetic, other summation order)
+        from textboost_amd import _lib as L
+        prev = L.lib().tb_groupnorm_set_variant(0)
+        y2, dx2, stats2 = torch.empty_like(y), torch.empty_like(dx), torch.empty_like(stats)
+        ops.groupnorm_fwd(x, y2, gamma, beta, stats2, ws, B, HW, C, eps=1e-5, silu=silu)
+        ops.groupnorm_bwd(dy, x, gamma, beta, stats2, dx2, ws, B, HW, C, silu=silu, add=add)
+        L.lib().tb_groupnorm_set_variant(prev)
+        torch.testing.assert_close(stats, stats2, rtol=1e-5, atol=1e-6)
+        assert rel_err(y, y2) < 1e-4 and rel_err(dx, dx2) < 1e-4
 
 
 @pytest.mark.parametrize("M,C,xdt", [(616, 768, torch.float32), (1000, 320, torch.float16), (77, 1280, torch.float16),

@@ -68,6 +68,7 @@ _SIGS = {
     "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_gemm_last_config": ([_VP], None),
     "tb_attention_set_variant": ([_I], C.c_int),
+    "tb_groupnorm_set_variant": ([_I], C.c_int),
     "tb_attention_fp8_ws_bytes": ([_I, _I, _I], C.c_int64),
     "tb_gemm8_set": ([_I], C.c_int),
     "tb_gemm8_last": ([_VP], C.c_int),

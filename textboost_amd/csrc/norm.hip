@@ -368,6 +368,140 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------- GroupNorm, one workgroup per (image, group)
+// Small maps with 8-aligned groups (C = 1280 / 2560 at 16x16 and 8x8: 40 / 80 channels per group): the whole (image, group) slice -- HW rows
+// of C / G / 8 16-byte vectors, <= GNF_VPT per thread -- is loaded ONCE into registers, reduced in the block and normalised from the
+// registers: one launch and one pass over x (and dy) instead of the statistics pass + the apply pass.  At these sizes the two-pass kernels
+// are launch latency (6 - 13 us each for 1 - 5 MB tensors).
+constexpr int GNF_VPT = 10;
+__device__ __forceinline__ void gnf_block_sum2(float& a, float& b, float* red /* [8] */) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // (red may still be read from a previous call)
+  if ((threadIdx.x & 63) == 0) red[wave] = a, red[4 + wave] = b;
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ stats, int HW, int C, int G, float eps, int silu) {
+  __shared__ float red[8];
+  const int g = blockIdx.x, b = blockIdx.y, gs = C / G, cv = gs >> 3;
+  const int items = HW * cv;
+  const f16* xb = X + (int64_t)b * HW * ldx + g * gs;
+  f16* yb = Y + (int64_t)b * HW * ldy + g * gs;
+  f16x8 v[GNF_VPT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < GNF_VPT; ++i) {
+    const int it = threadIdx.x + i * 256;
+    if (it < items) {
+      const int r = it / cv, c = it - r * cv;
+      v[i] = *(const f16x8*)(xb + (int64_t)r * ldx + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[i][e];
+        s += f;
+        q += f * f;
+      }
+    }
+  }
+  gnf_block_sum2(s, q, red);
+  const float n = (float)gs * (float)HW;
+  const float mean = s / n;
+  const float rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+  if (threadIdx.x == 0) {
+    stats[((int64_t)b * G + g) * 2 + 0] = mean;
+    stats[((int64_t)b * G + g) * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < GNF_VPT; ++i) {
+    const int it = threadIdx.x + i * 256;
+    if (it < items) {
+      const int r = it / cv, c = it - r * cv;
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = g * gs + c * 8 + e;
+        const float sc = rstd * gamma[ch];
+        const float z = (float)v[i][e] * sc + (beta[ch] - mean * sc);
+        o[e] = (f16)(silu ? silu_f(z) : z);
+      }
+      *(f16x8*)(yb + (int64_t)r * ldy + c * 8) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ X, int64_t ldx,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, const f16* __restrict__ add, int64_t ldadd,
+                                                           f16* __restrict__ dX, int64_t lddx, int HW, int C, int G, int silu) {
+  __shared__ float red[8];
+  const int g = blockIdx.x, b = blockIdx.y, gs = C / G, cv = gs >> 3;
+  const int items = HW * cv;
+  const f16* xb = X + (int64_t)b * HW * ldx + g * gs;
+  const f16* dyb = dY + (int64_t)b * HW * lddy + g * gs;
+  const f16* ab = add ? add + (int64_t)b * HW * ldadd + g * gs : nullptr;
+  f16* dxb = dX + (int64_t)b * HW * lddx + g * gs;
+  const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
+  f16x8 xh[GNF_VPT], dh[GNF_VPT];  // the slice's x and dy rows (both passes below work from these registers)
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < GNF_VPT; ++i) {
+    const int it = threadIdx.x + i * 256;
+    if (it < items) {
+      const int r = it / cv, c = it - r * cv;
+      xh[i] = *(const f16x8*)(xb + (int64_t)r * ldx + c * 8);
+      dh[i] = *(const f16x8*)(dyb + (int64_t)r * lddy + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = g * gs + c * 8 + e;
+        const float ga = gamma[ch];
+        const float x_ = ((float)xh[i][e] - mu) * rs;
+        float d = (float)dh[i][e];
+        if (silu) d *= silu_grad_f(x_ * ga + beta[ch]);
+        d *= ga;
+        s1 += d;
+        s2 += d * x_;
+      }
+    }
+  }
+  gnf_block_sum2(s1, s2, red);
+  const float n = (float)gs * (float)HW;
+  const float m1 = s1 / n, m2 = s2 / n;
+#pragma unroll
+  for (int i = 0; i < GNF_VPT; ++i) {
+    const int it = threadIdx.x + i * 256;
+    if (it < items) {
+      const int r = it / cv, c = it - r * cv;
+      f16x8 av;
+      if (ab) av = *(const f16x8*)(ab + (int64_t)r * ldadd + c * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = g * gs + c * 8 + e;
+        const float ga = gamma[ch];
+        const float x_ = ((float)xh[i][e] - mu) * rs;
+        float d = (float)dh[i][e];
+        if (silu) d *= silu_grad_f(x_ * ga + beta[ch]);
+        d *= ga;
+        float dx = rs * (d - m1 - x_ * m2);
+        if (ab) dx += (float)av[e];
+        o[e] = (f16)dx;
+      }
+      *(f16x8*)(dxb + (int64_t)r * lddx + c * 8) = o;
+    }
+  }
+}
+int g_gn_fused = 1;  // tb_groupnorm_set_variant: 0 = always the two-pass kernels
+inline bool gn_fused_ok(int B, int HW, int C, int G) {
+  const int gs = C / G;
+  return g_gn_fused && gs % 8 == 0 && (int64_t)HW * (gs / 8) <= 256 * GNF_VPT && (int64_t)B * G >= 128;
+}
+
 // ------------------------------------------------------------------------------------------- LayerNorm
 constexpr int LN_MAXV = 3;  // vectors of 8 per lane -> C <= 1536
 
@@ -544,6 +678,12 @@ extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy
   if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || ldy % 8 || B <= 0 || HW <= 0) return TB_EINVAL;
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
+  if (gn_fused_ok(B, HW, C, G)) {
+    hipLaunchKernelGGL(gn_fused_fwd_kernel, dim3(G, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, HW, C, G, eps,
+                       silu);
+    TB_CHECK_LAUNCH();
+    return TB_OK;
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)x, ldx, ws, HW, C, G, nch);
 #ifndef TB_GN_INBLOCK
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, stats, HW, C, G, nch, eps, 0);
@@ -562,6 +702,12 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || lddy % 8 || lddx % 8 || (add && ldadd % 8)) return TB_EINVAL;
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
+  if (gn_fused_ok(B, HW, C, G)) {
+    hipLaunchKernelGGL(gn_fused_bwd_kernel, dim3(G, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
+                       (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, silu);
+    TB_CHECK_LAUNCH();
+    return TB_OK;
+  }
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
                      ws, HW, C, G, nch, silu);
 #ifdef TB_GN_INBLOCK
@@ -630,4 +776,10 @@ extern "C" int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, cons
     return TB_EINVAL;
   TB_CHECK_LAUNCH();
   return TB_OK;
+}
+
+extern "C" int tb_groupnorm_set_variant(int fused) {  // A/B: 0 = the two-pass kernels for every shape; returns the previous value
+  const int old = g_gn_fused;
+  g_gn_fused = fused;
+  return old;
 }
