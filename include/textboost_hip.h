@@ -108,6 +108,10 @@ int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t l
 int tb_layernorm_lora_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
                           const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, void* t /* fp16 */,
                           int64_t ldt, tb_stream_t stream);
+/* same, with the down projection only for rows < lora_rows (a frozen batch without adapters behind them: the KPL teacher rows) */
+int tb_layernorm_lora_rows_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                               const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, void* t /* fp16 */,
+                               int64_t ldt, int64_t lora_rows, tb_stream_t stream);
 /* dx16 (optional, may be NULL): an fp16 copy of dx for the next dgrad GEMM (saves a conversion pass over the fp32 stream) */
 int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,
                      const float* gamma, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx,

@@ -78,6 +78,7 @@ _SIGS = {
     "tb_groupnorm_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I, _I, _I, _I, _I, _VP], C.c_int),
     "tb_layernorm_fwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _I, _F, _VP], C.c_int),
     "tb_layernorm_lora_fwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _I, _F, _VP, _I, _VP, _I64, _VP], C.c_int),
+    "tb_layernorm_lora_rows_fwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _I, _F, _VP, _I, _VP, _I64, _I64, _VP], C.c_int),
     "tb_layernorm_bwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_attention_fwd": ([C.POINTER(AttnDesc), _VP], C.c_int),
     "tb_attention_bwd": ([C.POINTER(AttnDesc), _VP], C.c_int),

@@ -547,7 +547,7 @@ template <typename T, typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, int64_t ldx, TO* __restrict__ Y, int64_t ldy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ stats, int64_t M, int C, float eps,
-                                                     const float* __restrict__ loraA, int R, f16* __restrict__ tdown, int64_t ldt) {
+                                                     const float* __restrict__ loraA, int R, f16* __restrict__ tdown, int64_t ldt, int64_t lora_rows) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
       for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
     }
   }
-  if (loraA) {
+  if (loraA && row < lora_rows) {  // (rows >= lora_rows: a frozen batch riding along -- their rows of tdown are left as they are, zero)
     // fused LoRA down projection (lora_A of peft lora.Linear on the normalised row): tdown[row, j] = sum_k y[row,k] * fp16(A[j,k]);
     // the row is still in registers, the R <= 24 adapter rows are L2 resident
     for (int j = 0; j < R; ++j) {
@@ -723,7 +723,7 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
 }
 
 static int ln_fwd_launch(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
-                         const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, f16* tdown, int64_t ldt,
+                         const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, f16* tdown, int64_t ldt, int64_t lora_rows,
                          tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!x || !y || !gamma || !beta || M <= 0) return TB_EINVAL;
@@ -732,11 +732,11 @@ static int ln_fwd_launch(const void* x, int64_t ldx, int x_dtype, void* y, int64
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 3) / 4));
   if (x_dtype == TB_F32 && y_dtype == TB_F16)
-    hipLaunchKernelGGL((ln_fwd_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt);
+    hipLaunchKernelGGL((ln_fwd_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt, lora_rows);
   else if (x_dtype == TB_F32 && y_dtype == TB_F32)
-    hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt);
+    hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt, lora_rows);
   else if (x_dtype == TB_F16 && y_dtype == TB_F16)
-    hipLaunchKernelGGL((ln_fwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt);
+    hipLaunchKernelGGL((ln_fwd_kernel<f16, f16>), grid, dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt, lora_rows);
   else
     return TB_EINVAL;
   TB_CHECK_LAUNCH();
@@ -745,14 +745,21 @@ static int ln_fwd_launch(const void* x, int64_t ldx, int x_dtype, void* y, int64
 
 extern "C" int tb_layernorm_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
                                 const float* beta, float* stats, int64_t M, int C, float eps, tb_stream_t stream) {
-  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, nullptr, 0, nullptr, 0, stream);
+  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 extern "C" int tb_layernorm_lora_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
                                      const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, void* t,
                                      int64_t ldt, tb_stream_t stream) {
   if (!loraA) return TB_EINVAL;
-  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, loraA, R, (f16*)t, ldt, stream);
+  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, loraA, R, (f16*)t, ldt, M, stream);
+}
+
+extern "C" int tb_layernorm_lora_rows_fwd(const void* x, int64_t ldx, int x_dtype, void* y, int64_t ldy, int y_dtype, const float* gamma,
+                                          const float* beta, float* stats, int64_t M, int C, float eps, const float* loraA, int R, void* t,
+                                          int64_t ldt, int64_t lora_rows, tb_stream_t stream) {
+  if (!loraA || lora_rows < 0 || lora_rows > M) return TB_EINVAL;
+  return ln_fwd_launch(x, ldx, x_dtype, y, ldy, y_dtype, gamma, beta, stats, M, C, eps, loraA, R, (f16*)t, ldt, lora_rows, stream);
 }
 
 extern "C" int tb_layernorm_bwd(const void* dy, int64_t lddy, int dy_dtype, const void* x, int64_t ldx, int x_dtype,

@@ -152,9 +152,15 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G=32, silu=False,
     return dx
 
 
-def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5, lora_A=None, t=None):
-    """lora_A fp32 [R, C] + t fp16 [M, >=R]: also write the LoRA down projection of the normalised rows into t[:, :R]."""
+def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5, lora_A=None, t=None, lora_rows=None):
+    """lora_A fp32 [R, C] + t fp16 [M, >=R]: also write the LoRA down projection of the normalised rows into t[:, :R]
+    (only for rows < lora_rows when given: the rows behind them belong to a frozen batch and keep their zero t)."""
     M, Cc = y.shape
+    if lora_A is not None and lora_rows is not None and lora_rows < M:
+        L.check(L.lib().tb_layernorm_lora_rows_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), _dt(y), L.ptr(gamma), L.ptr(beta),
+                                                   L.ptr(stats), M, Cc, eps, L.ptr(lora_A), lora_A.shape[0], L.ptr(t), t.stride(0), lora_rows,
+                                                   L.stream()), "tb_layernorm_lora_rows_fwd")
+        return y
     if lora_A is not None:
         L.check(L.lib().tb_layernorm_lora_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), _dt(y), L.ptr(gamma), L.ptr(beta),
                                               L.ptr(stats), M, Cc, eps, L.ptr(lora_A), lora_A.shape[0], L.ptr(t), t.stride(0), L.stream()),

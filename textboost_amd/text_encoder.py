@@ -170,9 +170,7 @@ class HipTextEncoder:
             qkv = self.buf(p + "qkv", M, 3 * D, f16)
             if self.r:
                 t = self.buf(p + "t", M, 64, f16)  # columns >= 3r (and the frozen extra rows) stay zero (K-extension operand of the qkv GEMM)
-                ops.layernorm_fwd(h[:Ms], x1[:Ms], W["ln1.g"], W["ln1.b"], ls1[:Ms], geo.eps, lora_A=self.lora_A[i], t=t[:Ms])
-                if M > Ms:
-                    ops.layernorm_fwd(h[Ms:], x1[Ms:], W["ln1.g"], W["ln1.b"], ls1[Ms:], geo.eps)
+                ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps, lora_A=self.lora_A[i], t=t, lora_rows=Ms)
                 ops.gemm(x1, W["qkv.w"], qkv, A2=t, W2=self.w2_fwd[i], bias=W["qkv.b"])
             else:
                 ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
