@@ -299,3 +299,86 @@ def test_step_invariants_at_batch_16():
     first = te.first_added
     torch.testing.assert_close(te.token_table[:first], w0[:first] * (1 - 1e-3 * 1e-2), rtol=2e-6, atol=0)
     assert torch.isfinite(te.token_table[first:]).all() and torch.isfinite(te.lora_B).all()
+
+
+def test_sd15_full_step_at_the_metric_batch_vs_oracle():
+    """BASELINE.json configs[1], the benchmarked launches themselves (B=8 tiles, split-K factors, XCD remaps, the hd = 40 attention
+    backward): ONE full-size forward + backward of the step's differentiable chain -- trainable CLIP-L (LoRA r=4, added rows) -> fp16
+    hidden states -> SD1.5 UNet forward -> UNet dgrad backward -> d(ehs) -> CLIP-L backward -> LoRA A / B and added-row gradients
+    (train_textboost.py:1054-1067, :1108) -- against the fp32 oracle, plus the frozen KPL teacher rows that ride in the student's launches
+    (:1096-1100).  The oracle runs the 8 samples one at a time (samples are independent; parameter gradients accumulate), which bounds
+    its memory to a B=1 autograd graph.  Tolerances: the existing full-size ones for pred / d_ehs; gradients that went through BOTH
+    networks 4e-3 / 6e-3 / 1e-2 (the small-config whole-step bound)."""
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle import train_step as ts
+    from oracle.unet_sd import UNetConfig
+    from textboost_amd import models
+    from textboost_amd.text_encoder import HipTextEncoder
+    torch.manual_seed(0)
+    B, T, D = 8, 77, 768
+    ref_unet, hip_unet = _full_unet_pair(models.SD15_UNET, UNetConfig.sd15(), 83, B, 64)
+    for p in ref_unet.parameters():
+        p.requires_grad_(False)                      # frozen (:696): dgrad only, like the product
+    csd = models.random_state_dict(models.clip_shapes(models.SD15_CLIP), 84, device="cpu")
+    base = TextBoostEncoder(CLIPTextCfg.sd15(), r=0)
+    base.load_hf_state_dict(csd)
+    ref = TextBoostEncoder(CLIPTextCfg.sd15(), r=4)
+    ref.load_hf_state_dict(csd)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.02)
+        null = base.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    ref.set_null_embedding(null)
+    base.set_null_embedding(null)
+    added = add_tokens(ref, [11, 22, 33])
+    hip = HipTextEncoder(models.SD15_CLIP, csd, B, mode="autocast", lora_rank=4, n_slots=2, device=dev, seed=0)
+    hip.set_null_embedding(null)
+    hip.add_tokens([11, 22, 33])
+    for i, layer in enumerate(ref.layers):
+        hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
+        hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
+    g = torch.Generator().manual_seed(6)
+    ids = ts.synthetic_ids(B, added, g)
+    pids = ts.synthetic_ids(B, added, g, prior=True)
+    pids[2, 1:] = 49407                              # one null prior prompt (--null_prob): pinned rows
+    x = torch.randn(B, 4, 64, 64, generator=g).half().float()
+    t = torch.tensor([999, 0, 611, 250, 17, 801, 500, 333])
+    dpred = torch.randn(B, 4, 64, 64, generator=g)
+    # ---- oracle, one sample at a time
+    preds, dehs = [], []
+    for b in range(B):
+        h = ref(ids[b:b + 1])
+        h.retain_grad()
+        p = ref_unet(x[b:b + 1], t[b:b + 1], h)
+        (p * dpred[b:b + 1]).sum().backward()
+        preds.append(p.detach())
+        dehs.append(h.grad.detach())
+    pred_ref, dehs_ref = torch.cat(preds), torch.cat(dehs)
+    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
+    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
+    gE = ref.token_embedding.weight.grad[added]
+    with torch.no_grad():
+        teacher_ref = base(pids)
+    # ---- HIP path: the step's own call sequence (trainer._phase_student / _phase_unet_* / _phase_encoder_backward)
+    from textboost_amd import ops
+    hip.pack_lora()
+    table0 = torch.empty(49408, D)
+    table0.copy_(csd["text_model.embeddings.token_embedding.weight"])
+    out = hip.forward(ids.to(dev), slot=0, extra_ids=pids.to(dev), extra_table=table0.to(dev))
+    h_hip, h_teacher = out[:B * T], out[B * T:]
+    parity("B=8 teacher rows inside the student pass (CLIP-L)", h_teacher.view(B, T, D), teacher_ref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-2)
+    assert torch.equal(h_teacher.view(B, T, D)[2].cpu(), null)
+    ehs16 = torch.empty(B * T, D, device=dev, dtype=torch.float16)
+    ops.convert(h_hip, ehs16)
+    pred = hip_unet.forward(x.half().to(dev), t.to(dev), ehs16)
+    parity("B=8 step: UNet pred", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
+    d_ehs = hip_unet.backward(dpred.to(dev))
+    parity("B=8 step: d_ehs", d_ehs.view(B, T, D), dehs_ref, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
+    for b in range(B):  # no sample may hide behind the others
+        parity(f"  d_ehs sample {b}", d_ehs.view(B, T, D)[b], dehs_ref[b], rel=6e-3, maxabs=8e-3, verbose=False)
+    hip.zero_grad()
+    hip.backward(d_ehs.float().contiguous(), slot=0)
+    parity("B=8 step: grad lora_A", hip.grad_A, gA, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+    parity("B=8 step: grad lora_B", hip.grad_B, gB, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+    parity("B=8 step: grad added rows", hip.grad_added, gE, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)

@@ -221,3 +221,46 @@ def test_geometry_from_published_model_configs():
         models.unet_geometry_from_config(dict(sd15_unet, down_block_types=["DownBlock2D"] * 4))  # mirror check: up blocks still cross-attn
     with pytest.raises(NotImplementedError):
         models.clip_geometry_from_config(dict(clip_l, hidden_act="relu"))
+
+
+# ------------------------------------------------------------------------------ bench.py --gpus N launch logic (run_textboost_db.py:106-111)
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_gpus_flag_decides_the_launch():
+    """`python bench.py --gpus N` with no launcher around it must itself start N ranks (the reference's driver runs
+    `torchrun --nproc-per-node=len(gpus)`), must refuse N > visible GPUs, and inside an existing launch must agree with WORLD_SIZE."""
+    b = _bench()
+    assert b.plan_launch(1, {}, 1) == {"action": "run", "world": 1, "rank": 0, "local": 0}
+    assert b.plan_launch(8, {}, 8) == {"action": "spawn", "world": 8}
+    p = b.plan_launch(2, {}, 1)  # a 1-GPU box asked for 2 GPUs: loud error, never a silent 1-GPU run
+    assert p["action"] == "error" and "exposes 1 GPU" in p["message"]
+    env = {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3"}
+    assert b.plan_launch(4, env, 8) == {"action": "run", "world": 4, "rank": 3, "local": 3}
+    assert b.plan_launch(8, env, 8)["action"] == "error"          # --gpus disagrees with the launcher
+    assert b.plan_launch(4, env, 2)["action"] == "error"          # LOCAL_RANK 3 on a 2-GPU node
+    assert b.plan_launch(0, {}, 8)["action"] == "error"
+    cmd = b.launcher_command(8, ["--gpus", "8", "--steps", "5"], 29999, python="py", script="bench.py")
+    assert cmd == ["py", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29999", "bench.py", "--gpus", "8", "--steps", "5"]
+    assert 1024 < b.free_port() < 65536
+
+
+def test_bench_spawn_starts_n_ranks_with_the_rank_environment(tmp_path, monkeypatch):
+    """spawn_ranks() end to end on CPU: the launcher command it builds really starts N processes that see RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 (a stand-in script takes bench.py's place: no GPU here)."""
+    import subprocess
+    b = _bench()
+    script = tmp_path / "probe.py"
+    script.write_text("import os,sys\nopen(os.path.join(sys.argv[1], 'r%s' % os.environ['RANK']), 'w').write("
+                      "'%s %s %s %s' % (os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], os.environ['MASTER_ADDR'], sys.argv[2]))\n")
+    cmd = b.launcher_command(2, [str(tmp_path), "--gpus=2"], b.free_port(), script=str(script))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "r0").read_text() == "2 0 127.0.0.1 --gpus=2"
+    assert (tmp_path / "r1").read_text() == "2 1 127.0.0.1 --gpus=2"

@@ -118,8 +118,8 @@ def load_trainer_state(step_obj, ckpt_dir: str):
         te.token_table[te.first_added:].copy_(model["token_embedding.added_rows"])
         n = opt["orig_rows_decay_steps"]
         te.token_table[: te.first_added].mul_((1.0 - step_obj.hp.emb_lr * step_obj.hp.wd) ** n)
-    if "lr_table" in opt and opt["lr_table"] is not None and getattr(step_obj, "lr_table", None) is None:
-        step_obj.set_lr_table(opt["lr_table"].tolist())
+    # the lr schedule is NOT restored: LambdaLR's lambdas always come from the current command line (:911-916); the caller sets the table
+    # (or, for a constant schedule, resets the multiplier slot the checkpointed `state` carried)
     with open(os.path.join(ckpt_dir, "random_states_0.pkl"), "rb") as f:
         rs = pickle.load(f)
     if "random_state" in rs:

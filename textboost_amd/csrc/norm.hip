@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
       for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
     }
   }
-  if (loraA && row < lora_rows) {  // (rows >= lora_rows: a frozen batch riding along -- their rows of tdown are left as they are, zero)
+  if (loraA && row < lora_rows) {  // (rows >= lora_rows: a frozen batch riding along -- their rows of tdown are zeroed below)
     // fused LoRA down projection (lora_A of peft lora.Linear on the normalised row): tdown[row, j] = sum_k y[row,k] * fp16(A[j,k]);
     // the row is still in registers, the R <= 24 adapter rows are L2 resident
     for (int j = 0; j < R; ++j) {
@@ -613,6 +613,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
       a = wave_sum(a);
       if (lane == 0) tdown[row * ldt + j] = (f16)a;
     }
+  } else if (loraA && lane < R) {
+    // a frozen row riding along (KPL teacher): its K-extension operand must be zero whatever an earlier call left in the buffer
+    tdown[row * ldt + lane] = (f16)0.f;
   }
 }
 

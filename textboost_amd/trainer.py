@@ -182,6 +182,7 @@ class TextBoostStep:
         self.kpl_partial = torch.empty(B * te.T, device=device)
         self.added_norms = torch.empty(max(te.n_added, 1), device=device)
         self.graph = None
+        self.graph_mode = "eager"
         self.external_noise = False
         self.side = torch.cuda.Stream(device=device) if self.kpl else None
         # The KPL teacher is the un-adapted encoder on the prior prompts (:1096-1100).  As its own M = 616 pass it was ~90 launches of pure launch

@@ -317,11 +317,13 @@ def main(args):
         if path == "latest":
             dirs = sorted([d for d in os.listdir(args.output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
             path = os.path.join(args.output_dir, dirs[-1]) if dirs else None
+            if path is None:
+                print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")  # :968-972
         else:  # :961-981: only the basename counts, the checkpoint is looked up under --output_dir
             path = os.path.join(args.output_dir, os.path.basename(path.rstrip("/")))
-            if not os.path.isdir(path):
-                print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")  # :968-972
-                path = None
+            if not os.path.isdir(path):  # the reference's soft "Starting a new training run" is only reachable for "latest" (:968-972); an
+                # explicit name that does not exist fails in accelerator.load_state -- a typo must not silently retrain from step 0
+                raise FileNotFoundError(f"--resume_from_checkpoint {args.resume_from_checkpoint!r}: no such checkpoint directory {path}")
         if path:
             ckpt.load_trainer_state(step, path)  # also restores the torch / numpy / `random` generator states the feeder draws from
             first_step = int(os.path.basename(path.rstrip("/")).split("-")[1])
@@ -362,6 +364,8 @@ def main(args):
         # lambda(k) for k = 0 .. max_train_steps lives on the device and is indexed by the count of SUCCESSFUL optimizer steps, like
         # accelerate's AcceleratedScheduler, which does not advance on an overflow-skipped step
         step.set_lr_table([lam(k) for k in range(args.max_train_steps + 1)])
+    else:
+        step.set_lr_multiplier(1.0)  # a resumed checkpoint's `state` may carry another schedule's multiplier: the lambdas are this run's (:911-916)
     step.capture(warmup=0)
     if feeder is not None:  # batch k+1 is produced on a side stream while step k runs (augment.PrefetchFeeder)
         from textboost_amd.augment import PrefetchFeeder
