@@ -3,6 +3,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from parity import parity
+
 pytestmark = pytest.mark.gpu
 
 
@@ -129,7 +131,8 @@ def test_attention_fwd_bwd(B, H, Sq, Skv, hd, causal):
     ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd, causal=causal)
     qr, kr, vr = [t.float().reshape(B, -1, C).requires_grad_(True) for t in (q, k, v)]
     oref, lref = ref_attention(qr, kr, vr, H, causal)
-    assert rel_err(o.view(B, Sq, C), oref) < 2e-3
+    # rel-L2 AND max-abs (relative to the largest reference magnitude) AND the worst head-dim channel (tests/parity.py)
+    parity(f"attention O {B}x{H}x{Sq}x{Skv}x{hd}", o.view(B, Sq, C), oref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-3)
     assert (lse - lref).abs().max().item() < 2e-3
     do = torch.randn(B * Sq, C, device="cuda").half()
     delta = torch.empty(B, H, Sq, device="cuda")
@@ -139,9 +142,43 @@ def test_attention_fwd_bwd(B, H, Sq, Skv, hd, causal):
     ws = torch.empty(8 * 2 * B * Skv * C, device="cuda") if Skv <= 128 else None   # exercises the split-q path
     ops.attention_bwd(q, k, v, o, lse, do, delta, dq, dk, dv, B, H, Sq, Skv, hd, causal=causal, ws=ws)
     oref.backward(do.float().view(B, Sq, C))
-    assert rel_err(dq.view(B, Sq, C), qr.grad) < 4e-3
-    assert rel_err(dk.reshape(B, Skv, C), kr.grad) < 4e-3
-    assert rel_err(dv.reshape(B, Skv, C), vr.grad) < 4e-3
+    parity("attention dQ", dq.view(B, Sq, C), qr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+    parity("attention dK", dk.reshape(B, Skv, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+    parity("attention dV", dv.reshape(B, Skv, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 256, 128), (1, 2, 256, 192), (2, 3, 512, 320), (1, 8, 1024, 1024), (2, 8, 4096, 4096)])
+def test_attention_fwd_software_pipelined_kernel(B, H, Sq, Skv):
+    """attn_fwd_il_kernel (hd = 40, Sq % 256 == 0, Skv % 64 == 0, >= 2 KV tiles: the SD1.x 64x64-map self-attention shape and its smaller
+    relatives): two query groups per wave run half an iteration apart, so the pipeline's prologue (2 tiles), the 4-slot ring wrapping,
+    and the epilogue are all exercised; keys are spiked in BOTH half-wave key sets of a late tile (the running-max exchange between the
+    half-waves) to force the re-base branch (cdna guide rule 26).  Against fp32 attention: rel-L2 / max-abs / worst channel / LSE."""
+    from textboost_amd import _lib as L
+    ops = _ops()
+    torch.manual_seed(5)
+    hd = 40
+    C = H * hd
+    q = torch.randn(B * Sq, C, device="cuda").half()
+    kv = torch.randn(B * Skv, 2 * C, device="cuda").half()
+    k, v = kv[:, :C], kv[:, C:]
+    kt = Skv - 64 if Skv > 128 else 64          # a late tile
+    for h in range(H):
+        k.view(B, Skv, C)[0, kt + 3, h * hd:(h + 1) * hd] = q.view(B, Sq, C)[0, 7 + h, h * hd:(h + 1) * hd] * 3    # key 3 of the tile: low half-wave
+        k.view(B, Skv, C)[0, kt + 22, h * hd:(h + 1) * hd] = q.view(B, Sq, C)[0, 40 + h, h * hd:(h + 1) * hd] * 3  # key 22: high half-wave
+    oref, lref = ref_attention(q.float().reshape(B, Sq, C), k.float().reshape(B, Skv, C), v.float().reshape(B, Skv, C), H, False)
+    res = []
+    for variant in (1, 1 | 1024):   # the pipelined kernel, then the LDS-DMA kernel it replaces for this shape
+        L.lib().tb_attention_set_variant(variant)
+        o = torch.empty(B * Sq, C, device="cuda", dtype=torch.float16)
+        lse = torch.empty(B, H, Sq, device="cuda")
+        ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd)
+        res.append((o, lse))
+    L.lib().tb_attention_set_variant(1)
+    for o, lse in res:
+        assert torch.isfinite(o).all()
+        parity(f"pipelined attention O {B}x{H}x{Sq}x{Skv}", o.view(B, Sq, C), oref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-3)
+        assert ((lse - lref).abs() / lref.abs().clamp_min(1.0)).max().item() < 2e-3
+    assert rel_err(res[0][0], res[1][0]) < 1e-3
 
 
 def test_attention_online_softmax_rescale_branch():

@@ -24,6 +24,7 @@
 #define TB_ATTN_FUSED_DELTA 1  // A/B on MI355X: delta = rowsum(dO*O) inside the dQ kernel, +1.0 % steps/s vs its own launch
 #include "common.h"
 #include "../../include/textboost_hip.h"
+#include "attn_il.h"
 
 namespace {
 
@@ -1536,6 +1537,7 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
       TB_CHECK_LAUNCH();
       return TB_OK;
     }
+    if (DT == 2 && KS == 3 && d.hd == 40 && !(g_attn_dma & 1024) && tb_attn_il_fwd_ok(d)) return tb_attn_il_fwd(d, s, rm);  // software-pipelined kernel
     if (DT == 2 && KS == 3 && d.hd == 40) {
       constexpr int PC = 6, NST = 4;
       const size_t lds = NST * (2 * KVT * PC * 16 + 64);

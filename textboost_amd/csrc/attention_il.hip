@@ -1,0 +1,441 @@
+// Software-pipelined ("interleaved") flash-attention kernels for the SD1.x 64x64-map self-attention shape (hd = 40, S = 4096, non-causal):
+// the shape that dominates the TextBoost step's attention time (train_textboost.py:1063-1067 -> diffusers Attention + AttnProcessor2_0 ->
+// F.scaled_dot_product_attention, and its autograd at :1108).
+//
+// Same arithmetic as attn_fwd_dma_kernel / attn_bwd_*_dma_kernel of attention.hip (swapped S^T = K Q^T so softmax statistics are lane-local,
+// -m folded into the head-dim padding column, the row sum as an all-ones column of V, lazy re-base, LDS-DMA staged row-major tiles, transposing
+// LDS reads) -- what changes is the INSTRUCTION STREAM.  Measured on MI355X (scratch/coissue2.*): a wave that issues an MFMA plus up to ~5
+// other instructions per 32-cycle matrix slot hides them completely, and two such waves on one SIMD keep the matrix pipe 82-90 % busy
+// (6 / 4 fillers per MFMA); the phase-structured kernels (all MFMAs, then all softmax VALU, behind one another inside a wave) sit at 42-47 %.
+// So every wave owns TWO 32-query groups and runs them half an iteration apart: while the matrix pipe works on group A (P.V of tile t-1, then
+// Q.K^T of tile t: 14 MFMAs) the vector ALU does group B's softmax of tile t-1 (max, exp2, fp16 pack: ~70 instructions, ~5 per MFMA), and
+// vice versa.  __builtin_amdgcn_sched_barrier(0) after every [MFMA + its slice of the other group's softmax + the LDS reads two MFMAs ahead]
+// pins the interleave; consecutive MFMAs alternate accumulators so no dependent pair is back to back.
+#include "common.h"
+#include "../../include/textboost_hip.h"
+#include "attn_il.h"
+
+namespace {
+
+constexpr int KVT = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+#ifndef TB_IL_REBASE
+#define TB_IL_REBASE 8.f
+#endif
+__device__ __attribute__((aligned(16))) const f16 g_zero8_il[8] = {};
+typedef const __attribute__((address_space(1))) f16x8* gvec8_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h16x4;
+typedef __attribute__((address_space(3))) h16x4* lds_h4p;
+typedef __attribute__((address_space(3))) const f16x8* lds_f8p;
+typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ f16x8 join8(h16x4 a, h16x4 b) {
+  u64x2 t;
+  t[0] = __builtin_bit_cast(unsigned long long, a);
+  t[1] = __builtin_bit_cast(unsigned long long, b);
+  return __builtin_bit_cast(f16x8, t);
+}
+// Transposing LDS read as inline asm: the builtin (__builtin_amdgcn_ds_read_tr16_b64_v4f16) makes hipcc drain vmcnt(0) -- the LDS-DMA prefetch --
+// in front of it (it cannot prove the read does not alias the DMA's LDS destination); asm reads are invisible to that pass.  They are also
+// invisible to its lgkmcnt bookkeeping: frag_wait<N>() below waits by hand, counting ONLY the asm reads issued after the wanted one (LDS
+// operations return in order, so compiler-issued reads in between can only make the wait stricter, never too weak).
+template <int OFF>
+__device__ __forceinline__ h16x4 tr_read(uint32_t addr) {
+  h16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void frag_wait(f16x8& a) {  // a's reads have landed once at most N later asm reads are outstanding
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+__device__ __forceinline__ f16x8 rm_read(uint32_t addr) { return *(lds_f8p)(uintptr_t)addr; }
+__device__ __forceinline__ float other_half_max(float v) {  // max over the two half-waves (lanes l and l ^ 32), VALU only
+  // v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b; with a = b = v every lane then holds its own value in one register and its
+  // partner's in the other.  Inline asm: hipcc (ROCm 7.2) folds fmaxf(r[0], r[1]) of __builtin_amdgcn_permlane32_swap(v, v) to r[0] alone --
+  // the maximum then only covers half of a query's keys and the re-base test misses the other half (found by the spiked-key test).
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {  // n wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+  }
+}
+
+struct Blk {
+  int x, h, b;
+};
+__device__ __forceinline__ Blk block_of(int remap) {  // XCD-aware order: all x blocks of one (batch, head) on one L2 (attention.hip attn_block)
+  Blk r;
+  const int gx = gridDim.x, H = gridDim.y, B = gridDim.z;
+  if (remap && ((H * B) & 7) == 0) {
+    const int lin = blockIdx.x + gx * (blockIdx.y + H * blockIdx.z);
+    const int xcd = lin & 7, k = lin >> 3;
+    const int pair = (k / gx) * 8 + xcd;
+    r.x = k - (k / gx) * gx;
+    r.h = pair % H;
+    r.b = pair / H;
+  } else {
+    r.x = blockIdx.x, r.h = blockIdx.y, r.b = blockIdx.z;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// hd = 40: KS = 3 k-steps of 16 over the padded 48-wide rows, DT = 2 head-dim blocks of 32, rows of PC = 6 16-byte chunks in LDS (5 data
+// chunks + the constant pad chunk [1, 0, .., 0]: the all-ones column that carries -m into Q.K^T and the row sum out of P.V).
+constexpr int F_KS = 3, F_DT = 2, F_PC = 6, F_PCB = F_PC * 16, F_TILE_B = KVT * F_PCB, F_STAGE_B = 2 * F_TILE_B + 64, F_NST = 4;
+
+struct FwdGroup {        // one 32-query group of a wave
+  f32x16 o[F_DT];        // O^T accumulators (row hd = the row sum)
+  f32x16 s[2];           // raw scores of the current tile (two 32-key halves), exp2 argument
+  f16x8 pk[2][2];        // P^T of the previous tile as B-operand fragments [32-key half][16-key quarter]
+  f16x8 qf[F_KS];        // lane-owned Q row, pre-scaled by scale * log2(e); slot hd carries -m
+  float m;               // running reference maximum (log2 domain, fp16-representable)
+};
+
+// The softmax of one group's score tile, cut into 14 slices that ride behind the 14 MFMAs of the other group's phase.
+//   slices 0..2 : the running-excess maximum (14 max3 + tail)
+//   slice  3    : cross-half max, the (rare, wave-uniform) re-base branch
+//   slices 3..13: 16 units of [2 exp2 + 1 fp16 pack]
+struct SmTmp {
+  float mx0, mx1;
+};
+template <int I>
+__device__ __forceinline__ void sm_unit(FwdGroup& g) {  // unit I of 16: registers 2 * (I & 7), +1 of half I >> 3
+  constexpr int kt = I >> 3, r = 2 * (I & 7);
+  const float p0 = fast_exp2(g.s[kt][r]), p1 = fast_exp2(g.s[kt][r + 1]);
+  g.pk[kt][r >> 3][r & 7] = (f16)p0;
+  g.pk[kt][r >> 3][(r & 7) + 1] = (f16)p1;
+}
+template <int SLOT>
+__device__ __forceinline__ void sm_slice(FwdGroup& g, SmTmp& t, bool first, bool fold_lane) {
+  if constexpr (SLOT == 0) {
+    t.mx0 = max3f(g.s[0][0], g.s[0][1], g.s[0][2]);
+    t.mx1 = max3f(g.s[1][0], g.s[1][1], g.s[1][2]);
+    t.mx0 = max3f(t.mx0, g.s[0][3], g.s[0][4]);
+    t.mx1 = max3f(t.mx1, g.s[1][3], g.s[1][4]);
+    t.mx0 = max3f(t.mx0, g.s[0][5], g.s[0][6]);
+    t.mx1 = max3f(t.mx1, g.s[1][5], g.s[1][6]);
+  } else if constexpr (SLOT == 1) {
+    t.mx0 = max3f(t.mx0, g.s[0][7], g.s[0][8]);
+    t.mx1 = max3f(t.mx1, g.s[1][7], g.s[1][8]);
+    t.mx0 = max3f(t.mx0, g.s[0][9], g.s[0][10]);
+    t.mx1 = max3f(t.mx1, g.s[1][9], g.s[1][10]);
+    t.mx0 = max3f(t.mx0, g.s[0][11], g.s[0][12]);
+    t.mx1 = max3f(t.mx1, g.s[1][11], g.s[1][12]);
+  } else if constexpr (SLOT == 2) {
+    t.mx0 = max3f(t.mx0, g.s[0][13], g.s[0][14]);
+    t.mx1 = max3f(t.mx1, g.s[1][13], g.s[1][14]);
+    t.mx0 = max3f(t.mx0, t.mx1, fmaxf(g.s[0][15], g.s[1][15]));
+    t.mx0 = other_half_max(t.mx0);
+  } else if constexpr (SLOT == 3) {
+    // Lazy re-base (attention.hip attn_fwd_kernel): m only has to stay within 2^REBASE of the true row maximum; it stays fp16-representable so
+    // that the Q slot subtracts exactly the m that l and the stored LSE use.
+    const float mx = t.mx0;
+    if (first || __any(mx > TB_IL_REBASE)) {
+      float d = first ? mx : fmaxf(mx, 0.f);
+      d = (float)(f16)(g.m + d) - g.m;
+      if (!first) {
+        const float alpha = fast_exp2(-d);
+#pragma unroll
+        for (int dd = 0; dd < F_DT; ++dd)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g.o[dd][r] *= alpha;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g.s[kt][r] -= d;
+      g.m += d;
+      if (fold_lane) g.qf[2][0] = (f16)(-g.m);
+    }
+    sm_unit<0>(g);
+  } else if constexpr (SLOT == 4) {
+    sm_unit<1>(g);
+  } else if constexpr (SLOT == 5) {
+    sm_unit<2>(g);
+    sm_unit<3>(g);
+  } else if constexpr (SLOT == 6) {
+    sm_unit<4>(g);
+  } else if constexpr (SLOT == 7) {
+    sm_unit<5>(g);
+    sm_unit<6>(g);
+  } else if constexpr (SLOT == 8) {
+    sm_unit<7>(g);
+  } else if constexpr (SLOT == 9) {
+    sm_unit<8>(g);
+    sm_unit<9>(g);
+  } else if constexpr (SLOT == 10) {
+    sm_unit<10>(g);
+  } else if constexpr (SLOT == 11) {
+    sm_unit<11>(g);
+    sm_unit<12>(g);
+  } else if constexpr (SLOT == 12) {
+    sm_unit<13>(g);
+  } else {
+    sm_unit<14>(g);
+    sm_unit<15>(g);
+  }
+}
+
+// operand fetch of MFMA n of a phase (n = 0..7: P.V, A = V^T fragment by two transposing reads; n = 8..13: Q.K^T, A = K rows)
+//   P.V   n -> (kt, jj, d) = (n >> 2, (n >> 1) & 1, n & 1)           (d alternates: consecutive MFMAs hit different accumulators)
+//   Q.K^T n -> (j, kt)     = ((n - 8) >> 1, (n - 8) & 1)
+template <int N>
+__device__ __forceinline__ f16x8 fetch_a(uint32_t vaddr, uint32_t kaddr) {
+  if constexpr (N < 8) {
+    constexpr int kt = N >> 2, jj = (N >> 1) & 1, d = N & 1;
+    constexpr int off = (kt * 32 + 16 * jj) * F_PCB + d * 64;
+    return join8(tr_read<off>(vaddr), tr_read<off + 8 * F_PCB>(vaddr));
+  } else {
+    constexpr int j = (N - 8) >> 1, kt = (N - 8) & 1;
+    return rm_read(kaddr + kt * 32 * F_PCB + j * 32);
+  }
+}
+template <int N>
+__device__ __forceinline__ void do_mfma(FwdGroup& g, const f16x8& a) {
+  if constexpr (N < 8) {
+    constexpr int kt = N >> 2, jj = (N >> 1) & 1, d = N & 1;
+    g.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g.pk[kt][jj], g.o[d], 0, 0, 0);
+  } else {
+    constexpr int j = (N - 8) >> 1, kt = (N - 8) & 1;
+    if constexpr (j == 0) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      g.s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g.qf[0], z, 0, 0, 0);
+    } else {
+      g.s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g.qf[j], g.s[kt], 0, 0, 0);
+    }
+  }
+}
+
+// One phase: group G's matrix work (PV of the previous tile from the V tile at `vaddr`, QK of the current one from the K tile at `kaddr`)
+// with group O's softmax interleaved.  LO..HI = the MFMA range that exists (prologue: 8..13, steady state: 0..13, epilogue: 0..7).
+// KEEP: the first phase of an iteration reads the 14 operand fragments from LDS (two MFMAs ahead of their use) and keeps them; the second
+// phase multiplies the SAME K / V^T fragments with the other group's operands, so it issues no LDS reads at all (half the LDS traffic and
+// 22 fewer instructions per phase).
+struct Frags {
+  f16x8 f[14];
+};
+template <int N, int LO, int HI, bool SM, bool KEEP>
+__device__ __forceinline__ void phase_step(FwdGroup& G, FwdGroup& O, SmTmp& t, Frags& F, uint32_t vaddr, uint32_t kaddr, bool first,
+                                           bool fold_lane) {
+  if constexpr (N <= HI) {
+    if constexpr (KEEP) {
+      if constexpr (N + 2 <= HI) F.f[N + 2] = fetch_a<N + 2>(vaddr, kaddr);  // operands two MFMAs ahead
+      if constexpr (N < 8) {  // a transposing-read fragment: asm reads issued after it = those of fragments N+1, N+2 (two each while they are P.V ones)
+        constexpr int later = ((N + 1 <= HI && N + 1 < 8) ? 2 : 0) + ((N + 2 <= HI && N + 2 < 8) ? 2 : 0);
+        frag_wait<later>(F.f[N]);
+      }
+    }
+    do_mfma<N>(G, F.f[N]);
+    if constexpr (SM) sm_slice<N>(O, t, first, fold_lane);
+    SB();
+    phase_step<N + 1, LO, HI, SM, KEEP>(G, O, t, F, vaddr, kaddr, first, fold_lane);
+  }
+}
+template <int LO, int HI, bool SM, bool KEEP>
+__device__ __forceinline__ void phase(FwdGroup& G, FwdGroup& O, Frags& F, uint32_t vaddr, uint32_t kaddr, bool first, bool fold_lane) {
+  SmTmp t;
+  if constexpr (KEEP) {
+    F.f[LO] = fetch_a<LO>(vaddr, kaddr);
+    F.f[LO + 1] = fetch_a<LO + 1>(vaddr, kaddr);
+    SB();
+  }
+  if constexpr (SM && LO > 0) {  // prologue / short phases: the slices that have no MFMA to ride behind run first
+    sm_slice<0>(O, t, first, fold_lane);
+    sm_slice<1>(O, t, first, fold_lane);
+    sm_slice<2>(O, t, first, fold_lane);
+    sm_slice<3>(O, t, first, fold_lane);
+    sm_slice<4>(O, t, first, fold_lane);
+    sm_slice<5>(O, t, first, fold_lane);
+    sm_slice<6>(O, t, first, fold_lane);
+    sm_slice<7>(O, t, first, fold_lane);
+    SB();
+  }
+  phase_step<LO, LO, HI, SM, KEEP>(G, O, t, F, vaddr, kaddr, first, fold_lane);
+  if constexpr (SM && HI < 13) {
+    sm_slice<8>(O, t, first, fold_lane);
+    sm_slice<9>(O, t, first, fold_lane);
+    sm_slice<10>(O, t, first, fold_lane);
+    sm_slice<11>(O, t, first, fold_lane);
+    sm_slice<12>(O, t, first, fold_lane);
+    sm_slice<13>(O, t, first, fold_lane);
+    SB();
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_il_kernel(const tb_attn_desc p, int remap) {
+  constexpr int NI = 2 * F_PC, WI = NI / 4;  // 12 one-KB load instructions per stage, 3 per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Blk blk = block_of(remap & 1);
+  const int b = blk.b, h = blk.h, hd = p.hd, Skv = p.Skv;
+  const int qblk = blk.x * 256;
+  const int64_t ldk = p.ldk, ldv = p.ldv;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * hd;
+  const char* Kg = (const char*)((const f16*)p.K + (int64_t)b * Skv * ldk + h * hd);
+  const char* Vg = (const char*)((const f16*)p.V + (int64_t)b * Skv * ldv + h * hd);
+  FwdGroup A, Bg;
+  Frags F;
+  const float c = p.scale * LOG2E;
+  auto load_q = [&](FwdGroup& g, int q) {
+#pragma unroll
+    for (int j = 0; j < F_KS; ++j) {
+      const int col = 16 * j + 8 * hi;
+      g.qf[j] = *(col < hd ? (gvec8_t)(Qg + (int64_t)q * p.ldq + col) : (gvec8_t)g_zero8_il);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g.qf[j][e] = (f16)((float)g.qf[j][e] * c);
+    }
+#pragma unroll
+    for (int d = 0; d < F_DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g.o[d][r] = 0.f;
+    g.m = 0.f;
+  };
+  load_q(A, qblk + wave * 64 + l31);
+  load_q(Bg, qblk + wave * 64 + 32 + l31);
+  // ---- this lane's part of a stage's loads: instruction t = wave + 4 i covers flat chunks t' * 64 + lane of tensor t / PC
+  uint32_t g_off[WI];
+  bool g_on[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave + 4 * i;
+    const int tensor = t >= F_PC ? 1 : 0;
+    const int f = (t - tensor * F_PC) * 64 + lane;
+    const int row = f / F_PC, cc = f - row * F_PC;
+    g_on[i] = cc < F_PC - 1;  // the pad chunk keeps its constant
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + cc * 16);
+  }
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * F_STAGE_B;
+    const char* kb = Kg + (int64_t)tile * KVT * ldk * 2;
+    const char* vb = Vg + (int64_t)tile * KVT * ldv * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave + 4 * i;
+      const char* src = (t >= F_PC ? vb : kb) + g_off[i];
+      if (g_on[i]) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + t * 1024), 16, 0, 0);
+    }
+  };
+  for (int u = threadIdx.x; u < 2 * KVT * F_NST; u += 256) {  // pad chunks [1, 0, .., 0] of every row of every stage (K and V)
+    const int st = u / (2 * KVT), r = u - st * 2 * KVT;
+    const f16x8 one = {(f16)1.f, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + st * F_STAGE_B + (r >= KVT ? F_TILE_B : 0) + (r & (KVT - 1)) * F_PCB + (F_PC - 1) * 16) = one;
+  }
+  const int ntiles = Skv / KVT;  // >= 2 (launcher)
+  stage_loads(0, 0);
+  stage_loads(1, 1);
+  const bool fold_lane = hi == ((hd >> 3) & 1);  // column hd of the lane's Q row = element 0 of chunk hd / 16 in these lanes
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem_raw;
+  const uint32_t k_lane = lds0 + l31 * F_PCB + hi * 16;
+  const int g4 = lane >> 4, j16 = lane & 15;
+  const uint32_t v_lane = lds0 + F_TILE_B + (4 * (g4 >> 1) + (j16 >> 2)) * F_PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
+  // tile t lives in slot t % 4; iteration t multiplies K(t) and V(t-1) and has the loads of tiles t+1 (in flight) and t+2 (issued now)
+#ifdef TB_IL_PROF
+  unsigned long long pf_[5] = {0, 0, 0, 0, 0}, pt_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long pf_t0 = pt_, pf_r0 = wall_clock64();
+#define TB_PF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
+#else
+#define TB_PF(k)
+#endif
+  auto sync_and_prefetch = [&](int t) {
+    TB_PF(4)
+    wait_vmcnt(t + 1 < ntiles ? WI : 0);  // tile t landed (this wave's part); tile t+1 may stay in flight
+    TB_PF(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TB_PF(1)
+    if (t + 2 < ntiles) stage_loads(t + 2, (t + 2) & 3);  // into the slot of tile t-2: every wave is past its last read of it
+    TB_PF(2)
+  };
+  // ---- prologue: QK_A(0); QK_B(0) || SM_A(0); then tile 1 with SM_B(0) as a first tile
+  sync_and_prefetch(0);
+  {
+    const uint32_t ka = k_lane;
+    phase<8, 13, false, true>(A, Bg, F, 0, ka, false, fold_lane);
+    phase<8, 13, true, false>(Bg, A, F, 0, ka, true, fold_lane);
+  }
+  for (int t = 1; t < ntiles; ++t) {
+    sync_and_prefetch(t);
+    const uint32_t ka = k_lane + (t & 3) * F_STAGE_B;
+    const uint32_t va = v_lane + ((t - 1) & 3) * F_STAGE_B;
+    phase<0, 13, true, true>(A, Bg, F, va, ka, t == 1, fold_lane);  // PV_A(t-1), QK_A(t) || SM_B(t-1)
+    TB_PF(3)
+    phase<0, 13, true, false>(Bg, A, F, va, ka, false, fold_lane);  // PV_B(t-1), QK_B(t) || SM_A(t): the same fragments
+  }
+#ifdef TB_IL_PROF
+  if (p.Delta && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)
+    for (int k = 0; k < 5; ++k) p.Delta[wave * 5 + k] = (float)pf_[k] / (float)ntiles;
+  if (p.Delta && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    p.Delta[20] = (float)(__builtin_amdgcn_s_memtime() - pf_t0);  // shader-clock ticks of the whole block
+    p.Delta[21] = (float)(wall_clock64() - pf_r0);                 // 100 MHz constant clock over the same span
+  }
+  if (p.Delta && threadIdx.x == 0) {  // per block: start / end on the constant clock, shader ticks, hardware id
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    double* o = (double*)(p.Delta + 64) + lin * 4;
+    o[0] = (double)pf_r0; o[1] = (double)wall_clock64(); o[2] = (double)(__builtin_amdgcn_s_memtime() - pf_t0); o[3] = (double)(hwid | ((unsigned long long)(xcc & 15) << 32));
+  }
+#endif
+  {  // ---- epilogue: the last tile's P.V (its V tile landed with the last barrier; no other wave writes LDS any more)
+    const uint32_t va = v_lane + ((ntiles - 1) & 3) * F_STAGE_B;
+    phase<0, 7, true, true>(A, Bg, F, va, 0, ntiles == 1, fold_lane);  // PV_A(n-1) || SM_B(n-1)
+    phase<0, 7, false, false>(Bg, A, F, va, 0, false, fold_lane);      // PV_B(n-1)
+  }
+  auto store = [&](FwdGroup& g, int q) {
+    // the all-ones column hd of V made O^T row hd the row sum: register 4 k of the hi == 0 lane of block hd / 32
+    float ls = 0.f;
+#pragma unroll
+    for (int d = 0; d < F_DT; ++d)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        if (d * 32 + k4 * 8 == hd) ls = g.o[d][4 * k4];
+    const float lsum = __shfl(ls, l31, 64);
+    const float inv = 1.f / lsum;
+    f16* Og = (f16*)p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * hd;
+#pragma unroll
+    for (int d = 0; d < F_DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < hd) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(g.o[d][4 * r4 + e] * inv);
+          *(f16x4*)(Og + col) = v;
+        }
+      }
+    if (p.LSE && hi == 0) p.LSE[((int64_t)b * p.H + h) * p.Sq + q] = g.m * (1.f / LOG2E) + logf(lsum);
+  };
+  store(A, qblk + wave * 64 + l31);
+  store(Bg, qblk + wave * 64 + 32 + l31);
+}
+
+}  // namespace
+
+bool tb_attn_il_fwd_ok(const tb_attn_desc& d) {
+  return !d.causal && d.hd == 40 && d.Sq % 256 == 0 && d.Skv % KVT == 0 && d.Skv >= 2 * KVT && d.ldk % 8 == 0 && d.ldv % 8 == 0 && !d.fp8_ws &&
+         (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31);
+}
+int tb_attn_il_fwd(const tb_attn_desc& d, hipStream_t s, int remap) {
+  const size_t lds = F_NST * F_STAGE_B;
+  hipLaunchKernelGGL(attn_fwd_il_kernel, dim3(d.Sq / 256, d.H, d.B), dim3(256), lds, s, d, remap);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}

@@ -1,0 +1,7 @@
+// Internal interface between attention.hip (dispatch) and attention_il.hip (software-pipelined kernels of the hd = 40 self-attention shape).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/textboost_hip.h"
+
+bool tb_attn_il_fwd_ok(const tb_attn_desc& d);
+int tb_attn_il_fwd(const tb_attn_desc& d, hipStream_t s, int remap);
