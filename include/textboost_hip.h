@@ -253,6 +253,38 @@ int tb_weight_decay(float* p, int64_t n, float factor, const float* state, tb_st
 int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, float* norms, tb_stream_t stream);
 int tb_row_norms(const float* w, int64_t rows, int D, float* norms, tb_stream_t stream);
 
+/* ---- fp32 (no-AMP) numeric mode ------------------------------------------------------------------------------------------------------
+ * The reference runs in full fp32 unless --mixed_precision fp16 is given (train_textboost.py:298-308 default None; :930-939 weight_dtype
+ * float32, no GradScaler): the README command (README.md:58-76).  Same layouts and semantics as the fp16 entry points above, every tensor fp32;
+ * contractions on the exact-fp32 matrix instruction (csrc/f32_path.hip).  LayerNorm, embedding, pins, KPL, convert and the optimizer entry
+ * points above already take fp32 tensors.
+ * tb_gemm_f32: the tb_gemm descriptor with fp32 A / A2 / W / W2 / R / C / C2 (c_dtype and r_dtype must be TB_F32; K, N, M unrestricted;
+ * conv: Cin % 4 == 0); ws is ignored.  tb_gemm_f32_t: linear only, A given as [K][M] (a_trans) and / or W given as [K][N] (w_trans) -- the
+ * weight-gradient-shaped products of the LoRA adapters (dB = dY^T t, dA = dt^T x; train_textboost.py:700-722) */
+int tb_gemm_f32(const tb_gemm_desc* d, tb_stream_t stream);
+int tb_gemm_f32_t(const tb_gemm_desc* d, int a_trans, int w_trans, tb_stream_t stream);
+/* attention with fp32 Q / K / V / O / dO / dQ / dK / dV (same descriptor; fp8_ws and ws of the descriptor are ignored).  The score matrix is
+ * materialised: ws = tb_attention_f32_ws_floats(B, H, Sq, Skv) floats (forward uses the first half) */
+int64_t tb_attention_f32_ws_floats(int B, int H, int Sq, int Skv);
+int tb_attention_f32_fwd(const tb_attn_desc* d, float* ws, int64_t ws_floats, tb_stream_t stream);
+int tb_attention_f32_bwd(const tb_attn_desc* d, float* ws, int64_t ws_floats, tb_stream_t stream);
+int tb_groupnorm_f32_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* stats, int B, int HW,
+                         int C, int G, float eps, int silu, tb_stream_t stream);
+int tb_groupnorm_f32_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* beta, const float* stats,
+                         const float* add, int64_t ldadd, float* dx, int64_t lddx, int B, int HW, int C, int G, int silu, tb_stream_t stream);
+int tb_add_noise_f32(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod, float* noisy, float* velocity,
+                     int B, int64_t per_sample, tb_stream_t stream);
+int tb_timestep_embed_f32(const int64_t* timesteps, float* out, int B, int dim, tb_stream_t stream);
+int tb_conv4_to_nhwc_f32(const float* in, int Cin, const float* w_packed, const float* bias, float* out, int64_t ldo, int B, int H, int W,
+                         int Cout, int sign, float in_scale, tb_stream_t stream);
+int tb_conv_to4_f32(const float* in, int64_t ldi, const float* w_packed, const float* bias, float* out, int B, int H, int W, int C,
+                    tb_stream_t stream);
+int tb_upsample2x_f32(const float* x, int64_t ldx, float* u, int64_t ldu, int B, int H, int W, int C, tb_stream_t stream);
+int tb_pool2x2_sum_f32(const float* du, int64_t ldu, float* dx, int64_t ldx, int B, int H, int W, int C, tb_stream_t stream);
+int tb_add_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t M, int C, tb_stream_t stream);
+int tb_mse_loss_f32(const float* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
+                    float* ws /* >= 256 floats */, tb_stream_t stream);
+
 /* ---- image augmentation + feeder --------------------------------------------------------------------------------
  * Replaces the Pillow / torchvision calls of textboost/augment/paired_augmentation.py:20-277 and textboost/dataset.py:324-381 (Resize(LANCZOS),
  * crop, ToImage / ToDtype / Normalize).  Device images are RGBX u8, one uint32 per pixel, [H][stride] pixels.  Bit-exact with Pillow.

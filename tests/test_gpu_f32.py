@@ -1,0 +1,267 @@
+"""fp32 (no-AMP) numeric mode, kernel level: every fp32 entry point of csrc/f32_path.hip against float64 torch on the CPU.
+
+The reference trains in fp32 unless --mixed_precision fp16 is passed (train_textboost.py:298-308, :930-939; README.md:58-76).  Contractions
+run on the exact-fp32 matrix instruction, so the only difference from an fp32 CPU run is summation order: tolerance 2e-6 rel-L2 /
+1e-5 max-abs (relative to the largest reference magnitude) for the GEMM family, 1e-5 / 5e-5 where exp / rsqrt are involved."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from parity import parity
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def _ops():
+    from textboost_amd import ops
+    return ops
+
+
+def _L():
+    from textboost_amd import _lib as L
+    return L
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 70, 52), (1, 5, 4), (300, 129, 200), (77, 768, 768)])
+def test_gemm_f32_linear_epilogues(M, N, K):
+    ops, L = _ops(), _L()
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(M, K + 8, generator=g)[:, 3:3 + K].to(dev)        # unaligned column slice: the scalar load path
+    W = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    R = torch.randn(M, N, generator=g).to(dev)
+    ref = A.double().cpu() @ W.double().cpu().t()
+    out = torch.empty(M, N, device=dev)
+    ops.gemm(A, W, out)
+    parity("gemm_f32", out, ref, rel=2e-6, maxabs=1e-5)
+    ops.gemm(A, W, out, bias=bias, R=R, alpha=0.5)
+    parity("gemm_f32 + bias + R", out, 0.5 * ref + bias.double().cpu() + R.double().cpu(), rel=2e-6, maxabs=1e-5)
+    pre = torch.empty(M, N, device=dev)
+    for act, fn in ((L.ACT_QUICK_GELU, lambda x: x * torch.sigmoid(1.702 * x)), (L.ACT_GELU, lambda x: F.gelu(x)), (L.ACT_SILU, F.silu)):
+        ops.gemm(A, W, out, bias=bias, act=act, C2=pre if act != L.ACT_SILU else None)
+        z = ref + bias.double().cpu()
+        parity(f"gemm_f32 act {act}", out, fn(z), rel=1e-5, maxabs=5e-5)
+        if act != L.ACT_SILU:
+            parity("  saved pre-activation", pre, z, rel=2e-6, maxabs=1e-5)
+    # activation-gradient epilogues: v * act'(C2)
+    z = torch.randn(M, N, generator=g).to(dev)
+    zc = z.double().cpu().requires_grad_(True)
+    (zc * torch.sigmoid(1.702 * zc)).sum().backward()
+    ops.gemm(A, W, out, act=L.ACT_QUICK_GELU_GRAD, C2=z)
+    parity("gemm_f32 quick-gelu grad", out, ref * zc.grad, rel=1e-5, maxabs=5e-5)
+    zc.grad = None
+    F.gelu(zc).sum().backward()
+    ops.gemm(A, W, out, act=L.ACT_GELU_GRAD, C2=z)
+    parity("gemm_f32 gelu grad", out, ref * zc.grad, rel=1e-5, maxabs=5e-5)
+
+
+def test_gemm_f32_k_extension_rowbias_and_transposed_views():
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    M, N, K1, K2 = 154, 96, 64, 16
+    A, A2 = torch.randn(M, K1, generator=g).to(dev), torch.randn(M, K2, generator=g).to(dev)
+    W, W2 = torch.randn(N, K1, generator=g).to(dev), torch.randn(N, K2, generator=g).to(dev)
+    rb = torch.randn(2, N, generator=g).to(dev)
+    out = torch.empty(M, N, device=dev)
+    ops.gemm(A, W, out, A2=A2, W2=W2, rowbias=rb, rows_per_group=77)
+    ref = A.double().cpu() @ W.double().cpu().t() + A2.double().cpu() @ W2.double().cpu().t() + rb.double().cpu().repeat_interleave(77, 0)
+    parity("gemm_f32 K-extension + rowbias", out, ref, rel=2e-6, maxabs=1e-5)
+    # transposed operand views (LoRA weight gradients): out[M,N] = At^T @ Wt, accumulated onto R
+    Mt, Nt, Kt = 48, 12, 231
+    At, Wt = torch.randn(Kt, Mt, generator=g).to(dev), torch.randn(Kt, Nt, generator=g).to(dev)
+    acc = torch.randn(Mt, Nt, generator=g).to(dev)
+    ref = acc.double().cpu() + 0.25 * At.double().cpu().t() @ Wt.double().cpu()
+    ops.gemm_f32_t(At, Wt, acc, Mt, Nt, Kt, a_trans=True, w_trans=True, R=acc, alpha=0.25)
+    parity("gemm_f32_t", acc, ref, rel=2e-6, maxabs=1e-5)
+
+
+def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+@pytest.mark.parametrize("mode", ["s1", "dgrad", "s2", "up", "tr"])
+def test_gemm_f32_conv_gathers(mode):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    B, Ci, Co, H, W = 2, 8, 12, 10, 6
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g)
+    wf = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous().to(dev)      # [Co][tap][Ci]
+    wd = w.permute(1, 2, 3, 0).reshape(Ci, 9 * Co).contiguous().to(dev)      # dgrad operand [Ci][tap][Co]
+    if mode == "s1":
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        out = torch.empty(B * H * W, Co, device=dev)
+        ops.gemm(_nhwc(x).to(dev), wf, out, conv=dict(B=B, Hin=H, Win=W, Cin=Ci, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=0))
+    elif mode == "dgrad":     # input gradient of the stride-1 conv: taps mirrored (sign = -1) on the transposed weights
+        dy = torch.randn(B, Co, H, W, generator=g)
+        xr = x.double().requires_grad_(True)
+        F.conv2d(xr, w.double(), padding=1).backward(dy.double())
+        ref = xr.grad
+        out = torch.empty(B * H * W, Ci, device=dev)
+        ops.gemm(_nhwc(dy).to(dev), wd, out, conv=dict(B=B, Hin=H, Win=W, Cin=Co, Hout=H, Wout=W, stride=1, sign=-1, upsample=0, transposed=0))
+    elif mode == "s2":
+        ref = F.conv2d(x.double(), w.double(), padding=1, stride=2)
+        Ho, Wo = ref.shape[2:]
+        out = torch.empty(B * Ho * Wo, Co, device=dev)
+        ops.gemm(_nhwc(x).to(dev), wf, out, conv=dict(B=B, Hin=H, Win=W, Cin=Ci, Hout=Ho, Wout=Wo, stride=2, sign=1, upsample=0, transposed=0))
+    elif mode == "up":
+        ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), padding=1)
+        out = torch.empty(B * 4 * H * W, Co, device=dev)
+        ops.gemm(_nhwc(x).to(dev), wf, out, conv=dict(B=B, Hin=H, Win=W, Cin=Ci, Hout=2 * H, Wout=2 * W, stride=1, sign=1, upsample=1, transposed=0))
+    else:                     # input gradient of the stride-2 conv (transposed gather)
+        xr = x.double().requires_grad_(True)
+        y = F.conv2d(xr, w.double(), padding=1, stride=2)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy.double())
+        ref = xr.grad
+        out = torch.empty(B * H * W, Ci, device=dev)
+        ops.gemm(_nhwc(dy).to(dev), wd, out, conv=dict(B=B, Hin=dy.shape[2], Win=dy.shape[3], Cin=Co, Hout=H, Wout=W, stride=2, sign=1,
+                                                       upsample=0, transposed=1))
+    parity(f"gemm_f32 conv {mode}", out, _nhwc(ref), rel=2e-6, maxabs=1e-5)
+
+
+def test_gemm_f32_geglu_forward_and_backward_epilogues():
+    from textboost_amd.unet import pack_geglu_rows
+    ops, L = _ops(), _L()
+    g = torch.Generator().manual_seed(3)
+    M, C = 90, 64
+    x = torch.randn(M, C, generator=g)
+    w = torch.randn(8 * C, C, generator=g) * 0.2
+    b = torch.randn(8 * C, generator=g)
+    w2 = torch.randn(C, 4 * C, generator=g) * 0.1
+    xr = x.double().requires_grad_(True)
+    proj = xr @ w.double().t() + b.double()
+    h, gate = proj.chunk(2, dim=-1)
+    gated = h * F.gelu(gate)
+    dy = torch.randn(M, C, generator=g)
+    out_ref = gated @ w2.double().t()
+    out_ref.backward(dy.double())
+    wp, bp = pack_geglu_rows(w).to(dev), pack_geglu_rows(b).to(dev)
+    raw = torch.empty(M, 8 * C, device=dev)
+    got = torch.empty(M, 4 * C, device=dev)
+    ops.gemm(x.to(dev), wp, got, bias=bp, act=L.ACT_GEGLU, C2=raw)
+    parity("gemm_f32 GEGLU", got, gated, rel=1e-5, maxabs=5e-5)
+    # backward: d(gated) = dy @ w2 in the ff.net.2 dgrad GEMM, GEGLU backward in its epilogue -> packed d(proj); then the ff1 dgrad
+    dproj = torch.empty(M, 8 * C, device=dev)
+    ops.gemm(dy.to(dev), w2.t().contiguous().to(dev), dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
+    dx = torch.empty(M, C, device=dev)
+    ops.gemm(dproj, wp.t().contiguous(), dx)
+    parity("gemm_f32 GEGLU backward -> dx", dx, xr.grad, rel=1e-5, maxabs=5e-5)
+
+
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 64, True), (3, 100, 320, False), (1, 16, 1280, True)])
+def test_groupnorm_f32(B, HW, C, silu):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    xb = torch.randn(B * HW, C + 8, generator=g) * 2 + 0.5
+    x = xb[:, 4:4 + C].to(dev)
+    gamma, beta = (torch.randn(C, generator=g) * 0.5 + 1).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    xr = x.double().cpu().view(B, HW, C).permute(0, 2, 1).requires_grad_(True)
+    y = F.group_norm(xr, 32, gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    if silu:
+        y = F.silu(y)
+    dy = torch.randn(B * HW, C, generator=g)
+    add = torch.randn(B * HW, C, generator=g)
+    y.backward(dy.double().view(B, HW, C).permute(0, 2, 1))
+    out, stats = torch.empty(B * HW, C, device=dev), torch.empty(B * 32, 2, device=dev)
+    ops.groupnorm_fwd(x, out, gamma, beta, stats, None, B, HW, C, 32, 1e-5, silu)
+    parity("groupnorm_f32 fwd", out, y.permute(0, 2, 1).reshape(B * HW, C), rel=1e-5, maxabs=5e-5)
+    dx = torch.empty(B * HW, C, device=dev)
+    ops.groupnorm_bwd(dy.to(dev), x, gamma, beta, stats, dx, None, B, HW, C, 32, silu, add=add.to(dev))
+    parity("groupnorm_f32 bwd", dx, xr.grad.permute(0, 2, 1).reshape(B * HW, C) + add.double(), rel=1e-5, maxabs=5e-5)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,hd,causal", [(2, 4, 96, 96, 40, False), (1, 8, 200, 77, 40, False), (2, 3, 77, 77, 64, True),
+                                                  (1, 2, 130, 70, 160, False)])
+def test_attention_f32(B, H, Sq, Skv, hd, causal):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    C = H * hd
+    q = torch.randn(B * Sq, C, generator=g).to(dev)
+    kv = torch.randn(B * Skv, 2 * C, generator=g).to(dev)
+    k, v = kv[:, :C], kv[:, C:]
+    qr, kr, vr = [t.double().cpu().reshape(B, -1, H, hd).transpose(1, 2).requires_grad_(True) for t in (q, k, v)]
+    s = qr @ kr.transpose(-1, -2) * hd ** -0.5
+    if causal:
+        s = s + torch.full((Sq, Skv), float("-inf"), dtype=torch.float64).triu(1)
+    oref = (torch.softmax(s, -1) @ vr).transpose(1, 2).reshape(B * Sq, C)
+    o, lse = torch.empty(B * Sq, C, device=dev), torch.empty(B, H, Sq, device=dev)
+    ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd, causal=causal)
+    parity("attention_f32 O", o, oref, rel=1e-5, maxabs=5e-5)
+    parity("attention_f32 LSE", lse, torch.logsumexp(s, -1), rel=1e-5, maxabs=5e-5)
+    do = torch.randn(B * Sq, C, generator=g)
+    oref.backward(do.double())
+    delta = torch.empty(B, H, Sq, device=dev)
+    dq, dkv = torch.empty(B * Sq, C, device=dev), torch.empty(B * Skv, 2 * C, device=dev)
+    ops.attention_bwd(q, k, v, o, lse, do.to(dev), delta, dq, dkv[:, :C], dkv[:, C:], B, H, Sq, Skv, hd, causal=causal)
+    back = lambda t, S: t.transpose(1, 2).reshape(B * S, C)  # noqa: E731
+    parity("attention_f32 dQ", dq, back(qr.grad, Sq), rel=1e-5, maxabs=5e-5)
+    parity("attention_f32 dK", dkv[:, :C], back(kr.grad, Skv), rel=1e-5, maxabs=5e-5)
+    parity("attention_f32 dV", dkv[:, C:], back(vr.grad, Skv), rel=1e-5, maxabs=5e-5)
+
+
+def test_streaming_kernels_f32():
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    B, H, W, C = 2, 6, 4, 16
+    # add_noise / velocity
+    from textboost_amd.trainer import alphas_cumprod
+    acp = alphas_cumprod(device=dev)
+    x0, noise = torch.randn(B, 4, H, W, generator=g).to(dev), torch.randn(B, 4, H, W, generator=g).to(dev)
+    t = torch.tensor([999, 3], device=dev)
+    noisy, vel = torch.empty_like(x0), torch.empty_like(x0)
+    ops.add_noise(x0, noise, t, acp, noisy, vel)
+    a = acp[t].double().cpu().view(B, 1, 1, 1)
+    parity("add_noise_f32", noisy, a.sqrt() * x0.double().cpu() + (1 - a).sqrt() * noise.double().cpu(), rel=1e-6, maxabs=1e-6)
+    parity("velocity_f32", vel, a.sqrt() * noise.double().cpu() - (1 - a).sqrt() * x0.double().cpu(), rel=1e-6, maxabs=1e-6)
+    # timestep embedding [cos | sin]
+    te = torch.empty(B, 320, device=dev)
+    ops.timestep_embed(t, te)
+    k = torch.arange(160, dtype=torch.float64)
+    arg = t.double().cpu()[:, None] * torch.exp(-9.210340371976184 * k / 160)
+    parity("timestep_embed_f32", te, torch.cat([arg.cos(), arg.sin()], 1), rel=2e-5, maxabs=1e-4)   # fp32 argument t * f up to 999
+    # boundary convs
+    xin = torch.randn(B, 4, H, W, generator=g)
+    w = torch.randn(C, 4, 3, 3, generator=g)
+    bias = torch.randn(C, generator=g)
+    out = torch.empty(B * H * W, C, device=dev)
+    ops.conv4_to_nhwc(xin.to(dev), w.permute(2, 3, 1, 0).reshape(36, C).contiguous().to(dev), bias.to(dev), out, B, H, W, C, sign=1)
+    parity("conv4_to_nhwc_f32", out, _nhwc(F.conv2d(xin.double(), w.double(), bias.double(), padding=1)), rel=2e-6, maxabs=1e-5)
+    wo = torch.randn(4, C, 3, 3, generator=g)
+    bo = torch.randn(4, generator=g)
+    a_nhwc = torch.randn(B * H * W, C, generator=g)
+    pred = torch.empty(B, 4, H, W, device=dev)
+    ops.conv_to4(a_nhwc.to(dev), wo.permute(0, 2, 3, 1).reshape(4, 9, C).contiguous().to(dev), bo.to(dev), pred, B, H, W, C)
+    a_nchw = a_nhwc.view(B, H, W, C).permute(0, 3, 1, 2)
+    parity("conv_to4_f32", pred, F.conv2d(a_nchw.double(), wo.double(), bo.double(), padding=1), rel=2e-6, maxabs=1e-5)
+    # conv_out input gradient through conv4_to_nhwc(sign=-1)
+    dpred = torch.randn(B, 4, H, W, generator=g)
+    ar = a_nchw.double().requires_grad_(True)
+    F.conv2d(ar, wo.double(), padding=1).backward(dpred.double())
+    da = torch.empty(B * H * W, C, device=dev)
+    ops.conv4_to_nhwc(dpred.to(dev), wo.permute(2, 3, 0, 1).reshape(36, C).contiguous().to(dev), None, da, B, H, W, C, sign=-1)
+    parity("conv_out dgrad f32", da, _nhwc(ar.grad), rel=2e-6, maxabs=1e-5)
+    # upsample / its backward / add / mse
+    xs = torch.randn(B * H * W, C, generator=g).to(dev)
+    u = torch.empty(B * 4 * H * W, C, device=dev)
+    ops.upsample2x(xs, u, B, H, W, C)
+    uref = F.interpolate(xs.cpu().view(B, H, W, C).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    assert torch.equal(u.cpu(), _nhwc(uref))
+    du = torch.randn(B * 4 * H * W, C, generator=g).to(dev)
+    dx = torch.empty(B * H * W, C, device=dev)
+    ops.pool2x2_sum(du, dx, B, H, W, C)
+    dref = F.avg_pool2d(du.double().cpu().view(B, 2 * H, 2 * W, C).permute(0, 3, 1, 2), 2) * 4
+    parity("pool2x2_sum_f32", dx, _nhwc(dref), rel=1e-6, maxabs=1e-6)
+    s = torch.empty_like(xs)
+    ops.add_f16(xs, dx, s)
+    assert torch.equal(s, xs + dx)
+    p_, t_ = torch.randn(B, 4, H, W, generator=g).to(dev), torch.randn(B, 4, H, W, generator=g).to(dev)
+    dp, loss, scale = torch.empty_like(p_), torch.zeros(1, device=dev), torch.full((1,), 8.0, device=dev)
+    ops.mse_loss(p_, t_, dp, loss, scale)
+    pr = p_.double().cpu().requires_grad_(True)
+    lr = F.mse_loss(pr, t_.double().cpu())
+    lr.backward()
+    assert abs(loss.item() - lr.item()) < 1e-6 * abs(lr.item()) + 1e-9
+    parity("mse_loss_f32 grad", dp, pr.grad * 8.0, rel=1e-6, maxabs=1e-6)

@@ -115,6 +115,21 @@ _SIGS = {
     "tb_weight_decay": ([_VP, _I64, _F, _VP, _VP], C.c_int),
     "tb_renorm_rows": ([_VP, _I, _I, _F, _VP, _VP], C.c_int),
     "tb_row_norms": ([_VP, _I64, _I, _VP, _VP], C.c_int),
+    "tb_gemm_f32": ([C.POINTER(GemmDesc), _VP], C.c_int),
+    "tb_gemm_f32_t": ([C.POINTER(GemmDesc), _I, _I, _VP], C.c_int),
+    "tb_attention_f32_ws_floats": ([_I, _I, _I, _I], _I64),
+    "tb_attention_f32_fwd": ([C.POINTER(AttnDesc), _VP, _I64, _VP], C.c_int),
+    "tb_attention_f32_bwd": ([C.POINTER(AttnDesc), _VP, _I64, _VP], C.c_int),
+    "tb_groupnorm_f32_fwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
+    "tb_groupnorm_f32_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _I, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_add_noise_f32": ([_VP, _VP, _VP, _VP, _VP, _VP, _I, _I64, _VP], C.c_int),
+    "tb_timestep_embed_f32": ([_VP, _VP, _I, _I, _VP], C.c_int),
+    "tb_conv4_to_nhwc_f32": ([_VP, _I, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_conv_to4_f32": ([_VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_upsample2x_f32": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_pool2x2_sum_f32": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_add_f32": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
+    "tb_mse_loss_f32": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP], C.c_int),
     "tb_resample_ksize": ([_I, _I, _I], C.c_int),
     "tb_resample_coeffs": ([_I, _I, _I, _VP, _VP], C.c_int),
     "tb_affine_nearest_tables": ([C.POINTER(C.c_double), _I, _I, _I, _I, _VP, _VP], C.c_int),
