@@ -265,3 +265,70 @@ def test_streaming_kernels_f32():
     lr.backward()
     assert abs(loss.item() - lr.item()) < 1e-6 * abs(lr.item()) + 1e-9
     parity("mse_loss_f32 grad", dp, pr.grad * 8.0, rel=1e-6, maxabs=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ executors in the fp32 mode
+def _small_unet_f32(B, hw, D, sd2=False, seed=0):
+    from oracle.unet_sd import UNet2DCondition, UNetConfig
+    from textboost_amd.unet import HipUNet, UNetGeometry
+    torch.manual_seed(seed)
+    cfg = UNetConfig.tiny(D)
+    if sd2:
+        cfg.use_linear_projection = True
+        cfg.num_heads = (1, 2, 2, 2)
+    ref = UNet2DCondition(cfg)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+    geo = UNetGeometry(block_out_channels=cfg.block_out_channels, num_heads=cfg.num_heads, cross_attention_dim=D,
+                       cross_attn_levels=cfg.cross_attn_levels, use_linear_projection=cfg.use_linear_projection)
+    hip = HipUNet(geo, ref.state_dict(), B, hw, hw, text_len=77, device=dev, dtype=torch.float32)
+    return ref, hip
+
+
+@pytest.mark.parametrize("sd2", [False, True])
+def test_unet_f32_forward_and_dgrad_backward_vs_oracle(sd2):
+    """the whole UNet executor with dtype = float32 (no-AMP mode, train_textboost.py:930-939) against the fp32 oracle: 1e-4 is the bar the
+    mode is held to (rel-L2, max-abs and worst channel); measured ~1e-6."""
+    B, hw, D = 2, 16, 64
+    ref, hip = _small_unet_f32(B, hw, D, sd2)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 4, hw, hw, generator=g)
+    t = torch.tensor([17, 801])
+    ehs = torch.randn(B, 77, D, generator=g).requires_grad_(True)
+    pred_ref = ref(x, t, ehs)
+    dpred = torch.randn(B, 4, hw, hw, generator=g)
+    pred_ref.backward(dpred)
+    pred = hip.forward(x.to(dev), t.to(dev), ehs.detach().view(B * 77, D).to(dev).contiguous())
+    assert pred.dtype == torch.float32
+    parity("fp32 UNet pred", pred, pred_ref, rel=1e-4, maxabs=1e-4, ch_dim=1, ch_rel=1e-4)
+    d_ehs = hip.backward(dpred.to(dev))
+    parity("fp32 UNet d_ehs", d_ehs.view(B, 77, D), ehs.grad, rel=1e-4, maxabs=1e-4, ch_dim=2, ch_rel=2e-4)
+
+
+def test_sd15_unet_full_size_f32_vs_oracle():
+    """the README command's arithmetic at full size: SD1.5 UNet, B=1, 64x64 latents, fp32 weights / activations / gradients."""
+    from oracle.unet_sd import UNet2DCondition, UNetConfig
+    from textboost_amd import models
+    from textboost_amd.unet import HipUNet
+    sd = models.random_state_dict(models.unet_shapes(models.SD15_UNET), 91, device="cpu")
+    with torch.device("meta"):
+        ref = UNet2DCondition(UNetConfig.sd15())
+    ref = ref.to_empty(device="cpu")
+    ref.load_state_dict(sd)
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    B = 1
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 4, 64, 64, generator=g)
+    t = torch.tensor([611])
+    ehs = torch.randn(B, 77, 768, generator=g).requires_grad_(True)
+    pred_ref = ref(x, t, ehs)
+    dpred = torch.randn(B, 4, 64, 64, generator=g)
+    pred_ref.backward(dpred)
+    hip = HipUNet(models.SD15_UNET, {k: v.to(dev) for k, v in sd.items()}, B, 64, 64, device=dev, dtype=torch.float32)
+    pred = hip.forward(x.to(dev), t.to(dev), ehs.detach().view(B * 77, 768).to(dev).contiguous())
+    parity("fp32 SD1.5 UNet pred", pred, pred_ref, rel=1e-4, maxabs=1e-4, ch_dim=1, ch_rel=1e-4)
+    d_ehs = hip.backward(dpred.to(dev))
+    parity("fp32 SD1.5 UNet d_ehs", d_ehs.view(B, 77, 768), ehs.grad, rel=1e-4, maxabs=2e-4, ch_dim=2, ch_rel=5e-4)

@@ -50,25 +50,26 @@ class UNetGeometry:
         return self.num_heads if isinstance(self.num_heads, int) else self.num_heads[level]
 
 
-def _f16(t):
-    return t.detach().to(torch.float16)
+def _f16(t, dtype=torch.float16):
+    return t.detach().to(dtype)
 
 
-def _f32_via_f16(t, dev):
-    """unet.to(fp16) (:937) rounds every parameter to fp16; biases / norm affines are consumed as fp32 here."""
-    return t.detach().to(torch.float16).to(torch.float32).to(dev).contiguous()
+def _f32_via_f16(t, dev, dtype=torch.float16):
+    """unet.to(fp16) (:937) rounds every parameter to fp16; biases / norm affines are consumed as fp32 here.  In the fp32 (no-AMP) mode
+    (`dtype` = float32: weight_dtype stays float32, :930-939) nothing is rounded."""
+    return t.detach().to(dtype).to(torch.float32).to(dev).contiguous()
 
 
-def pack_conv3x3(w, dev):
-    """[Co,Ci,3,3] -> fwd [Co, 9*Ci] (k = (ky*3+kx)*Ci + ci) and dgrad [Ci, 9*Co] (k = (ky*3+kx)*Co + co), fp16."""
-    w = _f16(w).to(dev)
+def pack_conv3x3(w, dev, dtype=torch.float16):
+    """[Co,Ci,3,3] -> fwd [Co, 9*Ci] (k = (ky*3+kx)*Ci + ci) and dgrad [Ci, 9*Co] (k = (ky*3+kx)*Co + co), fp16 (fp32 in the no-AMP mode)."""
+    w = _f16(w, dtype).to(dev)
     fwd = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
     dg = w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous()
     return fwd, dg
 
 
-def pack_linear(w, dev):
-    w = _f16(w).to(dev)
+def pack_linear(w, dev, dtype=torch.float16):
+    w = _f16(w, dtype).to(dev)
     if w.dim() == 4:  # 1x1 conv
         w = w.reshape(w.shape[0], w.shape[1])
     return w.contiguous(), w.t().contiguous()
@@ -84,12 +85,17 @@ def pack_geglu_rows(w):
 
 class HipUNet:
     """`forward(sample[B,4,h,w] fp16 NCHW, timesteps[B] i64, ehs[B*77, D] fp16) -> pred[B,4,h,w] fp16`,
-    `backward(dpred[B,4,h,w] fp32) -> d_ehs[B*77, D] fp32` (gradient of the scaled loss)."""
+    `backward(dpred[B,4,h,w] fp32) -> d_ehs[B*77, D] fp32` (gradient of the scaled loss).  With dtype = float32 (the reference's no-AMP
+    mode) sample / ehs / pred are fp32 as well."""
 
     def __init__(self, geo: UNetGeometry, state_dict: Dict[str, torch.Tensor], batch: int, height: int, width: int,
-                 text_len: int = 77, device="cuda", attn_fp8: bool = False):
+                 text_len: int = 77, device="cuda", attn_fp8: bool = False, dtype=torch.float16):
+        """dtype = torch.float16: the reference's --mixed_precision fp16 run (`unet.to(accelerator.device, dtype=weight_dtype)`, :937);
+        torch.float32: its default no-AMP run (:298-308, :930-939) -- every weight, activation and gradient fp32 (csrc/f32_path.hip)."""
+        assert dtype in (torch.float16, torch.float32)
         self.geo, self.B, self.H, self.W, self.T, self.dev = geo, batch, height, width, text_len, device
-        self.dtype = torch.float16
+        self.dtype = dtype
+        assert not (attn_fp8 and dtype != torch.float16)
         # BASELINE.json configs[4]: e4m3 P.V in the forward of the hd = 40 self-attention layers (opt-in; fp16 everywhere else and in the backward)
         self.attn_fp8 = attn_fp8
         self._fp8_ws = None
@@ -100,7 +106,8 @@ class HipUNet:
         self.gn_ws = torch.empty((2048 + 2 * batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
 
     # ------------------------------------------------------------------ buffers
-    def buf(self, name, rows, cols, dtype=torch.float16):
+    def buf(self, name, rows, cols, dtype=None):
+        dtype = self.dtype if dtype is None else dtype
         key = name
         t = self._bufs.get(key)
         if t is None or t.shape != (rows, cols) or t.dtype != dtype:
@@ -108,40 +115,42 @@ class HipUNet:
             self._bufs[key] = t
         return t
 
-    def scratch(self, tag, rows, cols, dtype=torch.float16):
+    def scratch(self, tag, rows, cols, dtype=None):
+        dtype = self.dtype if dtype is None else dtype
         return self.buf(f"scr.{tag}.{rows}x{cols}.{dtype}", rows, cols, dtype)
 
     # ------------------------------------------------------------------ weights
     def _pack(self, sd):
-        dev, geo = self.dev, self.geo
+        dev, geo, wdt = self.dev, self.geo, self.dtype
         P = {}
         self.P = P
+        _f32v = lambda t, d: _f32_via_f16(t, d, wdt)  # noqa: E731
 
         def conv(name):
-            P[name + ".w"], P[name + ".wd"] = pack_conv3x3(sd[name + ".weight"], dev)
-            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+            P[name + ".w"], P[name + ".wd"] = pack_conv3x3(sd[name + ".weight"], dev, wdt)
+            P[name + ".b"] = _f32v(sd[name + ".bias"], dev)
 
         def lin(name, bias=True):
-            P[name + ".w"], P[name + ".wd"] = pack_linear(sd[name + ".weight"], dev)
+            P[name + ".w"], P[name + ".wd"] = pack_linear(sd[name + ".weight"], dev, wdt)
             if bias:
-                P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+                P[name + ".b"] = _f32v(sd[name + ".bias"], dev)
 
         def norm(name):
-            P[name + ".g"] = _f32_via_f16(sd[name + ".weight"], dev)
-            P[name + ".b"] = _f32_via_f16(sd[name + ".bias"], dev)
+            P[name + ".g"] = _f32v(sd[name + ".weight"], dev)
+            P[name + ".b"] = _f32v(sd[name + ".bias"], dev)
 
         ch = geo.block_out_channels
         self.resnets: List[str] = []
         self.xattn: List[Tuple[str, int]] = []   # (prefix of attn2, C)
         self._walk = []
         # conv_in / conv_out as boundary kernels (4-channel NCHW side)
-        w = _f32_via_f16(sd["conv_in.weight"], dev)                     # [C0,4,3,3]
+        w = _f32v(sd["conv_in.weight"], dev)                     # [C0,4,3,3]
         P["conv_in.wp"] = w.permute(2, 3, 1, 0).reshape(36, ch[0]).contiguous()
-        P["conv_in.b"] = _f32_via_f16(sd["conv_in.bias"], dev)
-        w = _f32_via_f16(sd["conv_out.weight"], dev)                    # [4,C0,3,3]
+        P["conv_in.b"] = _f32v(sd["conv_in.bias"], dev)
+        w = _f32v(sd["conv_out.weight"], dev)                    # [4,C0,3,3]
         P["conv_out.wp"] = w.permute(0, 2, 3, 1).reshape(4, 9, ch[0]).contiguous()
         P["conv_out.wdp"] = w.permute(2, 3, 0, 1).reshape(36, ch[0]).contiguous()
-        P["conv_out.b"] = _f32_via_f16(sd["conv_out.bias"], dev)
+        P["conv_out.b"] = _f32v(sd["conv_out.bias"], dev)
         norm("conv_norm_out")
         lin("time_embedding.linear_1")
         lin("time_embedding.linear_2")
@@ -159,14 +168,14 @@ class HipUNet:
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{tb}.{n}")
             wq = torch.cat([sd[f"{tb}.attn1.to_{x}.weight"] for x in "qkv"], dim=0)
-            P[f"{tb}.attn1.qkv.w"], P[f"{tb}.attn1.qkv.wd"] = pack_linear(wq, dev)
+            P[f"{tb}.attn1.qkv.w"], P[f"{tb}.attn1.qkv.wd"] = pack_linear(wq, dev, wdt)
             lin(f"{tb}.attn1.to_out.0")
             lin(f"{tb}.attn2.to_q", bias=False)
             lin(f"{tb}.attn2.to_out.0")
             self.xattn.append((f"{tb}.attn2", C))
             wff = pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.weight"])
-            P[f"{tb}.ff1.w"], P[f"{tb}.ff1.wd"] = pack_linear(wff, dev)
-            P[f"{tb}.ff1.b"] = _f32_via_f16(pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.bias"]), dev)
+            P[f"{tb}.ff1.w"], P[f"{tb}.ff1.wd"] = pack_linear(wff, dev, wdt)
+            P[f"{tb}.ff1.b"] = _f32v(pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.bias"]), dev)
             lin(f"{tb}.ff.net.2")
 
         L_ = geo.layers_per_block
@@ -201,15 +210,15 @@ class HipUNet:
             prev = c
         # hoisted projections
         tw = torch.cat([sd[p + ".time_emb_proj.weight"] for p in self.resnets], dim=0)
-        P["temb_all.w"] = _f16(tw).to(dev).contiguous()
-        P["temb_all.b"] = _f32_via_f16(torch.cat([sd[p + ".time_emb_proj.bias"] for p in self.resnets], dim=0), dev)
+        P["temb_all.w"] = _f16(tw, wdt).to(dev).contiguous()
+        P["temb_all.b"] = _f32v(torch.cat([sd[p + ".time_emb_proj.bias"] for p in self.resnets], dim=0), dev)
         self.temb_off, o = {}, 0
         for p in self.resnets:
             self.temb_off[p] = o
             o += sd[p + ".time_emb_proj.weight"].shape[0]
         self.temb_total = o
         kv = torch.cat([torch.cat([sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0) for p, _ in self.xattn], dim=0)
-        P["kv_all.w"], P["kv_all.wd"] = pack_linear(kv, dev)
+        P["kv_all.w"], P["kv_all.wd"] = pack_linear(kv, dev, wdt)
         self.kv_off, o = {}, 0
         for p, C in self.xattn:
             self.kv_off[p] = o
@@ -331,7 +340,7 @@ class HipUNet:
             dt3 = self.scratch("g1", M, C)
             ops.gemm(dout, P[prefix + ".proj_out.wd"], dt3)
             dproj = self.scratch("gc", M, 8 * C)
-            if FUSE_GEGLU_BWD:   # ff.net.2 dgrad with the GEGLU backward fused into its epilogue
+            if FUSE_GEGLU_BWD or self.dtype == torch.float32:   # ff.net.2 dgrad with the GEGLU backward fused into its epilogue
                 ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
             else:
                 dgated = self.scratch("gb", M, 4 * C)
@@ -346,7 +355,7 @@ class HipUNet:
             dq2 = self.scratch("g2", M, C)
             delta = self.scratch("delta", B * heads, HW, torch.float32)
             dk2, dv2 = self.dkv_all[:, ko:ko + C], self.dkv_all[:, ko + C:ko + 2 * C]
-            xws = self.scratch("xattn_ws", 16 * 2 * B * T, C, torch.float32)
+            xws = self.scratch("xattn_ws", 16 * 2 * B * T, C, torch.float32) if self.dtype == torch.float16 else None
             ops.attention_bwd(q2, k2, v2, o2, lse2, do2, delta, dq2, dk2, dv2, B, heads, HW, T, hd, ws=xws)
             if stop_after_cross:
                 return
@@ -359,7 +368,7 @@ class HipUNet:
             dqkv = self.scratch("gq", M, 3 * C)
             # ws: 2 x [B, heads, HW] floats -- lets the hd = 40 / 64x64-map layers take the LDS-DMA staged dK/dV kernel (the dQ kernel
             # publishes -lse log2 e and -delta there for it); other shapes ignore it
-            sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 64, 80) and HW % 128 == 0 else None
+            sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 64, 80) and HW % 128 == 0 and self.dtype == torch.float16 else None
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, do1, delta, dqkv[:, :C], dqkv[:, C:2 * C],
                               dqkv[:, 2 * C:], B, heads, HW, HW, hd, ws=sws)
             dl1 = self.scratch("g2", M, C)
