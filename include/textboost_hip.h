@@ -282,6 +282,8 @@ int tb_conv_to4_f32(const float* in, int64_t ldi, const float* w_packed, const f
 int tb_upsample2x_f32(const float* x, int64_t ldx, float* u, int64_t ldu, int B, int H, int W, int C, tb_stream_t stream);
 int tb_pool2x2_sum_f32(const float* du, int64_t ldu, float* dx, int64_t ldx, int B, int H, int W, int C, tb_stream_t stream);
 int tb_add_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t M, int C, tb_stream_t stream);
+int tb_lora_pack_f32(const float* A, const float* Bcat, float* w2_fwd /* fp32 [layers][P*D, 64] */, float* w2_dgrad /* fp32 [layers][K, 64] */,
+                     int D, int K, int r, int P, int layers, float scaling, tb_stream_t stream);
 int tb_mse_loss_f32(const float* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
                     float* ws /* >= 256 floats */, tb_stream_t stream);
 

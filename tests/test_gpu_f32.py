@@ -332,3 +332,115 @@ def test_sd15_unet_full_size_f32_vs_oracle():
     parity("fp32 SD1.5 UNet pred", pred, pred_ref, rel=1e-4, maxabs=1e-4, ch_dim=1, ch_rel=1e-4)
     d_ehs = hip.backward(dpred.to(dev))
     parity("fp32 SD1.5 UNet d_ehs", d_ehs.view(B, 77, 768), ehs.grad, rel=1e-4, maxabs=2e-4, ch_dim=2, ch_rel=5e-4)
+
+
+def _encoders_f32(B, D, r=4, n_added=3, seed=0, act="quick_gelu"):
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle import train_step as ts
+    from textboost_amd.text_encoder import CLIPGeometry, HipTextEncoder
+    torch.manual_seed(seed)
+    ccfg = CLIPTextCfg.tiny(D)
+    ccfg.act = act
+    base = TextBoostEncoder(ccfg, r=0)
+    with torch.no_grad():
+        for n, p in base.named_parameters():
+            if "ln" in n or n.endswith("bias"):
+                p.add_(torch.randn_like(p) * 0.1)
+        base.token_embedding.weight.mul_(0.5)
+        null = base.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    base.set_null_embedding(null)
+    teacher = ts.make_teacher(base)
+    student = TextBoostEncoder(ccfg, r=r)
+    student.load_state_dict(base.state_dict(), strict=False)
+    student.set_null_embedding(null)
+    with torch.no_grad():
+        for n, p in student.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.05)
+    added = add_tokens(student, [100, 200, 300][:n_added])
+    geo = CLIPGeometry(hidden_size=D, intermediate_size=ccfg.intermediate_size, num_layers=ccfg.num_layers, num_heads=ccfg.num_heads, act=act)
+    sd = {hf: dict(base.named_parameters())[ours].detach() for ours, hf in base.hf_key_map().items()}
+    hip = HipTextEncoder(geo, sd, B, mode="fp32", lora_rank=r, n_slots=2, device=dev, seed=0)
+    hip.set_null_embedding(null)
+    hip.add_tokens([100, 200, 300][:n_added])
+    for i, layer in enumerate(student.layers):
+        hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
+        hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
+    hip_teacher = HipTextEncoder(geo, sd, B, mode="fp32", lora_rank=0, device=dev)
+    hip_teacher.set_null_embedding(null)
+    return student, teacher, hip, hip_teacher, added, null
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_text_encoder_f32_forward_backward_vs_oracle(act):
+    """the trainable encoder in the fp32 mode (fp32 LoRA products as exact-fp32 GEMMs) and the fp32 KPL teacher rows in the same pass"""
+    from oracle import train_step as ts
+    B, D = 3, 64
+    student, teacher, hip, hip_teacher, added, null = _encoders_f32(B, D, act=act)
+    g = torch.Generator().manual_seed(2)
+    ids = ts.synthetic_ids(B, added, g)
+    ids[1, 1:] = 49407
+    pids = ts.synthetic_ids(B, added, g, prior=True)
+    out_ref = student(ids)
+    R = torch.randn(B, 77, D, generator=g)
+    (out_ref * R).sum().backward()
+    with torch.no_grad():
+        t_ref = teacher(pids)
+    hip.pack_lora()
+    merged = hip.forward(ids.to(dev), slot=0, extra_ids=pids.to(dev), extra_table=hip_teacher.token_table)
+    out, t_out = merged[:B * 77], merged[B * 77:]
+    parity("fp32 encoder hidden states", out.view(B, 77, D), out_ref, rel=1e-5, maxabs=2e-5, ch_dim=2, ch_rel=1e-4)
+    parity("fp32 teacher rows", t_out.view(B, 77, D), t_ref, rel=1e-5, maxabs=2e-5)
+    assert torch.equal(out.view(B, 77, D)[1].cpu(), null)
+    hip.zero_grad()
+    hip.backward(R.view(B * 77, D).to(dev).contiguous(), slot=0)
+    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in student.layers])
+    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in student.layers])
+    parity("fp32 encoder grad lora_A", hip.grad_A, gA, rel=1e-4, maxabs=1e-4, ch_dim=0, ch_rel=1e-4)
+    parity("fp32 encoder grad lora_B", hip.grad_B, gB, rel=1e-4, maxabs=1e-4, ch_dim=0, ch_rel=1e-4)
+    parity("fp32 encoder grad added rows", hip.grad_added, student.token_embedding.weight.grad[added], rel=1e-4, maxabs=1e-4)
+
+
+@pytest.mark.parametrize("kpl_type,prediction_type", [("cos", "epsilon"), ("mse", "v_prediction")])
+def test_full_step_f32_matches_oracle_elementwise(kpl_type, prediction_type):
+    """Two optimizer steps of the no-AMP mode (no GradScaler: loss scale 1, nothing is ever skipped) against the fp32 oracle step:
+    losses, gradients (1e-4) and the updated parameters."""
+    from oracle import train_step as ts
+    from textboost_amd.trainer import StepHyper, TextBoostStep
+    B, hw, D = 2, 16, 64
+    ref_unet, hip_unet = _small_unet_f32(B, hw, D, seed=3)
+    student, teacher, hip_te, hip_teacher, added, null = _encoders_f32(B, D, seed=4)
+    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig(kpl_type=kpl_type, prediction_type=prediction_type))
+    hp = StepHyper(use_grad_scaler=False, init_scale=1.0, kpl_type=kpl_type, prediction_type=prediction_type)
+    step = TextBoostStep(hip_unet, hip_te, hip_teacher, hp, (B, 4, hw, hw), device=dev)
+    step.external_noise = True
+    g = torch.Generator().manual_seed(5)
+    te_ref = st_ref.te
+    for it in range(2):
+        ids, pids = ts.synthetic_ids(B, added, g), ts.synthetic_ids(B, added, g, prior=True)
+        x0, noise = torch.randn(B, 4, hw, hw, generator=g), torch.randn(B, 4, hw, hw, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        A_before = step.te.lora_A.clone()
+        out = st_ref.step(x0, noise, t, ids, pids)
+        step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t)
+        step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+        step.step_eager()
+        sc = step.scalars()
+        assert sc["found_inf"] == 0.0 and sc["loss_scale"] == 1.0
+        assert abs(sc["loss_mse"] - out["mse"]) < 1e-5 * abs(out["mse"]) + 1e-7, (sc, out["mse"])
+        assert abs(sc["loss_kpl"] - out["kpl"]) < 1e-4 * abs(out["kpl"]) + 1e-7, (sc, out["kpl"])
+        L_ = len(te_ref.layers)
+        gA = torch.stack([torch.cat(out["g_lora"][6 * l + 0: 6 * l + 6: 2]) for l in range(L_)])
+        gB = torch.stack([torch.cat(out["g_lora"][6 * l + 1: 6 * l + 6: 2]) for l in range(L_)])
+        clip = min(1.0, 1.0 / (out["lora_grad_norm"] + 1e-6))   # the oracle's g_lora are post-clip
+        assert abs(sc["grad_norm"] - out["lora_grad_norm"]) < 1e-4 * out["lora_grad_norm"]
+        parity(f"fp32 step {it} grad lora_A", step.te.grad_A * clip, gA, rel=1e-4, maxabs=1e-4)
+        parity(f"fp32 step {it} grad lora_B", step.te.grad_B * clip, gB, rel=1e-4, maxabs=1e-4)
+        parity(f"fp32 step {it} grad added rows", step.te.grad_added, out["g_emb_added"], rel=1e-4, maxabs=1e-4)
+        w, wr = step.te.token_table.cpu(), te_ref.token_embedding.weight.detach()
+        torch.testing.assert_close(w[:49408], wr[:49408], rtol=1e-6, atol=1e-7)
+        parity(f"fp32 step {it} updated added rows", w[added], wr[added], rel=2e-4, maxabs=5e-4)
+        A_ref = torch.stack([torch.cat([l.q.lora_A, l.k.lora_A, l.v.lora_A]) for l in te_ref.layers]).detach()
+        assert (step.te.lora_A.cpu() - A_ref).abs().max().item() < 2e-5           # < lr / 2: no element moved the other way
+        assert not torch.equal(step.te.lora_A, A_before)
+    assert step.scalars()["opt_steps"] == 2.0

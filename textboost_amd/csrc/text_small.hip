@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const f16* __restrict__ 
 // ---- one launch packs the fp16 K-extension operands of ALL layers (the stacks are contiguous over layers):
 //   W2 [l][p*D + n, p*r + j] = scaling * B[l][(p*D + n)*r + j]   (block diagonal, zero elsewhere; 64 columns)
 //   W2d[l][k, j]             = A[l][j*K + k] for j < R else 0    (fp16 [K, 64]: second K-source of the qkv dgrad GEMM)
-__global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ A, const float* __restrict__ Bcat, f16* __restrict__ W2,
-                                                        f16* __restrict__ W2d, int D, int K, int r, int P, int layers, float scaling) {
+template <typename TW>  // f16: K-extension operands of the fp16 GEMMs; float: the fp32 (no-AMP) mode
+__global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ A, const float* __restrict__ Bcat, TW* __restrict__ W2,
+                                                        TW* __restrict__ W2d, int D, int K, int r, int P, int layers, float scaling) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t nb = (int64_t)layers * P * D * 64, na = (int64_t)layers * K * 64;
   if (idx < nb) {
@@ -112,14 +113,14 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
     const int p = (int)((n / D) % P);
     float v = 0.f;
     if (j >= p * r && j < (p + 1) * r) v = scaling * Bcat[n * r + (j - p * r)];
-    W2[idx] = (f16)v;
+    W2[idx] = (TW)v;
   } else if (idx < nb + na) {
     const int64_t i = idx - nb;
     const int64_t lk = i / 64;  // layer * K + k
     const int j = (int)(i - lk * 64);
     const int64_t l = lk / K, k = lk - l * K;
     const int R = P * r;
-    W2d[i] = (f16)(j < R ? A[(l * R + j) * K + k] : 0.f);
+    W2d[i] = (TW)(j < R ? A[(l * R + j) * K + k] : 0.f);
   }
 }
 
@@ -382,8 +383,19 @@ extern "C" int tb_lora_pack(const float* A, const float* Bcat, void* w2_fwd, voi
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!A || !Bcat || !w2_fwd || !w2_dgrad || P * r > 64 || layers <= 0) return TB_EINVAL;
   const int64_t n = (int64_t)layers * ((int64_t)P * D + K) * 64;
-  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), dim3(256), 0, (hipStream_t)stream, A, Bcat, (f16*)w2_fwd, (f16*)w2_dgrad, D, K, r, P,
+  hipLaunchKernelGGL(lora_pack_kernel<f16>, GRID1D(n), dim3(256), 0, (hipStream_t)stream, A, Bcat, (f16*)w2_fwd, (f16*)w2_dgrad, D, K, r, P,
                      layers, scaling);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+// the same operands in fp32 for the no-AMP mode (train_textboost.py:298-308): w2_fwd fp32 [layers][P*D, 64], w2_dgrad fp32 [layers][K, 64]
+extern "C" int tb_lora_pack_f32(const float* A, const float* Bcat, float* w2_fwd, float* w2_dgrad, int D, int K, int r, int P, int layers,
+                                float scaling, tb_stream_t stream) {
+  (void)hipGetLastError();
+  if (!A || !Bcat || !w2_fwd || !w2_dgrad || P * r > 64 || layers <= 0) return TB_EINVAL;
+  const int64_t n = (int64_t)layers * ((int64_t)P * D + K) * 64;
+  hipLaunchKernelGGL(lora_pack_kernel<float>, GRID1D(n), dim3(256), 0, (hipStream_t)stream, A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, layers,
+                     scaling);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -427,6 +427,10 @@ def lora_down(x, A, t):
 
 
 def lora_pack(A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, scaling=1.0, layers=1):
+    if w2_fwd.dtype == torch.float32:
+        L.check(L.lib().tb_lora_pack_f32(L.ptr(A), L.ptr(Bcat), L.ptr(w2_fwd), L.ptr(w2_dgrad), D, K, r, P, layers, scaling, L.stream()),
+                "tb_lora_pack_f32")
+        return
     L.check(L.lib().tb_lora_pack(L.ptr(A), L.ptr(Bcat), L.ptr(w2_fwd), L.ptr(w2_dgrad), D, K, r, P, layers, scaling, L.stream()),
             "tb_lora_pack")
 
@@ -434,8 +438,20 @@ def lora_pack(A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, scaling=1.0, layers=1):
 _lora_ws = {}
 
 
-def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None):
+def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None, w2_fwd=None):
     M = x.shape[0]
+    if dY.dtype == torch.float32:
+        # fp32 (no-AMP) mode: the same three products as csrc/text_small.hip lora_bwd_fused_kernel, as exact-fp32 GEMMs on transposed views
+        #   (a) dt = dY @ W2 (W2 = the packed block-diagonal scaling * B, [P*D, 64])       (b) dB_p += scaling * dY_p^T @ t_p
+        #   (c) dA += dt[:, :P*r]^T @ x
+        gemm_f32_t(dY, w2_fwd, dt, M, dt.shape[1], P * D, w_trans=True)
+        dBv = dB.view(P * D, r)
+        for p in range(P):
+            gemm_f32_t(dY[:, p * D:(p + 1) * D], t[:, p * r:(p + 1) * r], dBv[p * D:(p + 1) * D], D, r, M, a_trans=True, w_trans=True,
+                       R=dBv[p * D:(p + 1) * D], alpha=scaling)
+        dAv = dA.view(P * r, K)
+        gemm_f32_t(dt, x, dAv, P * r, K, M, a_trans=True, w_trans=True, R=dAv)
+        return
     if ws is None:
         key = (M, D, K, r, P, x.device)
         ws = _lora_ws.get(key)

@@ -4,10 +4,12 @@ Mirrors /root/reference/textboost/text_encoder.py:17-87 (`TextBoostModel`), the 
 train_textboost.py:700-722 (peft `LoraConfig(r, lora_alpha=r, init_lora_weights="gaussian",
 target_modules=["q_proj","k_proj","v_proj"])`) and the token-table growth of textboost/utils.py:117-166.
 
-Two numeric modes, matching how the reference runs the two encoders in fp16 mixed precision:
-  * "autocast" -- the trainable encoder under accelerate autocast: fp32 master params, fp32 residual stream and
+Three numeric modes, matching how the reference runs the two encoders:
+  * "autocast" -- the trainable encoder under accelerate autocast (--mixed_precision fp16): fp32 master params, fp32 residual stream and
     LayerNorm/softmax statistics, fp16 Linear/attention operands (`train_textboost.py:919-926`);
-  * "half"     -- the KPL teacher `original_text_encoder.to(fp16)` (:650, :939): plain fp16 module, forward only.
+  * "half"     -- the KPL teacher `original_text_encoder.to(fp16)` (:650, :939): plain fp16 module, forward only;
+  * "fp32"     -- no mixed precision (the default, :298-308; weight_dtype stays float32, :930-939): every parameter, activation
+    and gradient fp32, for the trainable encoder and the teacher alike (csrc/f32_path.hip).
 
 All arithmetic is in libtextboost_hip.so; this file owns parameters, buffers and the layer schedule.
 Trainable state lives in three flat fp32 buffers so the optimizer / all-reduce see one tensor each:
@@ -46,25 +48,27 @@ class HipTextEncoder:
     def __init__(self, geo: CLIPGeometry, state_dict: Dict[str, torch.Tensor], batch: int, mode: str = "autocast", lora_rank: int = 0,
                  lora_alpha: Optional[float] = None, n_slots: int = 1, device="cuda", seed: Optional[int] = None):
         """state_dict uses transformers CLIPTextModel keys (`text_model.embeddings.token_embedding.weight`, ...)."""
-        assert mode in ("autocast", "half")
+        assert mode in ("autocast", "half", "fp32")
         assert geo.act in ("quick_gelu", "gelu")  # SD1.x CLIP-L / SD2.x OpenCLIP-H
         self.act_fwd, self.act_bwd = (L.ACT_QUICK_GELU, L.ACT_QUICK_GELU_GRAD) if geo.act == "quick_gelu" else (L.ACT_GELU, L.ACT_GELU_GRAD)
         self.geo, self.B, self.T, self.mode, self.dev = geo, batch, geo.max_pos, mode, device
         self.r = lora_rank
         self.scaling = (lora_alpha if lora_alpha is not None else lora_rank) / lora_rank if lora_rank else 0.0
-        self.res_dtype = torch.float32 if mode == "autocast" else torch.float16
+        self.res_dtype = torch.float32 if mode in ("autocast", "fp32") else torch.float16
+        self.op_dtype = torch.float32 if mode == "fp32" else torch.float16   # Linear / attention operands and activations
         self.n_slots = n_slots
         self._bufs: Dict[str, torch.Tensor] = {}
         D, Lr = geo.hidden_size, geo.num_layers
         sd = state_dict
         pre = "text_model."
-        f16 = lambda t: t.detach().to(torch.float16).to(device).contiguous()
-        f32r = lambda t: t.detach().to(torch.float16).to(torch.float32).to(device).contiguous()  # fp16-rounded, fp32 storage
-        tbl_dt = torch.float32 if mode == "autocast" else torch.float16
+        odt = self.op_dtype
+        f16 = lambda t: t.detach().to(odt).to(device).contiguous()
+        f32r = lambda t: t.detach().to(odt).to(torch.float32).to(device).contiguous()  # rounded like the operands (not at all in fp32 mode), fp32 storage
+        tbl_dt = torch.float32 if mode in ("autocast", "fp32") else torch.float16
         self.token_table = sd[pre + "embeddings.token_embedding.weight"].detach().to(tbl_dt).to(device).contiguous()
         self.pos_table = sd[pre + "embeddings.position_embedding.weight"].detach().to(tbl_dt).to(device).contiguous()
         # LayerNorm affine: fp32 params under autocast (LN runs in fp32); fp16-rounded for the half module
-        lnp = (lambda t: t.detach().float().to(device).contiguous()) if mode == "autocast" else f32r
+        lnp = (lambda t: t.detach().float().to(device).contiguous()) if mode in ("autocast", "fp32") else f32r
         self.Wl: List[Dict[str, torch.Tensor]] = []
         for i in range(Lr):
             lp = f"{pre}encoder.layers.{i}."
@@ -93,8 +97,8 @@ class HipTextEncoder:
             self.lora_B = torch.zeros(Lr, 3 * D, self.r, device=device)
             self.grad_A = torch.zeros_like(self.lora_A)
             self.grad_B = torch.zeros_like(self.lora_B)
-            self.w2_fwd = torch.zeros(Lr, 3 * D, 64, device=device, dtype=torch.float16)
-            self.w2_dgrad = torch.zeros(Lr, D, 64, device=device, dtype=torch.float16)
+            self.w2_fwd = torch.zeros(Lr, 3 * D, 64, device=device, dtype=odt)
+            self.w2_dgrad = torch.zeros(Lr, D, 64, device=device, dtype=odt)
 
     # ------------------------------------------------------------------ reference-facing surface
     def set_null_embedding(self, null):  # text_encoder.py:28-32
@@ -154,7 +158,8 @@ class HipTextEncoder:
         if extra_ids is not None:
             B = B + extra_ids.shape[0]
         M = B * T
-        rdt, f16, f32 = self.res_dtype, torch.float16, torch.float32
+        rdt, f16, f32 = self.res_dtype, self.op_dtype, torch.float32   # (`f16` = the operand dtype: fp32 in the no-AMP mode)
+        full32 = self.mode == "fp32"
         ids = input_ids.reshape(-1).contiguous()
         s = f"s{slot}."
         self._bufs[s + "ids"] = ids
@@ -170,7 +175,11 @@ class HipTextEncoder:
             qkv = self.buf(p + "qkv", M, 3 * D, f16)
             if self.r:
                 t = self.buf(p + "t", M, 64, f16)  # columns >= 3r (and the frozen extra rows) stay zero (K-extension operand of the qkv GEMM)
-                ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps, lora_A=self.lora_A[i], t=t, lora_rows=Ms)
+                if full32:  # no fused (fp16) down projection: t[:Ms, :3r] = x1 @ A^T as an exact-fp32 GEMM
+                    ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
+                    ops.gemm(x1[:Ms], self.lora_A[i], t[:Ms, :3 * self.r])
+                else:
+                    ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps, lora_A=self.lora_A[i], t=t, lora_rows=Ms)
                 ops.gemm(x1, W["qkv.w"], qkv, A2=t, W2=self.w2_fwd[i], bias=W["qkv.b"])
             else:
                 ops.layernorm_fwd(h, x1, W["ln1.g"], W["ln1.b"], ls1, geo.eps)
@@ -209,7 +218,8 @@ class HipTextEncoder:
     def backward(self, d_out, slot=0, pins=True):
         """d_out: fp32 [B*T, D] gradient of the (scaled) loss w.r.t. forward(slot)'s output. Accumulates into
         grad_A / grad_B / grad_added."""
-        assert self.mode == "autocast"
+        assert self.mode in ("autocast", "fp32")
+        full32 = self.mode == "fp32"
         geo, T = self.geo, self.T
         D, I, H = geo.hidden_size, geo.intermediate_size, geo.num_heads
         hd = D // H
@@ -217,12 +227,13 @@ class HipTextEncoder:
         ids = self._bufs[s + "ids"]
         M = ids.numel()
         B = M // T
-        f16, f32 = torch.float16, torch.float32
+        f16, f32 = self.op_dtype, torch.float32
         if pins:
             ops.pin_bwd(d_out, ids, B, T, self.use_fixed_special_embedding, EOS_ID)
         h_last = self._bufs[f"{s}l{geo.num_layers - 1}.h3"][:M]
         dh = self.buf("g.dh_a", M, D, f32)
-        dh16 = self.buf("g.dh16", M, D, f16)  # fp16 copy of the running residual gradient, written by the LayerNorm backward
+        # fp16 copy of the running residual gradient, written by the LayerNorm backward (fp32 mode: the fp32 gradient itself feeds the GEMMs)
+        dh16 = None if full32 else self.buf("g.dh16", M, D, f16)
         ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh, dx16=dh16)
         dh_other = self.buf("g.dh_b", M, D, f32)
         for i in reversed(range(geo.num_layers)):
@@ -234,13 +245,13 @@ class HipTextEncoder:
             lse = self._bufs[p + "lse"][:B * H]
             x1 = self._bufs[p + "x1"][:M]
             dpre = self.buf("g.dpre", M, I, f16)
-            ops.gemm(dh16, W["fc2.wd"], dpre, act=self.act_bwd, C2=pre)
+            ops.gemm(dh if full32 else dh16, W["fc2.wd"], dpre, act=self.act_bwd, C2=pre)
             dx2 = self.buf("g.dx", M, D, f16)
             ops.gemm(dpre, W["fc1.wd"], dx2)
             dh2 = dh_other
             ops.layernorm_bwd(dx2, h2, W["ln2.g"], self._bufs[p + "ls2"], dh2, add=dh, dx16=dh16)
             do = self.buf("g.do", M, D, f16)
-            ops.gemm(dh16, W["out.wd"], do)
+            ops.gemm(dh2 if full32 else dh16, W["out.wd"], do)
             dqkv = self.buf("g.dqkv", M, 3 * D, f16)
             delta = self.buf("g.delta", B * H, T, f32)
             ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, do, delta, dqkv[:, :D], dqkv[:, D:2 * D],
@@ -249,11 +260,11 @@ class HipTextEncoder:
             if self.r:
                 dt = self.buf("g.dt", M, 64, f16)
                 ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, self.grad_A[i], self.grad_B[i], D, D, self.r, 3,
-                             self.scaling)
+                             self.scaling, w2_fwd=self.w2_fwd[i])
                 ops.gemm(dqkv, W["qkv.wd"], dx1, A2=dt, W2=self.w2_dgrad[i])
             else:
                 ops.gemm(dqkv, W["qkv.wd"], dx1)
-            ops.layernorm_bwd(dx1, h_in, W["ln1.g"], self._bufs[p + "ls1"], dh, add=dh2, dx16=dh16 if i > 0 else None)
+            ops.layernorm_bwd(dx1, h_in, W["ln1.g"], self._bufs[p + "ls1"], dh, add=dh2, dx16=dh16 if (i > 0 and not full32) else None)
             # dh (buffer a) now holds the gradient w.r.t. this layer's input; dh2 (buffer b) is free again
         if self.n_added:
             ops.embed_bwd(dh, ids, self.grad_added, self.first_added)

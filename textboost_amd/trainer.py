@@ -173,10 +173,13 @@ class TextBoostStep:
         self.input_ids = self.ids_all[:B]
         self.prior_ids = self.ids_all[B:] if self.kpl else torch.zeros(B, te.T, dtype=torch.int64, device=device)
         self.d_all = torch.zeros(nb * te.T, D, device=device)
-        self.noisy = torch.empty(B, C, H, W, device=device, dtype=torch.float16)
+        # activations handed to the UNet: fp16 under --mixed_precision fp16 (`.to(unet.dtype)`, :1064-1066), fp32 in the no-AMP mode
+        adt = unet.dtype
+        assert (adt == torch.float32) == (text_encoder.mode == "fp32"), "fp32 (no-AMP) mode needs both the UNet and the text encoder in fp32"
+        self.noisy = torch.empty(B, C, H, W, device=device, dtype=adt)
         self.velocity = torch.empty(B, C, H, W, device=device) if hyper.prediction_type == "v_prediction" else None
         self.dpred = torch.empty(B, C, H, W, device=device)
-        self.ehs16 = torch.empty(B * te.T, D, device=device, dtype=torch.float16)
+        self.ehs16 = torch.empty(B * te.T, D, device=device, dtype=adt)
         self.d_ehs = self.d_all[: B * te.T]
         self.d_prior = self.d_all[B * te.T:]
         self.kpl_partial = torch.empty(B * te.T, device=device)
