@@ -81,7 +81,7 @@ def test_fp16_overflow_skips_the_step_and_halves_the_scale():
 
 
 def test_cli_rejects_unbuilt_arithmetic_options(tmp_path):
-    """Options that would change the step's arithmetic but are not built must fail loudly (no silent fp16 run under --mixed_precision no)."""
+    """Options that would change the step's arithmetic but are not built must fail loudly (the fp32 no-AMP mode is built: tests/test_gpu_f32.py)."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -89,7 +89,7 @@ def test_cli_rejects_unbuilt_arithmetic_options(tmp_path):
     import train_textboost as T
     base = ["--pretrained_model_name_or_path", "/nonexistent/sd15", "--output_dir", str(tmp_path / "o"), "--train_batch_size", "1",
             "--resolution", "128", "--max_train_steps", "1"]
-    for extra in (["--mixed_precision", "no"], [], ["--mixed_precision", "fp16", "--gradient_accumulation_steps", "2"],
+    for extra in (["--mixed_precision", "bf16"], ["--mixed_precision", "fp16", "--gradient_accumulation_steps", "2"],
                   ["--mixed_precision", "fp16", "--lora_rank", "0"], ["--mixed_precision", "fp16", "--text_encoder_use_attention_mask"]):
         with pytest.raises(NotImplementedError):
             T.main(T.parse_args(base + extra))

@@ -444,3 +444,34 @@ def test_full_step_f32_matches_oracle_elementwise(kpl_type, prediction_type):
         assert (step.te.lora_A.cpu() - A_ref).abs().max().item() < 2e-5           # < lr / 2: no element moved the other way
         assert not torch.equal(step.te.lora_A, A_before)
     assert step.scalars()["opt_steps"] == 2.0
+
+
+def test_cli_readme_command_runs_in_fp32(tmp_path):
+    """The reference's README command (README.md:58-76) passes no --mixed_precision: everything runs in fp32 (train_textboost.py:298-308,
+    :930-939), no GradScaler.  4 steps on synthetic latents through the CLI: the step is captured in a HIP graph, the loss scale stays 1,
+    no step is skipped, the reference output layout is written, and a second run with the same seed reproduces the weights bit for bit."""
+    import os
+    import sys
+    from safetensors.torch import load_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+
+    def run(out):
+        args = T.parse_args(["--pretrained_model_name_or_path", "/nonexistent/sd15", "--output_dir", out, "--train_batch_size", "2",
+                             "--resolution", "128", "--max_train_steps", "4", "--checkpointing_steps", "4", "--placeholder_token", "<dog>",
+                             "--augment_inversion", "--lora_rank", "4", "--learning_rate", "5e-5", "--emb_learning_rate", "1e-3",
+                             "--seed", "42", "--kpl_weight", "0.1"])
+        assert args.mixed_precision is None
+        T.main(args)
+        return load_file(os.path.join(out, "text_encoder", "adapter_model.safetensors")), torch.load(os.path.join(out, "dog.bin"))
+
+    sd1, tok1 = run(str(tmp_path / "a"))
+    log = open(os.path.join(str(tmp_path / "a"), "training.log")).read()
+    assert "precision fp32" in log and " scale 1 " in log   # the no-AMP mode ran, loss scale stayed 1
+    assert len(sd1) == 72 and any(v.abs().max() > 0 for k, v in sd1.items() if "lora_B" in k)
+    assert os.path.isdir(os.path.join(str(tmp_path / "a"), "checkpoint-4"))
+    sd2, tok2 = run(str(tmp_path / "b"))
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    assert torch.equal(tok1["<dog>"], tok2["<dog>"])

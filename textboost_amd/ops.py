@@ -228,10 +228,19 @@ _attn_f32_ws = {}
 def _attn_f32_workspace(dev, B, H, Sq, Skv):
     """fp32 mode: the materialised score / probability matrices (grown to the largest attention shape seen, shared by every layer)."""
     need = int(L.lib().tb_attention_f32_ws_floats(B, H, Sq, Skv))
+    dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    if dev.index is None:
+        dev = torch.device(dev.type, torch.cuda.current_device())
     ws = _attn_f32_ws.get(dev)
     if ws is None or ws.numel() < need:
         ws = _attn_f32_ws[dev] = torch.empty(need, device=dev, dtype=torch.float32)
     return ws
+
+
+def reserve_attention_f32(dev, B, H, Sq, Skv):
+    """fp32 mode: size the shared score workspace up front (the executors call this at construction, so no allocation happens later inside
+    a HIP-graph capture)."""
+    _attn_f32_workspace(dev if isinstance(dev, torch.device) else torch.device(dev), B, H, Sq, Skv)
 
 
 def attention_fp8_workspace(B, H, Skv, device):

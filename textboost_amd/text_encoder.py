@@ -84,6 +84,8 @@ class HipTextEncoder:
                 W[n + ".g"], W[n + ".b"] = lnp(sd[lp + HF_LAYER[n] + ".weight"]), lnp(sd[lp + HF_LAYER[n] + ".bias"])
             self.Wl.append(W)
         self.lnf_g, self.lnf_b = lnp(sd[pre + "final_layer_norm.weight"]), lnp(sd[pre + "final_layer_norm.bias"])
+        if mode == "fp32":
+            ops.reserve_attention_f32(device, 3 * batch, geo.num_heads, self.T, self.T)   # student + prior + teacher rows in one pass
         self.null_embedding = torch.zeros(self.T, D, device=device, dtype=torch.float32)
         self.use_fixed_special_embedding = False
         self.first_added = self.token_table.shape[0]

@@ -104,6 +104,8 @@ class HipUNet:
         self._pack(state_dict)
         # tb_groupnorm_ws_floats = B * chunks * G * 2 with B * chunks <= 2048 (+B when chunks clamps to 1)
         self.gn_ws = torch.empty((2048 + 2 * batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
+        if dtype == torch.float32:  # the fp32 attention materialises its score matrices: reserve the largest one now (level 0 self-attention)
+            ops.reserve_attention_f32(device, batch, geo.heads(0), height * width, max(height * width, text_len))
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name, rows, cols, dtype=None):

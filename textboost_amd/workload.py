@@ -34,22 +34,28 @@ def synthetic_ids(B, added_ids, gen: torch.Generator, prior=False, null_prob=0.1
 
 def build_step(batch=8, latent=64, unet_geo: UNetGeometry = models.SD15_UNET, clip_geo: CLIPGeometry = models.SD15_CLIP,
                lora_rank=4, n_added=18, hyper: StepHyper | None = None, weight_seed=1234, data_seed=1000, device="cuda",
-               world_size=1, with_vae=False, attn_fp8=False):
+               world_size=1, with_vae=False, attn_fp8=False, precision="fp16"):
     """Config 2 of BASELINE.json by default: SD1.5 UNet + CLIP-L, per-GPU batch 8, 512^2 (64^2 latents), LoRA r=4, KPL on,
-    18 added token vectors (2 placeholder + 16 augmentation vectors)."""
-    hyper = hyper or StepHyper()
+    18 added token vectors (2 placeholder + 16 augmentation vectors).
+    precision: "fp16" = the reference driver's --mixed_precision fp16 (run_textboost_db.py:150); "fp32" = its default no-AMP mode
+    (train_textboost.py:298-308, the README command): fp32 everywhere, no GradScaler."""
+    assert precision in ("fp16", "fp32")
+    f32 = precision == "fp32"
+    hyper = hyper or (StepHyper(use_grad_scaler=False, init_scale=1.0) if f32 else StepHyper())
     usd = models.random_state_dict(models.unet_shapes(unet_geo), weight_seed, device=device)
-    unet = HipUNet(unet_geo, usd, batch, latent, latent, text_len=clip_geo.max_pos, device=device, attn_fp8=attn_fp8)
+    unet = HipUNet(unet_geo, usd, batch, latent, latent, text_len=clip_geo.max_pos, device=device, attn_fp8=attn_fp8,
+                   dtype=torch.float32 if f32 else torch.float16)
     del usd
     csd = models.random_state_dict(models.clip_shapes(clip_geo), weight_seed + 1, device=device)
-    teacher = HipTextEncoder(clip_geo, csd, batch, mode="half", device=device)
+    teacher = HipTextEncoder(clip_geo, csd, batch, mode="fp32" if f32 else "half", device=device)
     # null embedding = frozen encoder output for the empty prompt (the reference ships one only for SD2.1, SURVEY 0.5)
     null_ids = torch.full((1, clip_geo.max_pos), EOS, dtype=torch.int64, device=device)
     null_ids[0, 0] = BOS
-    frozen = HipTextEncoder(clip_geo, csd, 1, mode="autocast", device=device)
+    frozen = HipTextEncoder(clip_geo, csd, 1, mode="fp32" if f32 else "autocast", device=device)
     null = frozen.forward(null_ids, pins=False).clone()
     del frozen
-    te = HipTextEncoder(clip_geo, csd, batch, mode="autocast", lora_rank=lora_rank, n_slots=2, device=device, seed=weight_seed + 2)
+    te = HipTextEncoder(clip_geo, csd, batch, mode="fp32" if f32 else "autocast", lora_rank=lora_rank, n_slots=2, device=device,
+                        seed=weight_seed + 2)
     del csd
     te.set_null_embedding(null)
     teacher.set_null_embedding(null)

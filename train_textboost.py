@@ -128,7 +128,12 @@ def main(args):
         latents, latent = None, pixels.shape[-1] // 8
     if latents is not None:
         latent = latents.shape[-1]
-    unet = HipUNet(unet_geo, usd, B, latent, latent, text_len=clip_geo.max_pos, device=dev)
+    # --mixed_precision (:298-308): "fp16" = fp16 UNet / teacher, autocast text encoder with fp32 masters, dynamic loss scaling (:930-939);
+    # unset / "no" = the default: weight_dtype float32, everything in fp32, no GradScaler (accelerate launch would otherwise take the mode from its
+    # own config file; there is none here, so the flag alone decides)
+    fp32_mode = args.mixed_precision in (None, "no")
+    adt = torch.float32 if fp32_mode else torch.float16
+    unet = HipUNet(unet_geo, usd, B, latent, latent, text_len=clip_geo.max_pos, device=dev, dtype=adt)
     # ---- validation sampling (:453-531, :1212-1228): prompts must arrive tokenised (no tokenizer offline)
     val_ids_path = os.path.join(args.instance_data_dir or "", "validation_input_ids.pt")
     val_ids = torch.load(val_ids_path) if args.validation_prompts and os.path.exists(val_ids_path) else None
@@ -149,13 +154,14 @@ def main(args):
         # DDIM instance's value) and steps_offset are inherited from the model's own scheduler
         scfg_path = os.path.join(mdir, "scheduler", "scheduler_config.json")
         scfg = json.load(open(scfg_path)) if os.path.exists(scfg_path) else None
-        sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),
+        sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),  # (validation images: fp16 pipeline in both modes)
                              HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5,
                              scheduler_config=scfg)
         del dsd
     del usd
-    teacher = HipTextEncoder(clip_geo, csd, B, mode="half", device=dev) if args.kpl_weight > 0 else None
-    frozen = HipTextEncoder(clip_geo, csd, 1, mode="autocast", device=dev)
+    te_mode = "fp32" if fp32_mode else "autocast"
+    teacher = HipTextEncoder(clip_geo, csd, B, mode="fp32" if fp32_mode else "half", device=dev) if args.kpl_weight > 0 else None
+    frozen = HipTextEncoder(clip_geo, csd, 1, mode=te_mode, device=dev)
     null_ids = torch.full((1, clip_geo.max_pos), EOS, dtype=torch.int64, device=dev)
     null_ids[0, 0] = BOS
     null = frozen.forward(null_ids, pins=False).clone()  # SD1.x null embedding (the reference ships one only for SD2.1: SURVEY 0.5)
@@ -167,7 +173,7 @@ def main(args):
         if tuple(t.shape) == tuple(null.shape[-2:]):
             null = t.to(dev, null.dtype).reshape(null.shape)
             logger.info("null embedding loaded from %s", shipped)
-    te = HipTextEncoder(clip_geo, csd, B, mode="autocast", lora_rank=args.lora_rank, n_slots=1, device=dev, seed=args.seed)
+    te = HipTextEncoder(clip_geo, csd, B, mode=te_mode, lora_rank=args.lora_rank, n_slots=1, device=dev, seed=args.seed)
     del csd
     te.set_null_embedding(null)
     if teacher is not None:
@@ -204,7 +210,7 @@ def main(args):
         pred_type = json.load(open(sched_cfg)).get("prediction_type", "epsilon")
         if pred_type not in ("epsilon", "v_prediction"):
             raise ValueError(f"Unknown prediction type {pred_type}")  # :1075
-    hp = StepHyper(prediction_type=pred_type,
+    hp = StepHyper(prediction_type=pred_type, use_grad_scaler=not fp32_mode, init_scale=1.0 if fp32_mode else 65536.0,
                    lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
                    beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
                    max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight, kpl_type="cos" if args.kpl_type == "cos" else "mse",
@@ -214,9 +220,9 @@ def main(args):
                                   "fp16 setting its UNet LoRA parameters are cast to fp16 at :938 and GradScaler.unscale_ rejects them; the saved "
                                   "unet/ is never loaded by inference.py) have no runnable reference behaviour to match: not built")
     # options that change the step's arithmetic and are not built fail loudly instead of silently training something else
-    if args.mixed_precision != "fp16":
-        raise NotImplementedError("only --mixed_precision fp16 is built (the reference driver's setting, run_textboost_db.py:150): fp16 UNet / "
-                                  "teacher, autocast text encoder with fp32 masters, dynamic loss scaling; got %r" % (args.mixed_precision,))
+    if args.mixed_precision == "bf16":
+        raise NotImplementedError("--mixed_precision bf16 is not built: fp16 (the reference driver's setting, run_textboost_db.py:150) and the "
+                                  "default no-AMP fp32 mode (:298-308, the README command) are")
     if getattr(args, "concepts_list", None):
         raise NotImplementedError("--concepts_list (multi-concept training, :661-694) is not built: a run would silently train only "
                                   "--placeholder_token")
@@ -332,8 +338,8 @@ def main(args):
             if prior_feeder is not None:
                 prior_feeder.stream.take(first_step * B)
     if is_main:
-        logger.info("mean_norm %.6f | added tokens %s | world %d | per-GPU batch %d", step.mean_norm, list(added_tokens) +
-                    list(aug_token_dict), world, B)
+        logger.info("mean_norm %.6f | added tokens %s | world %d | per-GPU batch %d | precision %s", step.mean_norm, list(added_tokens) +
+                    list(aug_token_dict), world, B, "fp32 (no mixed precision, no GradScaler)" if fp32_mode else "fp16 mixed precision")
         print("Mean norm:", step.mean_norm)
 
     def run_validation(done):
