@@ -64,7 +64,7 @@ def roofline_leg(step):
         a[3] += byts
     # the roofline object is about ONE kernel symbol: candidates are the single-kernel records (the attention-backward and
     # GroupNorm entry points launch 2-3 kernels per call and are listed in the table only)
-    single = {k: v for k, v in agg.items() if k.startswith(("gemm_kernel<", "conv_halo_kernel<", "gemm8_kernel<")) or k == "attn_fwd_kernel"}
+    single = {k: v for k, v in agg.items() if k.startswith(("gemm_kernel<", "conv_halo_kernel<", "gemm8_kernel<", "gemm_f32_kernel")) or k == "attn_fwd_kernel"}
     dom = max(single.items(), key=lambda kv: kv[1][1])
     name, (n, t, fl, _) = dom
     table = {k: {"launches": v[0], "total_ms": round(v[1] * 1e3, 3), "avg_us": round(v[1] / v[0] * 1e6, 2),
@@ -302,11 +302,17 @@ def main():
     ap.add_argument("--fp8-attn", action="store_true",
                     help="BASELINE.json configs[4]: e4m3 P.V in the forward of the hd = 40 self-attention layers (secondary measurement; "
                          "the metric's numerics are fp16)")
+    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16",
+                    help="fp16 = --mixed_precision fp16, the reference driver's mode and the BASELINE.json metric; fp32 = the reference's default "
+                         "no-AMP mode (README command; exact-fp32 MFMA at 1/16 of the fp16 matrix rate) -- a secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     args.vae = args.vae or args.feeder
+    if args.precision == "fp32":
+        global MFMA_PEAK_TFLOPS
+        MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = the fp32 vector rate (MI355X_MICROARCH.md)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
@@ -341,7 +347,7 @@ def main():
     step, added = build_step(batch=args.batch, latent=args.latent, data_seed=1000 + rank, world_size=world,
                              device=torch.device("cuda", local), unet_geo=models.SD21_UNET if sd21 else models.SD15_UNET,
                              clip_geo=models.SD21_CLIP if sd21 else models.SD15_CLIP, lora_rank=8 if sd21 else 4, with_vae=args.vae,
-                             attn_fp8=args.fp8_attn)
+                             attn_fp8=args.fp8_attn, precision=args.precision)
     step.force_dist = force_dist
     feed = None
     if args.feeder:
@@ -380,7 +386,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         roof, table = roofline_leg(step)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sd21 and not args.vae:  # the CPU baseline is the headline workload's
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sd21 and not args.vae and args.precision == "fp16":  # the CPU baseline is the headline workload's
         try:
             cpu = cpu_baseline_leg()
         except Exception as e:  # the baseline is a reported reference, never fatal to the GPU number
@@ -408,6 +414,9 @@ def main():
         if args.fp8_attn:
             metric = metric[:-1] + ", fp8 P.V in the self-attention forward)"
             workload += "; e4m3 P.V (v_mfma_scale_f32_32x32x64_f8f6f4) in the forward of the 64x64-map self-attention layers (BASELINE.json configs[4])"
+        if args.precision == "fp32":
+            metric = metric[:-1] + ", fp32 no-AMP mode)"
+            workload += "; fp32 (no mixed precision) mode: every weight / activation / gradient fp32, v_mfma_f32_32x32x2_f32, no GradScaler"
         if sd21:  # secondary measurement; algorithmic FLOP taken from the recorded launches of the eager leg
             metric = "train steps/sec (batch=%d, SD2.1 shapes, %d^2 latents, LoRA r=8)" % (args.batch, args.latent)
             workload = ("SURVEY 8(d) config 4: SD2.x UNet (865.9M, Linear proj_in/out, head dim 64) + OpenCLIP-H text encoder (23 layers, "
@@ -419,7 +428,7 @@ def main():
             # global step; sps is the rate of the slowest rank (the timed region ends at a barrier, dt is the max over ranks)
             "metric": metric, "value": round(sps * world, 4), "unit": "steps/s",
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16", "data": "synthetic",
             "config": {"workload": workload,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "images_per_s": round(sps * args.batch * world, 2)},

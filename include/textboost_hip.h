@@ -284,6 +284,10 @@ int tb_pool2x2_sum_f32(const float* du, int64_t ldu, float* dx, int64_t ldx, int
 int tb_add_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t M, int C, tb_stream_t stream);
 int tb_lora_pack_f32(const float* A, const float* Bcat, float* w2_fwd /* fp32 [layers][P*D, 64] */, float* w2_dgrad /* fp32 [layers][K, 64] */,
                      int D, int K, int r, int P, int layers, float scaling, tb_stream_t stream);
+/* UNet cross-attention K/V adapters (--unet_params_to_train crossattn_kv, train_textboost.py:712-721; fp32 mode only, as in the reference):
+ * block-structured K-extension operand of the hoisted K/V GEMM: w2[n, col_base[n] + j] = scaling * B[n, j] (B fp32 [rows, r]) */
+int tb_kv_lora_pack_f32(const float* B, const int32_t* col_base, float* w2 /* fp32 [rows, ncols] */, int64_t rows, int ncols, int r,
+                        float scaling, tb_stream_t stream);
 int tb_mse_loss_f32(const float* pred, const float* target, float* dpred, float* loss_out, const float* loss_scale, int64_t N,
                     float* ws /* >= 256 floats */, tb_stream_t stream);
 

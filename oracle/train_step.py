@@ -121,8 +121,11 @@ class StepConfig:
 class TrainState:
     """Everything train_textboost.py:696-722/:828-854/:1003-1021 builds before the loop."""
 
-    def __init__(self, text_encoder: TextBoostEncoder, teacher: TextBoostEncoder, unet, added_token_ids, cfg: StepConfig):
+    def __init__(self, text_encoder: TextBoostEncoder, teacher: TextBoostEncoder, unet, added_token_ids, cfg: StepConfig, unet_lora=None):
+        """unet_lora: list of the UNet's cross-attention K/V adapter parameters (--unet_params_to_train crossattn_kv, :712-721): the THIRD
+        AdamW group (:838-841: default lr, same weight decay), not covered by the gradient clip (:1128-1133 clips the text encoder only)."""
         self.te, self.teacher, self.unet, self.cfg = text_encoder, teacher, unet, cfg
+        self.unet_lora = list(unet_lora) if unet_lora is not None else []
         self.added = list(added_token_ids)
         self.acp = alphas_cumprod()
         for p in self.te.parameters():
@@ -132,8 +135,11 @@ class TrainState:
             p.requires_grad_(True)
         for p in list(self.unet.parameters()) + list(self.teacher.parameters()):
             p.requires_grad_(False)
+        for p in self.unet_lora:
+            p.requires_grad_(True)
         self.opt_emb = AdamWState(lr=cfg.emb_lr, wd=cfg.wd)
         self.opt_lora = AdamWState(lr=cfg.lr, wd=cfg.wd)
+        self.opt_unet = AdamWState(lr=cfg.lr, wd=cfg.wd)
         with torch.no_grad():  # :1017 -- mean row norm over ALL rows, after token addition
             self.mean_norm = self.te.token_embedding.weight.norm(dim=-1).mean().item()
 
@@ -156,10 +162,10 @@ class TrainState:
             else:
                 kp = F.mse_loss(h, h0, reduction="mean")
             loss = loss + cfg.kpl_weight * kp
-        params = [te.token_embedding.weight] + self.lora
+        params = [te.token_embedding.weight] + self.lora + self.unet_lora
         grads = list(torch.autograd.grad(loss, params, allow_unused=True))         # :1108
         grads = [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
-        g_emb, g_lora = grads[0], grads[1:]
+        g_emb, g_lora, g_unet = grads[0], grads[1:1 + len(self.lora)], grads[1 + len(self.lora):]
         g_emb[: min(self.added)] = 0                                                # :1109-1117
         if cfg.mixing is not None:                                                  # :1119-1126
             for (n, p), g in zip([(n, p) for n, p in te.named_parameters() if "lora_" in n], g_lora):
@@ -172,6 +178,8 @@ class TrainState:
         with torch.no_grad():
             adamw_step([te.token_embedding.weight], [g_emb], self.opt_emb)          # :1134 group 0
             adamw_step(self.lora, g_lora, self.opt_lora)                            #        group 1
+            if self.unet_lora:
+                adamw_step(self.unet_lora, g_unet, self.opt_unet)                   #        group 2 (:838-841), unclipped
             w = te.token_embedding.weight                                           # :1138-1149
             rows = w[self.added]
             vn = rows.norm(dim=-1, keepdim=True)
@@ -179,7 +187,7 @@ class TrainState:
             w[self.added] = (scale / vn) * rows
         return {"loss": loss.item(), "mse": loss_mse.item(), "kpl": float(kp.detach()), "lora_grad_norm": gnorm.item(),
                 "added_embedding_norm": vn.mean().item(), "ehs": ehs.detach(), "pred": pred.detach(),
-                "g_emb_added": g_emb[self.added].clone(), "g_lora": [g.clone() for g in g_lora]}
+                "g_emb_added": g_emb[self.added].clone(), "g_lora": [g.clone() for g in g_lora], "g_unet": [g.clone() for g in g_unet]}
 
 
 def make_teacher(te_before_tokens: TextBoostEncoder) -> TextBoostEncoder:

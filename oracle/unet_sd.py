@@ -106,14 +106,30 @@ class Attention(nn.Module):
         self.to_k = nn.Linear(kv, dim, bias=False)
         self.to_v = nn.Linear(kv, dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
+        self.kv_lora_r = 0
+
+    def add_kv_lora(self, r, alpha=None):
+        """peft LoraConfig(r, lora_alpha=r, init_lora_weights="gaussian", target_modules=["attn2.to_k", "attn2.to_v"]) of
+        /root/reference/train_textboost.py:712-721: y = W x + B (A x) * (alpha / r), A ~ N(0, (1/r)^2), B = 0."""
+        kv, dim = self.to_k.in_features, self.to_k.out_features
+        self.kv_lora_r, self.kv_lora_scaling = r, (alpha if alpha is not None else r) / r
+        self.k_lora_A = nn.Parameter(torch.randn(r, kv) / r)
+        self.k_lora_B = nn.Parameter(torch.zeros(dim, r))
+        self.v_lora_A = nn.Parameter(torch.randn(r, kv) / r)
+        self.v_lora_B = nn.Parameter(torch.zeros(dim, r))
+        return [self.k_lora_A, self.k_lora_B, self.v_lora_A, self.v_lora_B]
 
     def forward(self, x, ctx=None):
         ctx = x if ctx is None else ctx
         B, S, C = x.shape
         hd = C // self.heads
         q = self.to_q(x).view(B, S, self.heads, hd).transpose(1, 2)
-        k = self.to_k(ctx).view(B, -1, self.heads, hd).transpose(1, 2)
-        v = self.to_v(ctx).view(B, -1, self.heads, hd).transpose(1, 2)
+        k, v = self.to_k(ctx), self.to_v(ctx)
+        if self.kv_lora_r:
+            k = k + F.linear(F.linear(ctx, self.k_lora_A), self.k_lora_B) * self.kv_lora_scaling
+            v = v + F.linear(F.linear(ctx, self.v_lora_A), self.v_lora_B) * self.kv_lora_scaling
+        k = k.view(B, -1, self.heads, hd).transpose(1, 2)
+        v = v.view(B, -1, self.heads, hd).transpose(1, 2)
         # AttnProcessor2_0: F.scaled_dot_product_attention, no mask, scale hd^-0.5
         p = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
         o = (p @ v).transpose(1, 2).reshape(B, S, C)
@@ -294,6 +310,15 @@ class UNet2DCondition(nn.Module):
             prev = c
         self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
+
+    def add_crossattn_kv_adapters(self, r, alpha=None):
+        """--unet_params_to_train crossattn_kv (/root/reference/train_textboost.py:712-721): rank-r adapters on every attn2.to_k / to_v.
+        Returns {module path of the attn2: [k_A, k_B, v_A, v_B]} in module order (the third AdamW group, :838-841)."""
+        out = {}
+        for name, m in self.named_modules():
+            if name.endswith(".attn2") and isinstance(m, Attention):
+                out[name] = m.add_kv_lora(r, alpha)
+        return out
 
     def forward(self, sample, timesteps, encoder_hidden_states):
         temb = self.time_embedding(timestep_embedding(timesteps, self.cfg.block_out_channels[0]).to(sample.dtype))

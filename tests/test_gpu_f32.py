@@ -475,3 +475,89 @@ def test_cli_readme_command_runs_in_fp32(tmp_path):
     for k in sd1:
         assert torch.equal(sd1[k], sd2[k]), k
     assert torch.equal(tok1["<dog>"], tok2["<dog>"])
+
+
+def test_unet_crossattn_kv_lora_step_matches_oracle(tmp_path):
+    """--unet_params_to_train crossattn_kv (train_textboost.py:712-721, :838-841): rank-r adapters on all 16 attn2.to_k / to_v,
+    gradients off the hoisted K/V operand, third (unclipped) AdamW group.  Two fp32 optimizer steps against the oracle: adapter gradients,
+    the extra d(ehs) term through the text-encoder gradients, the updated adapters; plus the checkpoint round trip and <out>/unet/."""
+    from oracle import train_step as ts
+    from textboost_amd import checkpoint as ckpt
+    from textboost_amd.trainer import StepHyper, TextBoostStep
+    B, hw, D, r = 2, 16, 64, 4
+    ref_unet, hip_unet = _small_unet_f32(B, hw, D, seed=3)
+    adapters = ref_unet.add_crossattn_kv_adapters(r)
+    hip_unet.enable_kv_lora(r, seed=0)
+    with torch.no_grad():   # non-zero B so that every gradient path is exercised; copy the oracle's adapters into the flat layout
+        for ps in adapters.values():
+            ps[1].normal_(std=0.05)
+            ps[3].normal_(std=0.05)
+    for l, (p, C) in enumerate(hip_unet.xattn):
+        kA, kB, vA, vB = adapters[p]
+        ko = hip_unet.kv_off[p]
+        hip_unet.kv_lora_A[l, :r].copy_(kA.detach()); hip_unet.kv_lora_A[l, r:].copy_(vA.detach())
+        hip_unet.kv_lora_B[ko:ko + C].copy_(kB.detach()); hip_unet.kv_lora_B[ko + C:ko + 2 * C].copy_(vB.detach())
+    student, teacher, hip_te, hip_teacher, added, null = _encoders_f32(B, D, seed=4)
+    unet_params = [q for ps in adapters.values() for q in ps]
+    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig(), unet_lora=unet_params)
+    hp = StepHyper(use_grad_scaler=False, init_scale=1.0)
+    step = TextBoostStep(hip_unet, hip_te, hip_teacher, hp, (B, 4, hw, hw), device=dev)
+    assert step.n_unet == sum(q.numel() for q in unet_params)
+    step.external_noise = True
+    g = torch.Generator().manual_seed(7)
+
+    def flat(ps_list, which):  # oracle tensors -> the executor's layout
+        A = torch.stack([torch.cat([ps_list[4 * l + 0], ps_list[4 * l + 2]]) for l in range(len(hip_unet.xattn))])
+        Bm = torch.cat([torch.cat([ps_list[4 * l + 1], ps_list[4 * l + 3]]) for l in range(len(hip_unet.xattn))])
+        return A if which == "A" else Bm
+
+    for it in range(2):
+        ids, pids = ts.synthetic_ids(B, added, g), ts.synthetic_ids(B, added, g, prior=True)
+        x0, noise = torch.randn(B, 4, hw, hw, generator=g), torch.randn(B, 4, hw, hw, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        out = st_ref.step(x0, noise, t, ids, pids)
+        step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t)
+        step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+        step.step_eager()
+        sc = step.scalars()
+        assert abs(sc["loss_mse"] - out["mse"]) < 1e-5 * abs(out["mse"]) + 1e-7
+        parity(f"step {it} grad UNet lora_A", hip_unet.kv_grad_A, flat(out["g_unet"], "A"), rel=1e-4, maxabs=1e-4)
+        parity(f"step {it} grad UNet lora_B", hip_unet.kv_grad_B, flat(out["g_unet"], "B"), rel=1e-4, maxabs=1e-4)
+        parity(f"step {it} grad added rows (through the adapters' d_ehs term)", step.te.grad_added, out["g_emb_added"], rel=1e-4, maxabs=1e-4)
+        cur = [q.detach() for q in unet_params]
+        assert (hip_unet.kv_lora_A.cpu() - flat(cur, "A")).abs().max().item() < 2e-5      # < lr / 2
+        assert (hip_unet.kv_lora_B.cpu() - flat(cur, "B")).abs().max().item() < 2e-5
+    # checkpoint round trip + the final unet/ directory
+    ckpt.save_trainer_state(step, str(tmp_path / "checkpoint-2"))
+    A0, B0, m0 = hip_unet.kv_lora_A.clone(), hip_unet.kv_lora_B.clone(), step.m_unet.clone()
+    hip_unet.kv_lora_A.zero_(); hip_unet.kv_lora_B.zero_(); step.m_unet.zero_()
+    ckpt.load_trainer_state(step, str(tmp_path / "checkpoint-2"))
+    assert torch.equal(hip_unet.kv_lora_A, A0) and torch.equal(hip_unet.kv_lora_B, B0) and torch.equal(step.m_unet, m0)
+    ckpt.save_unet_adapters(hip_unet, str(tmp_path / "unet"), "base")
+    from safetensors.torch import load_file
+    sd = load_file(str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    assert len(sd) == 64 and sd["mid_block.attentions.0.transformer_blocks.0.attn2.to_v.lora_A.default.weight"].shape == (r, D)
+
+
+def test_cli_unet_crossattn_kv(tmp_path):
+    """the CLI with --unet_params_to_train crossattn_kv (fp32 mode): trains, checkpoints (model_1.safetensors), writes <out>/unet/; the same flag
+    under --mixed_precision fp16 has no runnable reference behaviour (:937 casts the adapters to fp16, GradScaler rejects them) and must raise."""
+    import os
+    import sys
+    from safetensors.torch import load_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+    out = str(tmp_path / "o")
+    base = ["--pretrained_model_name_or_path", "/nonexistent/sd15", "--output_dir", out, "--train_batch_size", "1", "--resolution", "128",
+            "--max_train_steps", "3", "--checkpointing_steps", "2", "--placeholder_token", "<dog>", "--lora_rank", "4", "--seed", "1",
+            "--unet_params_to_train", "crossattn_kv"]
+    T.main(T.parse_args(base))
+    sd = load_file(os.path.join(out, "unet", "diffusion_pytorch_model.safetensors"))
+    assert len(sd) == 64
+    assert any(v.abs().max() > 0 for k, v in sd.items() if "lora_B" in k), "the UNet adapters did not train"
+    assert os.path.exists(os.path.join(out, "checkpoint-2", "model_1.safetensors"))
+    with pytest.raises(NotImplementedError):
+        T.main(T.parse_args(base + ["--mixed_precision", "fp16"]))
+    with pytest.raises(NotImplementedError):
+        T.main(T.parse_args(base[:-1] + ["attn"]))

@@ -130,6 +130,7 @@ _SIGS = {
     "tb_pool2x2_sum_f32": ([_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP], C.c_int),
     "tb_add_f32": ([_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I, _VP], C.c_int),
     "tb_lora_pack_f32": ([_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _F, _VP], C.c_int),
+    "tb_kv_lora_pack_f32": ([_VP, _VP, _VP, _I64, _I, _I, _F, _VP], C.c_int),
     "tb_mse_loss_f32": ([_VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP], C.c_int),
     "tb_resample_ksize": ([_I, _I, _I], C.c_int),
     "tb_resample_coeffs": ([_I, _I, _I, _VP, _VP], C.c_int),

@@ -43,6 +43,40 @@ def load_lora_state_dict(te, sd):
             te.lora_B[i, p * D:(p + 1) * D].copy_(sd[base + ".lora_B.weight"])
 
 
+def unet_lora_state_dict(unet) -> Dict[str, torch.Tensor]:
+    """UNet cross-attention K/V adapters (--unet_params_to_train crossattn_kv, :712-721) under the parameter names diffusers' `unet.add_adapter`
+    gives them (peft-injected modules, adapter "default"): `<attn2 path>.to_{k,v}.lora_{A,B}.default.weight`."""
+    sd = {}
+    r = unet.kv_r
+    for l, (p, C) in enumerate(unet.xattn):
+        ko = unet.kv_off[p]
+        for j, name in enumerate(("to_k", "to_v")):
+            sd[f"{p}.{name}.lora_A.default.weight"] = unet.kv_lora_A[l, j * r:(j + 1) * r].detach().float().cpu().contiguous()
+            sd[f"{p}.{name}.lora_B.default.weight"] = unet.kv_lora_B[ko + j * C:ko + (j + 1) * C].detach().float().cpu().contiguous()
+    return sd
+
+
+def load_unet_lora_state_dict(unet, sd):
+    r = unet.kv_r
+    for l, (p, C) in enumerate(unet.xattn):
+        ko = unet.kv_off[p]
+        for j, name in enumerate(("to_k", "to_v")):
+            unet.kv_lora_A[l, j * r:(j + 1) * r].copy_(sd[f"{p}.{name}.lora_A.default.weight"])
+            unet.kv_lora_B[ko + j * C:ko + (j + 1) * C].copy_(sd[f"{p}.{name}.lora_B.default.weight"])
+
+
+def save_unet_adapters(unet, out_dir: str, base_model_name_or_path: str):
+    """<out>/unet/ (:1237-1239).  The reference's `unet.save_pretrained` writes the WHOLE fp32 UNet (3.4 GB: the frozen base weights under
+    `.base_layer.` names plus the adapters); no reader of the output layout loads it (inference.py / eval_dreambooth.py never open unet/).
+    Written here: the adapter tensors under exactly those parameter names, plus a note naming the base model whose weights are unchanged."""
+    os.makedirs(out_dir, exist_ok=True)
+    save_file(unet_lora_state_dict(unet), os.path.join(out_dir, "diffusion_pytorch_model.safetensors"), metadata={"format": "pt"})
+    with open(os.path.join(out_dir, "adapter_note.json"), "w") as f:
+        json.dump({"contains": "cross-attention to_k / to_v LoRA adapters only", "r": unet.kv_r, "lora_alpha": unet.kv_r,
+                   "target_modules": ["attn2.to_k", "attn2.to_v"], "base_model_name_or_path": base_model_name_or_path,
+                   "base_weights": "unchanged (frozen): load them from base_model_name_or_path/unet"}, f, indent=2, sort_keys=True)
+
+
 def adapter_config(rank: int, base_model_name_or_path: str) -> dict:
     """peft 0.13.2 LoraConfig JSON for LoraConfig(r, lora_alpha=r, init_lora_weights="gaussian", target q/k/v) (:702-709)."""
     return {"alpha_pattern": {}, "auto_mapping": None, "base_model_name_or_path": base_model_name_or_path, "bias": "none",
@@ -88,8 +122,12 @@ def save_trainer_state(step_obj, ckpt_dir: str):
     # every optimizer step so far, which depends on the lr schedule and on skipped steps -- saving them makes resume bit-exact
     model["text_model.embeddings.token_embedding.weight"] = te.token_table.detach().float().cpu().contiguous()
     save_file(model, os.path.join(ckpt_dir, "model.safetensors"))
+    extra = {}
+    if getattr(step_obj, "n_unet", 0):  # accelerate.prepare(text_encoder, unet, ...) (:924-926) saves the second model as model_1.safetensors
+        save_file(unet_lora_state_dict(step_obj.unet), os.path.join(ckpt_dir, "model_1.safetensors"))
+        extra = {"m_unet": step_obj.m_unet.cpu(), "v_unet": step_obj.v_unet.cpu()}
     torch.save({"m_lora": step_obj.m_lora.cpu(), "v_lora": step_obj.v_lora.cpu(), "m_emb": step_obj.m_emb.cpu(),
-                "v_emb": step_obj.v_emb.cpu(), "state": step_obj.state.cpu(),
+                "v_emb": step_obj.v_emb.cpu(), "state": step_obj.state.cpu(), **extra,
                 "orig_rows_decay_steps": float(step_obj.state[2].item()),
                 "lr_table": step_obj.lr_table.cpu() if getattr(step_obj, "lr_table", None) is not None else None},
                os.path.join(ckpt_dir, "optimizer.bin"))
@@ -111,6 +149,10 @@ def load_trainer_state(step_obj, ckpt_dir: str):
     opt = torch.load(os.path.join(ckpt_dir, "optimizer.bin"))
     for k in ("m_lora", "v_lora", "m_emb", "v_emb", "state"):
         getattr(step_obj, k).copy_(opt[k])
+    if getattr(step_obj, "n_unet", 0):
+        load_unet_lora_state_dict(step_obj.unet, load_file(os.path.join(ckpt_dir, "model_1.safetensors")))
+        step_obj.m_unet.copy_(opt["m_unet"])
+        step_obj.v_unet.copy_(opt["v_unet"])
     full = model.get("text_model.embeddings.token_embedding.weight")
     if full is not None:
         te.token_table.copy_(full)

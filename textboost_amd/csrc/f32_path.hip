@@ -511,9 +511,30 @@ __global__ void mse_f32_final_kernel(const float* __restrict__ partial, int n, f
   }
 }
 
+// K-extension operand of the hoisted cross-attention K/V GEMM with rank-r adapters on every to_k / to_v (--unet_params_to_train crossattn_kv,
+// train_textboost.py:712-721): W2[n, col_base[n] + j] = scaling * B[n, j], zero elsewhere (row n = output feature of the concatenated
+// projections, col_base[n] = first column of that row's adapter in the concatenated down projections t = ehs A_all^T)
+__global__ void kv_lora_pack_f32_kernel(const float* __restrict__ B, const int* __restrict__ col_base, float* __restrict__ W2, int64_t rows,
+                                        int ncols, int r, float scaling) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * ncols) return;
+  const int64_t n = idx / ncols;
+  const int j = (int)(idx - n * ncols) - col_base[n];
+  W2[idx] = (j >= 0 && j < r) ? scaling * B[n * r + j] : 0.f;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
+extern "C" int tb_kv_lora_pack_f32(const float* B, const int32_t* col_base, float* w2, int64_t rows, int ncols, int r, float scaling,
+                                   tb_stream_t stream) {
+  (void)hipGetLastError();
+  if (!B || !col_base || !w2 || rows <= 0 || ncols <= 0 || r <= 0) return TB_EINVAL;
+  hipLaunchKernelGGL(kv_lora_pack_f32_kernel, dim3((unsigned)((rows * ncols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, col_base, w2, rows,
+                     ncols, r, scaling);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
 extern "C" int tb_gemm_f32(const tb_gemm_desc* dp, tb_stream_t stream) {
   (void)hipGetLastError();
   if (!dp) return TB_EINVAL;

@@ -444,6 +444,11 @@ def lora_pack(A, Bcat, w2_fwd, w2_dgrad, D, K, r, P, scaling=1.0, layers=1):
             "tb_lora_pack")
 
 
+def kv_lora_pack(B, col_base, w2, r, scaling=1.0):
+    L.check(L.lib().tb_kv_lora_pack_f32(L.ptr(B), L.ptr(col_base), L.ptr(w2), w2.shape[0], w2.shape[1], r, scaling, L.stream()),
+            "tb_kv_lora_pack_f32")
+
+
 _lora_ws = {}
 
 

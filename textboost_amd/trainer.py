@@ -137,14 +137,29 @@ class TextBoostStep:
         self.acp = alphas_cumprod(hyper.num_train_timesteps, device=device)
         # ---- flat trainable-gradient buffer: [grad_A | grad_B | grad_added]  (one all-reduce, one sumsq each)
         nA, nB, nE = te.lora_A.numel(), te.lora_B.numel(), te.n_added * D
-        self.flat_grad = torch.zeros(nA + nB + nE, device=device)
+        # --unet_params_to_train crossattn_kv (:712-721, HipUNet.enable_kv_lora): the UNet's K/V adapters are the optimizer's THIRD group
+        # (:838-841: default lr, same decay; the clip at :1128-1133 covers the text encoder only); their gradients ride in the same flat buffer
+        nUA = unet.kv_lora_A.numel() if getattr(unet, "kv_r", 0) else 0
+        nUB = unet.kv_lora_B.numel() if nUA else 0
+        self.n_unet = nUA + nUB
+        self.flat_grad = torch.zeros(nA + nB + nE + self.n_unet, device=device)
         self.flat_lora = torch.cat([te.lora_A.reshape(-1), te.lora_B.reshape(-1)])  # fp32 masters, flat
         te.lora_A = self.flat_lora[:nA].view_as(te.lora_A)
         te.lora_B = self.flat_lora[nA:].view_as(te.lora_B)
         te.grad_A = self.flat_grad[:nA].view_as(te.lora_A)
         te.grad_B = self.flat_grad[nA:nA + nB].view_as(te.lora_B)
-        te.grad_added = self.flat_grad[nA + nB:].view(te.n_added, D)
+        te.grad_added = self.flat_grad[nA + nB:nA + nB + nE].view(te.n_added, D)
         self.n_lora = nA + nB
+        self.n_emb = nE
+        if self.n_unet:
+            o = nA + nB + nE
+            self.flat_unet = torch.cat([unet.kv_lora_A.reshape(-1), unet.kv_lora_B.reshape(-1)])
+            unet.kv_lora_A = self.flat_unet[:nUA].view_as(unet.kv_lora_A)
+            unet.kv_lora_B = self.flat_unet[nUA:].view_as(unet.kv_lora_B)
+            unet.kv_grad_A = self.flat_grad[o:o + nUA].view_as(unet.kv_lora_A)
+            unet.kv_grad_B = self.flat_grad[o + nUA:].view_as(unet.kv_lora_B)
+            self.m_unet = torch.zeros(self.n_unet, device=device)
+            self.v_unet = torch.zeros(self.n_unet, device=device)
         self.m_lora = torch.zeros(self.n_lora, device=device)
         self.v_lora = torch.zeros(self.n_lora, device=device)
         self.m_emb = torch.zeros(nE, device=device)
@@ -223,6 +238,7 @@ class TextBoostStep:
             self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))                  # :1027-1037
         ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
         te.pack_lora()
+        self.unet.pack_kv_lora()
         if self.merge_teacher:
             nb = self.ids_all.shape[0]
             out = te.forward(self.ids_all, slot=0, extra_ids=self.prior_ids, extra_table=self.teacher_table32)
@@ -243,13 +259,13 @@ class TextBoostStep:
 
     def _phase_unet_backward(self):
         hp, st = self.hp, self.state
+        self.flat_grad.zero_()  # every trainable gradient is accumulated into this buffer (UNet adapters here, the encoder's below)
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
         ops.mse_loss(self.pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
         self.unet.backward(self.dpred, d_ehs_out=self.d_ehs)                       # :1108 (UNet part, dgrad only)
 
     def _phase_encoder_backward(self):
         hp, te = self.hp, self.te
-        self.flat_grad.zero_()
         te.backward(self.d_all, slot=0)
         if hp.mixing is not None:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
             gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
@@ -298,7 +314,7 @@ class TextBoostStep:
         D = te.geo.hidden_size
         ops.sumsq(self.flat_grad[: self.n_lora], st[L.ST_SUMSQ_LORA:])
         if te.n_added:
-            ops.sumsq(self.flat_grad[self.n_lora:], st[L.ST_SUMSQ_EMB:])
+            ops.sumsq(self.flat_grad[self.n_lora:self.n_lora + self.n_emb], st[L.ST_SUMSQ_EMB:])
         if self.lr_table is not None:
             ops.lr_from_table(st, self.lr_table)
         ops.scaler_update(st, hp.max_grad_norm, hp.beta1, hp.beta2, 2.0, 0.5, hp.growth_interval, hp.use_grad_scaler,
@@ -311,9 +327,12 @@ class TextBoostStep:
         ops.weight_decay(orig, 1.0 - hp.emb_lr * hp.wd, st)
         if te.n_added:
             added = te.token_table[te.first_added:]
-            ops.adamw(added.view(-1), self.flat_grad[self.n_lora:], self.m_emb, self.v_emb, hp.emb_lr, st, L.ST_COEF_EMB, hp.beta1,
-                      hp.beta2, hp.eps, hp.wd)
+            ops.adamw(added.view(-1), self.flat_grad[self.n_lora:self.n_lora + self.n_emb], self.m_emb, self.v_emb, hp.emb_lr, st,
+                      L.ST_COEF_EMB, hp.beta1, hp.beta2, hp.eps, hp.wd)
             ops.renorm_rows(added, self.mean_norm, self.added_norms)                # :1138-1149
+        if self.n_unet:  # group 2 (:838-841): the unclipped unscale coefficient, the default learning rate
+            ops.adamw(self.flat_unet, self.flat_grad[self.n_lora + self.n_emb:], self.m_unet, self.v_unet, hp.lr, st, L.ST_COEF_EMB,
+                      hp.beta1, hp.beta2, hp.eps, hp.wd)
 
     def step_eager(self):
         self.draw()

@@ -121,6 +121,37 @@ class HipUNet:
         dtype = self.dtype if dtype is None else dtype
         return self.buf(f"scr.{tag}.{rows}x{cols}.{dtype}", rows, cols, dtype)
 
+    # ------------------------------------------------------------------ cross-attention K/V adapters
+    def enable_kv_lora(self, r: int, alpha: Optional[float] = None, seed: Optional[int] = None):
+        """--unet_params_to_train crossattn_kv (train_textboost.py:712-721): peft LoraConfig(r, lora_alpha=r, "gaussian",
+        target_modules=["attn2.to_k", "attn2.to_v"]) on the otherwise frozen UNet; its parameters are the optimizer's third group
+        (:838-841).  fp32 mode only -- under --mixed_precision fp16 the reference casts these parameters to fp16 (:937) and GradScaler
+        refuses them.  Layout: kv_lora_A [n_layers, 2r, Dc] (k rows, then v rows), kv_lora_B [kv_total, r] (row n = output feature n of the
+        concatenated K/V projections, i.e. aligned with the columns of the hoisted kv_all GEMM)."""
+        assert self.dtype == torch.float32, "UNet adapters need the fp32 (no-AMP) mode"
+        dev, Dc, n = self.dev, self.geo.cross_attention_dim, len(self.xattn)
+        g = torch.Generator(device="cpu")
+        if seed is not None:
+            g.manual_seed(seed)
+        self.kv_r = r
+        self.kv_scaling = (alpha if alpha is not None else r) / r
+        self.kv_lora_A = (torch.randn(n, 2 * r, Dc, generator=g) / r).to(dev)
+        self.kv_lora_B = torch.zeros(self.kv_total, r, device=dev)
+        self.kv_grad_A = torch.zeros_like(self.kv_lora_A)
+        self.kv_grad_B = torch.zeros_like(self.kv_lora_B)
+        cb = torch.empty(self.kv_total, dtype=torch.int32)
+        for l, (p, C) in enumerate(self.xattn):
+            ko = self.kv_off[p]
+            cb[ko:ko + C] = l * 2 * r
+            cb[ko + C:ko + 2 * C] = l * 2 * r + r
+        self.kv_col_base = cb.to(dev)
+        self.kv_w2 = torch.zeros(self.kv_total, n * 2 * r, device=dev)
+
+    def pack_kv_lora(self):
+        """refresh the K-extension operand from the adapter masters (once per optimizer step, like HipTextEncoder.pack_lora)"""
+        if getattr(self, "kv_r", 0):
+            ops.kv_lora_pack(self.kv_lora_B, self.kv_col_base, self.kv_w2, self.kv_r, self.kv_scaling)
+
     # ------------------------------------------------------------------ weights
     def _pack(self, sd):
         dev, geo, wdt = self.dev, self.geo, self.dtype
@@ -403,7 +434,13 @@ class HipUNet:
         # ---- hoisted cross-attention K/V projections of the text states
         self.kv_all = self.buf("kv_all", B * self.T, self.kv_total)
         self.dkv_all = self.buf("dkv_all", B * self.T, self.kv_total)
-        ops.gemm(ehs16, P["kv_all.w"], self.kv_all)
+        if getattr(self, "kv_r", 0):  # adapters: kv = ehs W^T + (ehs A_all^T) W2^T, W2 = block-structured scaling * B (pack_kv_lora)
+            n2r = self.kv_w2.shape[1]
+            self.kv_t = self.buf("kv_t", B * self.T, n2r)
+            ops.gemm(ehs16, self.kv_lora_A.view(n2r, -1), self.kv_t)
+            ops.gemm(ehs16, P["kv_all.w"], self.kv_all, A2=self.kv_t, W2=self.kv_w2)
+        else:
+            ops.gemm(ehs16, P["kv_all.w"], self.kv_all)
         # ---- concat buffers of the up path (hidden part first, skip part second)
         skip_level = [0]
         for i in range(nl):
@@ -586,4 +623,22 @@ class HipUNet:
         if d_ehs_out is None:
             d_ehs_out = self.buf("d_ehs", B * self.T, geo.cross_attention_dim, torch.float32)
         ops.gemm(self.dkv_all, P["kv_all.wd"], d_ehs_out)
+        if getattr(self, "kv_r", 0):
+            # adapter gradients off the hoisted operand (ACCUMULATED into kv_grad_A / kv_grad_B: the trainer zeroes the flat gradient buffer):
+            #   dt = dkv W2                       dB[rows of (layer, proj)] += scaling * dkv[:, rows]^T t[:, cols]
+            #   dA_all += dt^T ehs                d_ehs += dt A_all
+            M, r, n2r, Dc = B * self.T, self.kv_r, self.kv_w2.shape[1], geo.cross_attention_dim
+            ehs = S["ehs16"]
+            dt = self.buf("kv_dt", M, n2r)
+            ops.gemm_f32_t(self.dkv_all, self.kv_w2, dt, M, n2r, self.kv_total, w_trans=True)
+            for l, (p, C) in enumerate(self.xattn):
+                ko = self.kv_off[p]
+                for proj in range(2):
+                    rows = slice(ko + proj * C, ko + (proj + 1) * C)
+                    cols = slice(l * 2 * r + proj * r, l * 2 * r + (proj + 1) * r)
+                    ops.gemm_f32_t(self.dkv_all[:, rows], self.kv_t[:, cols], self.kv_grad_B[rows], C, r, M, a_trans=True, w_trans=True,
+                                   R=self.kv_grad_B[rows], alpha=self.kv_scaling)
+            gA = self.kv_grad_A.view(n2r, Dc)
+            ops.gemm_f32_t(dt, ehs, gA, n2r, Dc, M, a_trans=True, w_trans=True, R=gA)
+            ops.gemm_f32_t(dt, self.kv_lora_A.view(n2r, Dc), d_ehs_out, M, Dc, n2r, w_trans=True, R=d_ehs_out)
         return d_ehs_out

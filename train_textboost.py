@@ -215,10 +215,20 @@ def main(args):
                    beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
                    max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight, kpl_type="cos" if args.kpl_type == "cos" else "mse",
                    mixing=(args.augment_ops if args.augment_ops == "object" else "style") if args.mixing else None)
-    if args.with_image_prior or args.unet_params_to_train != "none":
-        raise NotImplementedError("--with_image_prior (broken in the reference, SURVEY 0.6) and --unet_params_to_train (under the reference's "
-                                  "fp16 setting its UNet LoRA parameters are cast to fp16 at :938 and GradScaler.unscale_ rejects them; the saved "
-                                  "unet/ is never loaded by inference.py) have no runnable reference behaviour to match: not built")
+    if args.with_image_prior:
+        raise NotImplementedError("--with_image_prior is broken in the reference itself (generate_prior_images is called with 6 of its 7 "
+                                  "arguments, SURVEY 0.6): no runnable reference behaviour to match")
+    if args.unet_params_to_train not in ("none", "crossattn_kv"):
+        raise NotImplementedError(f"--unet_params_to_train {args.unet_params_to_train}: the reference adds adapters only for 'crossattn_kv' (:712); "
+                                  "every other value trains nothing in the UNet and only writes an unchanged copy of it to <output_dir>/unet")
+    if args.unet_params_to_train == "crossattn_kv":
+        if not fp32_mode:
+            raise NotImplementedError("--unet_params_to_train crossattn_kv needs the fp32 (no --mixed_precision) mode: under fp16 the reference "
+                                      "casts the UNet's freshly added LoRA parameters to fp16 (:937) and GradScaler.unscale_ rejects them")
+        if args.lora_rank <= 0:
+            raise ValueError("--unet_params_to_train crossattn_kv is only reached with --lora_rank > 0 (:700-721)")
+        unet.enable_kv_lora(args.lora_rank, seed=None if args.seed is None else args.seed + 1)
+        logger.info("Added LoRA to U-Net")  # :721
     # options that change the step's arithmetic and are not built fail loudly instead of silently training something else
     if args.mixed_precision == "bf16":
         raise NotImplementedError("--mixed_precision bf16 is not built: fp16 (the reference driver's setting, run_textboost_db.py:150) and the "
@@ -403,6 +413,8 @@ def main(args):
         import torch.distributed as dist
         dist.barrier()  # accelerator.wait_for_everyone() :1235
     if is_main:  # :1236-1266
+        if args.unet_params_to_train != "none":  # :1237-1239
+            ckpt.save_unet_adapters(unet, os.path.join(args.output_dir, "unet"), mdir)
         if args.lora_rank > 0:
             ckpt.save_text_encoder_adapter(te, os.path.join(args.output_dir, "text_encoder"), mdir)
         ckpt.save_token_embeddings(te, args.output_dir, added_tokens, aug_token_dict if args.augment_inversion else None)
