@@ -77,7 +77,10 @@ def adamw_step(params, grads, st: AdamWState):
 
 
 def clip_grad_norm(grads, max_norm):
-    """torch.nn.utils.clip_grad_norm_ (L2): coef = min(1, max_norm / (total + 1e-6))."""
+    """torch.nn.utils.clip_grad_norm_ (L2): coef = min(1, max_norm / (total + 1e-6)).  No gradients (--lora_rank 0: the encoder has no
+    trainable parameter): norm 0, like torch."""
+    if len(grads) == 0:
+        return torch.zeros(())
     total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     for g in grads:

@@ -363,7 +363,7 @@ def _encoders_f32(B, D, r=4, n_added=3, seed=0, act="quick_gelu"):
     hip = HipTextEncoder(geo, sd, B, mode="fp32", lora_rank=r, n_slots=2, device=dev, seed=0)
     hip.set_null_embedding(null)
     hip.add_tokens([100, 200, 300][:n_added])
-    for i, layer in enumerate(student.layers):
+    for i, layer in enumerate(student.layers if r else []):
         hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
         hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
     hip_teacher = HipTextEncoder(geo, sd, B, mode="fp32", lora_rank=0, device=dev)
@@ -561,3 +561,68 @@ def test_cli_unet_crossattn_kv(tmp_path):
         T.main(T.parse_args(base + ["--mixed_precision", "fp16"]))
     with pytest.raises(NotImplementedError):
         T.main(T.parse_args(base[:-1] + ["attn"]))
+
+
+def test_gradient_accumulation_equals_one_step_on_the_concatenated_batch():
+    """--gradient_accumulation_steps 2 (train_textboost.py:1039: accelerate divides each micro loss by G, the optimizer / schedule / step
+    counter move on the G-th batch only): two micro batches of B must give the update of ONE step on the 2B concatenation (both losses
+    are batch means).  fp32 mode, eager and as the two captured graphs."""
+    from oracle import train_step as ts
+    from textboost_amd.trainer import StepHyper, TextBoostStep
+    hw, D = 16, 64
+
+    def make(B, accum):
+        _, hip_unet = _small_unet_f32(B, hw, D, seed=3)
+        _, _, hip_te, hip_teacher, added, _ = _encoders_f32(B, D, seed=4)
+        st = TextBoostStep(hip_unet, hip_te, hip_teacher, StepHyper(use_grad_scaler=False, init_scale=1.0, grad_accum=accum), (B, 4, hw, hw),
+                           device=dev)
+        st.external_noise = True
+        return st, added
+
+    g = torch.Generator().manual_seed(8)
+    big, added = make(4, 1)
+    ids, pids = ts.synthetic_ids(4, added, g), ts.synthetic_ids(4, added, g, prior=True)
+    x0, noise, t = torch.randn(4, 4, hw, hw, generator=g), torch.randn(4, 4, hw, hw, generator=g), torch.randint(0, 1000, (4,), generator=g)
+    big.x0.copy_(x0); big.noise.copy_(noise); big.timesteps.copy_(t); big.input_ids.copy_(ids); big.prior_ids.copy_(pids)
+    assert big.step_eager() is True
+    for graphs in (False, True):
+        acc, _ = make(2, 2)
+        if graphs:
+            acc.capture(warmup=0)
+            assert acc.graph_mode == "micro+tail"
+        synced = []
+        for h in range(2):
+            sl = slice(2 * h, 2 * h + 2)
+            acc.x0.copy_(x0[sl]); acc.noise.copy_(noise[sl]); acc.timesteps.copy_(t[sl]); acc.input_ids.copy_(ids[sl]); acc.prior_ids.copy_(pids[sl])
+            synced.append(acc.replay() if graphs else acc.step_eager())
+        assert synced == [False, True]
+        assert acc.scalars()["opt_steps"] == 1.0
+        parity("accumulated gradient / G", acc.flat_grad / 2, big.flat_grad, rel=1e-5, maxabs=1e-5)
+        assert (acc.te.lora_A - big.te.lora_A).abs().max().item() < 2e-5 and (acc.te.lora_B - big.te.lora_B).abs().max().item() < 2e-5
+        parity("updated added rows", acc.te.token_table[acc.te.first_added:], big.te.token_table[big.te.first_added:], rel=1e-5, maxabs=1e-4)
+
+
+def test_lora_rank_zero_trains_the_added_rows_only():
+    """--lora_rank 0 (:700: no adapter is injected; optimizer group 1 is empty): one fp32 step against the oracle without adapters."""
+    from oracle import train_step as ts
+    from textboost_amd.trainer import StepHyper, TextBoostStep
+    B, hw, D = 2, 16, 64
+    ref_unet, hip_unet = _small_unet_f32(B, hw, D, seed=3)
+    student, teacher, hip_te, hip_teacher, added, null = _encoders_f32(B, D, r=0, seed=4)
+    st_ref = ts.TrainState(student, teacher, ref_unet, added, ts.StepConfig())
+    step = TextBoostStep(hip_unet, hip_te, hip_teacher, StepHyper(use_grad_scaler=False, init_scale=1.0), (B, 4, hw, hw), device=dev)
+    step.external_noise = True
+    assert step.n_lora == 0
+    g = torch.Generator().manual_seed(9)
+    ids, pids = ts.synthetic_ids(B, added, g), ts.synthetic_ids(B, added, g, prior=True)
+    x0, noise, t = torch.randn(B, 4, hw, hw, generator=g), torch.randn(B, 4, hw, hw, generator=g), torch.randint(0, 1000, (B,), generator=g)
+    out = st_ref.step(x0, noise, t, ids, pids)
+    step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t); step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+    step.step_eager()
+    sc = step.scalars()
+    assert sc["opt_steps"] == 1.0 and abs(sc["loss_mse"] - out["mse"]) < 1e-5 * abs(out["mse"]) + 1e-7
+    assert abs(sc["loss_kpl"] - out["kpl"]) < 1e-4 * abs(out["kpl"]) + 1e-6   # student == teacher up to the added rows
+    parity("r=0 grad added rows", step.te.grad_added, out["g_emb_added"], rel=1e-4, maxabs=1e-4)
+    w, wr = step.te.token_table.cpu(), student.token_embedding.weight.detach()
+    torch.testing.assert_close(w[:49408], wr[:49408], rtol=1e-6, atol=1e-7)
+    parity("r=0 updated added rows", w[added], wr[added], rel=2e-4, maxabs=5e-4)

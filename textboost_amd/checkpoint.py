@@ -26,6 +26,8 @@ def lora_state_dict(te) -> Dict[str, torch.Tensor]:
     """flat [L,3r,D] / [L,3D,r] masters -> PEFT key layout (adapter name stripped on save, like peft does)."""
     sd = {}
     D, r = te.geo.hidden_size, te.r
+    if not r:  # --lora_rank 0: no adapter exists
+        return sd
     for i in range(te.geo.num_layers):
         for p, name in enumerate(("q_proj", "k_proj", "v_proj")):
             base = f"base_model.model.text_model.encoder.layers.{i}.self_attn.{name}"
@@ -36,6 +38,8 @@ def lora_state_dict(te) -> Dict[str, torch.Tensor]:
 
 def load_lora_state_dict(te, sd):
     D, r = te.geo.hidden_size, te.r
+    if not r:
+        return
     for i in range(te.geo.num_layers):
         for p, name in enumerate(("q_proj", "k_proj", "v_proj")):
             base = f"base_model.model.text_model.encoder.layers.{i}.self_attn.{name}"

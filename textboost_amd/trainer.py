@@ -41,6 +41,7 @@ class StepHyper:
     init_scale: float = 65536.0
     growth_interval: int = 2000
     num_train_timesteps: int = 1000
+    grad_accum: int = 1           # --gradient_accumulation_steps (:1039 accelerator.accumulate; single process only, :573-577)
 
 
 def alphas_cumprod(T=1000, beta_start=0.00085, beta_end=0.012, device="cuda"):
@@ -136,18 +137,22 @@ class TextBoostStep:
         D = te.geo.hidden_size
         self.acp = alphas_cumprod(hyper.num_train_timesteps, device=device)
         # ---- flat trainable-gradient buffer: [grad_A | grad_B | grad_added]  (one all-reduce, one sumsq each)
-        nA, nB, nE = te.lora_A.numel(), te.lora_B.numel(), te.n_added * D
+        has_lora = te.r > 0  # --lora_rank 0: only the added token rows train (:700: no adapter is injected, optimizer group 1 is empty)
+        nA, nB, nE = (te.lora_A.numel(), te.lora_B.numel(), te.n_added * D) if has_lora else (0, 0, te.n_added * D)
         # --unet_params_to_train crossattn_kv (:712-721, HipUNet.enable_kv_lora): the UNet's K/V adapters are the optimizer's THIRD group
         # (:838-841: default lr, same decay; the clip at :1128-1133 covers the text encoder only); their gradients ride in the same flat buffer
         nUA = unet.kv_lora_A.numel() if getattr(unet, "kv_r", 0) else 0
         nUB = unet.kv_lora_B.numel() if nUA else 0
         self.n_unet = nUA + nUB
         self.flat_grad = torch.zeros(nA + nB + nE + self.n_unet, device=device)
-        self.flat_lora = torch.cat([te.lora_A.reshape(-1), te.lora_B.reshape(-1)])  # fp32 masters, flat
-        te.lora_A = self.flat_lora[:nA].view_as(te.lora_A)
-        te.lora_B = self.flat_lora[nA:].view_as(te.lora_B)
-        te.grad_A = self.flat_grad[:nA].view_as(te.lora_A)
-        te.grad_B = self.flat_grad[nA:nA + nB].view_as(te.lora_B)
+        if has_lora:
+            self.flat_lora = torch.cat([te.lora_A.reshape(-1), te.lora_B.reshape(-1)])  # fp32 masters, flat
+            te.lora_A = self.flat_lora[:nA].view_as(te.lora_A)
+            te.lora_B = self.flat_lora[nA:].view_as(te.lora_B)
+            te.grad_A = self.flat_grad[:nA].view_as(te.lora_A)
+            te.grad_B = self.flat_grad[nA:nA + nB].view_as(te.lora_B)
+        else:
+            self.flat_lora = torch.zeros(0, device=device)
         te.grad_added = self.flat_grad[nA + nB:nA + nB + nE].view(te.n_added, D)
         self.n_lora = nA + nB
         self.n_emb = nE
@@ -199,6 +204,9 @@ class TextBoostStep:
         self.d_prior = self.d_all[B * te.T:]
         self.kpl_partial = torch.empty(B * te.T, device=device)
         self.added_norms = torch.empty(max(te.n_added, 1), device=device)
+        self.accum = max(1, int(hyper.grad_accum))
+        assert self.accum == 1 or world_size == 1, "Gradient accumulation is not supported when training with multiple processes."  # :573-577
+        self._micro = 0          # position inside the accumulation cycle
         self.graph = None
         self.graph_mode = "eager"
         self.external_noise = False
@@ -259,7 +267,8 @@ class TextBoostStep:
 
     def _phase_unet_backward(self):
         hp, st = self.hp, self.state
-        self.flat_grad.zero_()  # every trainable gradient is accumulated into this buffer (UNet adapters here, the encoder's below)
+        if self.accum == 1:  # (accumulating: the buffer is zeroed by `replay` / `step_eager` at the start of a cycle instead)
+            self.flat_grad.zero_()  # every trainable gradient is accumulated into this buffer (UNet adapters here, the encoder's below)
         target = self.noise if hp.prediction_type == "epsilon" else self.velocity  # :1070-1075
         ops.mse_loss(self.pred, target, self.dpred, st[L.ST_LOSS_MSE:], st[L.ST_LOSS_SCALE:])  # :1085-1090
         self.unet.backward(self.dpred, d_ehs_out=self.d_ehs)                       # :1108 (UNet part, dgrad only)
@@ -267,7 +276,7 @@ class TextBoostStep:
     def _phase_encoder_backward(self):
         hp, te = self.hp, self.te
         te.backward(self.d_all, slot=0)
-        if hp.mixing is not None:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
+        if hp.mixing is not None and te.r:  # :1119-1126 -- rows of each adapter's lora_B [D, r]: odd rows (object) / even rows (style) get no update
             gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
             gB[:, :, (1 if hp.mixing == "object" else 0)::2, :].zero_()
 
@@ -312,15 +321,17 @@ class TextBoostStep:
     def optimizer_step(self):
         hp, te, st = self.hp, self.te, self.state
         D = te.geo.hidden_size
-        ops.sumsq(self.flat_grad[: self.n_lora], st[L.ST_SUMSQ_LORA:])
+        if self.n_lora:
+            ops.sumsq(self.flat_grad[: self.n_lora], st[L.ST_SUMSQ_LORA:])
         if te.n_added:
             ops.sumsq(self.flat_grad[self.n_lora:self.n_lora + self.n_emb], st[L.ST_SUMSQ_EMB:])
         if self.lr_table is not None:
             ops.lr_from_table(st, self.lr_table)
         ops.scaler_update(st, hp.max_grad_norm, hp.beta1, hp.beta2, 2.0, 0.5, hp.growth_interval, hp.use_grad_scaler,
-                          grad_div=float(self.world))
-        ops.adamw(self.flat_lora, self.flat_grad[: self.n_lora], self.m_lora, self.v_lora, hp.lr, st, L.ST_COEF_LORA, hp.beta1,
-                  hp.beta2, hp.eps, hp.wd)
+                          grad_div=float(self.world * self.accum))  # DDP's mean / accelerate's loss / gradient_accumulation_steps, folded
+        if self.n_lora:
+            ops.adamw(self.flat_lora, self.flat_grad[: self.n_lora], self.m_lora, self.v_lora, hp.lr, st, L.ST_COEF_LORA, hp.beta1,
+                      hp.beta2, hp.eps, hp.wd)
         # group 0: the whole embedding matrix is an AdamW param; rows < first_added have zero grad (:1114-1117) and
         # therefore only see the decoupled decay
         orig = te.token_table[: te.first_added].view(-1)
@@ -335,10 +346,20 @@ class TextBoostStep:
                       hp.beta1, hp.beta2, hp.eps, hp.wd)
 
     def step_eager(self):
+        """one loop iteration of the reference (:1024-1150).  With --gradient_accumulation_steps G > 1 an iteration is a MICRO step: gradients of G
+        consecutive batches accumulate (accelerate divides each loss by G: folded into the unscale coefficient), the optimizer, the lr
+        schedule and the step counter move on the G-th one only.  Returns True when the optimizer stepped (accelerator.sync_gradients)."""
+        if self._micro == 0 and self.accum > 1:
+            self.flat_grad.zero_()
         self.draw()
         self.forward_backward()
+        self._micro += 1
+        if self._micro < self.accum:
+            return False
+        self._micro = 0
         self.all_reduce()
         self.optimizer_step()
+        return True
 
     # ------------------------------------------------------------------ HIP graph
     def capture(self, warmup: int = 2, single_graph: bool = True):
@@ -352,6 +373,19 @@ class TextBoostStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         dist = self.world > 1 or self.force_dist
+        if self.accum > 1:  # two graphs: the micro step (draw + forward / backward, accumulating) and the optimizer tail of every G-th one
+            self._micro = 0
+            self.flat_grad.zero_()
+            self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
+                self.draw()
+                self.forward_backward()
+            with torch.cuda.graph(self.g2, capture_error_mode="thread_local"):
+                self.optimizer_step()
+            self.flat_grad.zero_()
+            self.graph = (self.g1, self.g2)
+            self.graph_mode = "micro+tail"
+            return
         G = lambda: torch.cuda.CUDAGraph()  # noqa: E731
         cap = lambda g, **kw: torch.cuda.graph(g, capture_error_mode="thread_local", **kw)  # noqa: E731  (thread_local: the RCCL watchdog
         #                                                                      thread keeps polling its events while this thread captures)
@@ -408,12 +442,23 @@ class TextBoostStep:
     def replay(self):
         if self.graph is None:
             return self.step_eager()
+        if self.accum > 1:
+            if self._micro == 0:
+                self.flat_grad.zero_()
+            self.graph[0].replay()
+            self._micro += 1
+            if self._micro < self.accum:
+                return False
+            self._micro = 0
+            self.graph[1].replay()
+            return True
         if len(self.graph) == 1:
             self.graph[0].replay()
         else:
             self.graph[0].replay()
             self.all_reduce()
             self.graph[1].replay()
+        return True
 
     # ------------------------------------------------------------------ host-side reads (NOT in the hot loop)
     def scalars(self):

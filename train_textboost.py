@@ -211,6 +211,7 @@ def main(args):
         if pred_type not in ("epsilon", "v_prediction"):
             raise ValueError(f"Unknown prediction type {pred_type}")  # :1075
     hp = StepHyper(prediction_type=pred_type, use_grad_scaler=not fp32_mode, init_scale=1.0 if fp32_mode else 65536.0,
+                   grad_accum=args.gradient_accumulation_steps,
                    lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
                    beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
                    max_grad_norm=args.max_grad_norm, kpl_weight=args.kpl_weight, kpl_type="cos" if args.kpl_type == "cos" else "mse",
@@ -238,12 +239,8 @@ def main(args):
                                   "--placeholder_token")
     if getattr(args, "tokenizer_name", None):
         raise NotImplementedError("--tokenizer_name is not built: the tokenizer is read from <pretrained_model_name_or_path>/tokenizer")
-    if args.gradient_accumulation_steps != 1:
-        raise NotImplementedError("--gradient_accumulation_steps > 1 is not built (one optimizer step per batch, as the reference's driver runs)")
     if args.text_encoder_use_attention_mask:
         raise NotImplementedError("--text_encoder_use_attention_mask is not built (off in the reference defaults, utils.py:14-17)")
-    if args.lora_rank <= 0:
-        raise NotImplementedError("--lora_rank 0 (embedding-only training) is not built")
     if args.validation_prompts and args.validation_scheduler != "DPMSolverMultistepScheduler":
         raise NotImplementedError("validation sampling implements DPMSolverMultistepScheduler only")
     step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
@@ -388,9 +385,15 @@ def main(args):
         prefetcher = PrefetchFeeder(feeder, B, step.pixel_values, step.input_ids)
         prefetcher.prefetch(index_stream.take(B))
     t0 = time.perf_counter()
-    for it in range(first_step, args.max_train_steps):
-        next_batch(it)
-        step.replay()
+    G = args.gradient_accumulation_steps
+    for mit in range(first_step * G, args.max_train_steps * G):  # one loop iteration = one batch (:1024-1033); `step` counts optimizer steps
+        next_batch(mit)
+        synced = step.replay()
+        if prefetcher is not None and not synced:
+            prefetcher.prefetch(index_stream.take(B))
+        if not synced:  # accelerator.sync_gradients is False: gradients keep accumulating (:1039), nothing below runs (:1153)
+            continue
+        it = mit // G
         done = it + 1
         if is_main and (done % 50 == 0 or done == args.max_train_steps):  # scalars are read off the hot loop
             sc = step.scalars()
@@ -403,7 +406,8 @@ def main(args):
             ckpt.rotate_checkpoints(args.output_dir, args.checkpoints_total_limit)
             cdir = os.path.join(args.output_dir, f"checkpoint-{done}")
             ckpt.save_trainer_state(step, cdir)
-            ckpt.save_text_encoder_adapter(te, os.path.join(cdir, "text_encoder"), mdir)
+            if args.lora_rank > 0:  # :1178-1182
+                ckpt.save_text_encoder_adapter(te, os.path.join(cdir, "text_encoder"), mdir)
             ckpt.save_token_embeddings(te, cdir, added_tokens, aug_token_dict if args.augment_inversion else None)
         if prefetcher is not None and done < args.max_train_steps:
             # after the checkpoint, so that the generator states saved in it are those BEFORE the next batch's draws (resume replays them)
