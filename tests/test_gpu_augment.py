@@ -227,7 +227,7 @@ def test_cli_trains_from_image_files_through_the_device_feeder(tmp_path, monkeyp
         a = np.clip(np.stack([xx * 255 // w, yy * 255 // h, (xx + yy) % 256], -1) + r.integers(-20, 21, (h, w, 3)), 0, 255).astype(np.uint8)
         Image.fromarray(a).save(str(data / f"{i:02d}.png"))
     tok = _WordTokenizer()
-    monkeypatch.setattr(T, "load_tokenizer", lambda mdir: tok)
+    monkeypatch.setattr(T, "load_tokenizer", lambda mdir, name=None: tok)
     # the knowledge-preservation prompts come from the reference's hard-coded relative path (train_textboost.py:892)
     (tmp_path / "data").mkdir()
     (tmp_path / "data" / "human-written-prompts.jsonl").write_text(
@@ -316,7 +316,7 @@ def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch):
     prompts = {}
 
     def run(out, extra):
-        monkeypatch.setattr(T, "load_tokenizer", lambda mdir: _WordTokenizer())
+        monkeypatch.setattr(T, "load_tokenizer", lambda mdir, name=None: _WordTokenizer())
         seen = []
         from textboost_amd import augment as D
         orig = D.DeviceFeeder.batch
@@ -368,3 +368,42 @@ def test_prefetch_feeder_matches_direct_batches():
         del busy
     with pytest.raises(RuntimeError):
         pre.commit()
+
+
+def test_cli_concepts_list_trains_two_concepts(tmp_path, monkeypatch):
+    """--concepts_list (train_textboost.py:602-615, :661-694; dataset.py:302-308): two concepts, each with its own image directory and
+    placeholder token -- every concept's images carry that concept's token list, both placeholder rows are registered, trained and saved;
+    --tokenizer_name is accepted (:630-633)."""
+    import sys
+    pytest.importorskip("PIL")
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train_textboost as T
+    from tests.test_host_logic import _WordTokenizer
+    r = np.random.default_rng(1)
+    concepts = []
+    for name, init in (("<dog>", "dog"), ("<cat>", "cat")):
+        d = tmp_path / name.strip("<>")
+        d.mkdir()
+        a = r.integers(0, 256, (150, 170, 3)).astype(np.uint8)
+        Image.fromarray(a).save(str(d / "00.png"))
+        concepts.append({"instance_data_dir": str(d), "placeholder_token": name, "initializer_token": init})
+    cl = tmp_path / "concepts.json"
+    cl.write_text(json.dumps(concepts))
+    tok = _WordTokenizer()
+    seen = {}
+    monkeypatch.setattr(T, "load_tokenizer", lambda mdir, name=None: seen.setdefault("name", name) and tok or tok)
+    monkeypatch.chdir(tmp_path)
+    out = str(tmp_path / "run")
+    args = T.parse_args(["--pretrained_model_name_or_path", "/nonexistent/sd15", "--concepts_list", str(cl), "--output_dir", out,
+                         "--train_batch_size", "2", "--resolution", "128", "--max_train_steps", "3", "--lora_rank", "4",
+                         "--mixed_precision", "fp16", "--seed", "3", "--template", "textboost", "--tokenizer_name", str(tmp_path / "tok")])
+    T.main(args)
+    assert seen["name"] == str(tmp_path / "tok")
+    log = open(os.path.join(out, "training.log")).read()
+    assert "device feeder: 2 resident instance image(s)" in log
+    for n in ("dog", "cat"):
+        v = torch.load(os.path.join(out, n + ".bin"))
+        assert torch.isfinite(v[f"<{n}>"]).all()
+    assert "<dog>" in tok.vocab and "<cat>" in tok.vocab

@@ -55,10 +55,13 @@ def multi_vector_names(token: str, n: int):
     return [f"{stem}_{i}{tail}" for i in range(n)]
 
 
-def load_tokenizer(model_dir):
-    """`AutoTokenizer.from_pretrained(..., subfolder="tokenizer", use_fast=False)` (:629-641) from LOCAL files only; None when absent."""
-    tdir = os.path.join(model_dir or "", "tokenizer")
+def load_tokenizer(model_dir, tokenizer_name=None):
+    """`AutoTokenizer.from_pretrained(..., subfolder="tokenizer", use_fast=False)` (:629-641) from LOCAL files only; None when absent.
+    --tokenizer_name (:630-633) names the tokenizer directory itself."""
+    tdir = tokenizer_name if tokenizer_name else os.path.join(model_dir or "", "tokenizer")
     if not os.path.exists(os.path.join(tdir, "vocab.json")):
+        if tokenizer_name:
+            raise FileNotFoundError(f"--tokenizer_name {tokenizer_name}: no vocab.json there (only local tokenizer files can be loaded)")
         return None
     from transformers import CLIPTokenizer
     return CLIPTokenizer.from_pretrained(tdir, local_files_only=True)
@@ -119,9 +122,18 @@ def main(args):
     latents = torch.load(lat_path) if args.instance_data_dir and os.path.exists(lat_path) else None
     px_path = os.path.join(args.instance_data_dir or "", "pixel_values.pt")
     pixels = torch.load(px_path) if args.instance_data_dir and os.path.exists(px_path) else None
-    tokenizer = load_tokenizer(mdir)
+    tokenizer = load_tokenizer(mdir, getattr(args, "tokenizer_name", None))
     from textboost_amd import data as tbdata
-    use_images = tokenizer is not None and tbdata.has_instance_images(args.instance_data_dir)
+    # :602-615: one concept from the flags, or the --concepts_list JSON (a list of such dicts: multi-concept training)
+    if getattr(args, "concepts_list", None):
+        with open(args.concepts_list, "r") as f:
+            concepts = json.load(f)
+        for c in concepts:
+            c.setdefault("initializer_token", args.initializer_token)
+    else:
+        concepts = [{"instance_data_dir": args.instance_data_dir, "placeholder_token": args.placeholder_token,
+                     "initializer_token": args.initializer_token}]
+    use_images = tokenizer is not None and all(tbdata.has_instance_images(c.get("instance_data_dir")) for c in concepts)
     if use_images:
         latents, pixels, latent = None, None, args.resolution // 8
     if pixels is not None:
@@ -183,15 +195,20 @@ def main(args):
     g = torch.Generator().manual_seed(args.seed or 0)
     added_tokens, aug_token_dict = {}, {}
     n_place = 1
-    placeholder_names = None
+    concept_names = []  # per concept: the list of its placeholder vector names (`concept["instance_token"] = placeholder_tokens`, :691-692)
     if tokenizer is not None:  # the reference's own registration: one vector per BPE piece of the initialiser, rows copied from the pieces
-        placeholder_names, ids = tbdata.add_token(te, tokenizer, args.placeholder_token, args.initializer_token)
-        added_tokens.update(zip(placeholder_names, ids))
+        for c in concepts:  # :665-679
+            names, ids = tbdata.add_token(te, tokenizer, c["placeholder_token"], c["initializer_token"])
+            concept_names.append(names)
+            added_tokens.update(zip(names, ids))
         if args.augment_inversion:
             _, aug_token_dict = tbdata.add_augmentation_tokens(te, tokenizer, "style" if args.augment_ops == "style" else "object")
     else:
-        for name in multi_vector_names(args.placeholder_token, n_place):
-            added_tokens[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
+        for c in concepts:
+            names = multi_vector_names(c["placeholder_token"], n_place)
+            concept_names.append(names)
+            for name in names:
+                added_tokens[name] = te.add_tokens(torch.randint(0, 49406, (1,), generator=g).tolist())[0]
         if args.augment_inversion:
             for tok, n in (AUG_TOKENS_OBJECT if args.augment_ops == "object" else AUG_TOKENS_STYLE):
                 for name in multi_vector_names(tok, n):
@@ -199,7 +216,8 @@ def main(args):
     added_ids = list(added_tokens.values()) + list(aug_token_dict.values())
     if args.validation_prompts and tokenizer is not None:  # log_validation (:502-505): `<i>` -> the i-th concept's placeholder vectors
         for j, prompt in enumerate(args.validation_prompts):
-            prompt = prompt.replace("<0>", " ".join(placeholder_names))
+            for ci, names in enumerate(concept_names):
+                prompt = prompt.replace(f"<{ci}>", " ".join(names))
             val_ids[j] = tokenizer(prompt, truncation=True, padding="max_length", max_length=tokenizer.model_max_length,
                                    return_tensors="pt").input_ids[0]
 
@@ -234,11 +252,6 @@ def main(args):
     if args.mixed_precision == "bf16":
         raise NotImplementedError("--mixed_precision bf16 is not built: fp16 (the reference driver's setting, run_textboost_db.py:150) and the "
                                   "default no-AMP fp32 mode (:298-308, the README command) are")
-    if getattr(args, "concepts_list", None):
-        raise NotImplementedError("--concepts_list (multi-concept training, :661-694) is not built: a run would silently train only "
-                                  "--placeholder_token")
-    if getattr(args, "tokenizer_name", None):
-        raise NotImplementedError("--tokenizer_name is not built: the tokenizer is read from <pretrained_model_name_or_path>/tokenizer")
     if args.text_encoder_use_attention_mask:
         raise NotImplementedError("--text_encoder_use_attention_mask is not built (off in the reference defaults, utils.py:14-17)")
     if args.validation_prompts and args.validation_scheduler != "DPMSolverMultistepScheduler":
@@ -273,8 +286,10 @@ def main(args):
             pipe = tbaug.PairedAugmentation(hflip="inversion" if args.augment_inversion else "false", augment_prompt=args.augment_prompt,
                                             inversion=args.augment_inversion, p=args.augment_p, ops=args.augment_ops)
         # the reference formats the template with the LIST of placeholder names (`concept["instance_token"] = placeholder_tokens`, :691-692)
-        paths = [p for p in tbdata.get_images_path(args.instance_data_dir, args.num_samples) if p.lower().endswith(tbdata.IMAGE_EXTENSIONS)]
-        images = [(tbaug.to_device_image(tbdata.decode_rgb(p)), placeholder_names) for p in paths]
+        images = []
+        for c, names in zip(concepts, concept_names):  # dataset.py:302-308: every concept's images, each with that concept's token list
+            paths = [p for p in tbdata.get_images_path(c["instance_data_dir"], args.num_samples) if p.lower().endswith(tbdata.IMAGE_EXTENSIONS)]
+            images += [(tbaug.to_device_image(tbdata.decode_rgb(p)), names) for p in paths]
         feeder = tbaug.DeviceFeeder(images, tokenizer, tbdata.load_templates(args.template), size=args.resolution,
                                     center_crop=args.center_crop, augment_pipe=pipe)
         index_stream = tbdata.IndexStream(len(images), args.seed or 0, rank, world)
