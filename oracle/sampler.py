@@ -192,6 +192,62 @@ class DPMSolverPP2M:
         return out
 
 
+class DDPMAncestral:
+    """diffusers 0.29 DDPMScheduler as `DDPMScheduler.from_config(pipeline.scheduler.config, variance_type="fixed_small")` builds it for
+    --validation_scheduler DDPMScheduler (/root/reference/train_textboost.py:341-345, :483-495): SD's betas, clip_sample false (SD's config),
+    timestep_spacing "leading" with steps_offset (timesteps = arange(n) * (T // n), reversed, + offset), ancestral step
+        prev_t = t - T // n;  abar_prev = abar[prev_t] (1 for prev_t < 0);  alpha = abar_t / abar_prev;  beta = 1 - alpha
+        x0 = (x - sqrt(1 - abar_t) eps) / sqrt(abar_t)      (v-prediction: sqrt(abar_t) x - sqrt(1 - abar_t) v)
+        x_prev = sqrt(abar_prev) beta / (1 - abar_t) x0 + sqrt(alpha) (1 - abar_prev) / (1 - abar_t) x + sqrt(var) z   (z for t > 0),
+        var = max((1 - abar_prev) / (1 - abar_t) beta, 1e-20).   [3P: restated, diffusers is not installed here]"""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, prediction_type="epsilon", steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double()
+        self.T, self.prediction_type, self.steps_offset = num_train_timesteps, prediction_type, steps_offset
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n: int):
+        self.n = n
+        self.timesteps = ((torch.arange(0, n, dtype=torch.float64) * (self.T // n)).round().flip(0).long() + self.steps_offset)
+        return self.timesteps
+
+    def coefficients(self, t: int):
+        """(c_x0, c_x, sqrt(var)) of the step at timestep t"""
+        prev_t = t - self.T // self.n
+        ab_t = float(self.alphas_cumprod[t])
+        ab_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        alpha = ab_t / ab_p
+        beta = 1.0 - alpha
+        c_x0 = ab_p ** 0.5 * beta / (1.0 - ab_t)
+        c_x = alpha ** 0.5 * (1.0 - ab_p) / (1.0 - ab_t)
+        var = max((1.0 - ab_p) / (1.0 - ab_t) * beta, 1e-20)
+        return c_x0, c_x, (var ** 0.5 if t > 0 else 0.0)
+
+    def step(self, eps, t: int, sample, noise):
+        ab_t = float(self.alphas_cumprod[t])
+        if self.prediction_type == "epsilon":
+            x0 = (sample - (1.0 - ab_t) ** 0.5 * eps) / ab_t ** 0.5
+        else:
+            x0 = ab_t ** 0.5 * sample - (1.0 - ab_t) ** 0.5 * eps
+        c_x0, c_x, sd = self.coefficients(t)
+        return c_x0 * x0 + c_x * sample + sd * noise
+
+
+def sample_latents_ddpm(unet: Callable, cond, uncond, latents, step_noise, steps=25, guidance=7.5, **scheduler_kwargs):
+    """the guided loop with the ancestral DDPM step; step_noise[i] = the variance noise of step i (the pipeline draws it from its generator)"""
+    sch = DDPMAncestral(**scheduler_kwargs)
+    ts = sch.set_timesteps(steps)
+    x = latents * sch.init_noise_sigma
+    B = x.shape[0]
+    ehs = torch.cat([uncond, cond])
+    for i, t in enumerate(ts.tolist()):
+        e = unet(torch.cat([x, x]), torch.full((2 * B,), t, dtype=torch.long), ehs)
+        eps = e[:B] + guidance * (e[B:] - e[:B])
+        x = sch.step(eps, t, x, step_noise[i])
+    return x
+
+
 def sample_latents(unet: Callable, cond, uncond, latents, steps=25, guidance=7.5, **scheduler_kwargs):
     """The denoising loop of StableDiffusionPipeline.__call__ with classifier-free guidance (do_classifier_free_guidance = g > 1):
     eps = eps_uncond + g (eps_cond - eps_uncond); `unet(x[2B], t[2B], ehs[2B])` -> eps[2B]."""

@@ -104,6 +104,54 @@ def test_guided_sampling_loop_matches_oracle_on_tiny_models():
     assert (img.cpu() - img_ref).abs().mean() < 2e-2
 
 
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_ddpm_validation_scheduler_follows_the_oracle(pred):
+    """--validation_scheduler DDPMScheduler (train_textboost.py:341-345, :483-495): the ancestral step in `tb_dpm_step`'s form (the variance noise
+    rides in the m_prev operand) against the oracle's restatement of diffusers' DDPMScheduler.step over all 25 steps, then the guided loop
+    with the tiny UNet against the oracle loop on the same noise draws."""
+    from oracle.sampler import DDPMAncestral as Ref, sample_latents_ddpm
+    from oracle.vae_encoder import VAEConfig
+    from tests.test_gpu_model import make_unet
+    from textboost_amd import ops
+    from textboost_amd.sampler import DDPMAncestral, HipSampler
+    from textboost_amd.vae import VAEGeometry
+    ref = Ref(prediction_type=pred)
+    sch = DDPMAncestral.from_config({"prediction_type": pred, "clip_sample": False, "steps_offset": 1})
+    ts = ref.set_timesteps(25)
+    assert sch.set_timesteps(25) == ts.tolist() and ts[0].item() == 961 and ts[-1].item() == 1
+    torch.manual_seed(0)
+    B, n, g = 2, 4 * 16 * 16, 7.5
+    x_ref = torch.randn(B, n)
+    x = x_ref.clone().to(dev); m_prev = torch.zeros(B, n, device=dev); x2 = torch.zeros(2 * B, n, device=dev, dtype=torch.float16)
+    for i, t in enumerate(ts.tolist()):
+        e2 = torch.randn(2 * B, n).half()
+        z = torch.randn(B, n)
+        eps = e2[:B].float() + g * (e2[B:].float() - e2[:B].float())
+        x_ref = ref.step(eps, t, x_ref, z)
+        a_t, s_t = sch.data_prediction_scalars(i)
+        ca, cb, cc = sch.coefficients(i)
+        m_prev.copy_(z)
+        ops.dpm_step(x, e2.to(dev), m_prev, x2, n, B, g, a_t, s_t, ca, cb, cc)
+    assert rel_err(x, x_ref) < 1e-5
+    if pred != "epsilon":
+        return
+    Bm, hw, D, steps = 2, 16, 64, 6
+    ref_unet, hip_unet, _ = make_unet(2 * Bm, hw, D, seed=5)
+    _, hip_dec = _decoder_pair(VAEConfig.tiny(), VAEGeometry(block_out_channels=(64, 64, 128, 128), layers_per_block=1), 14, Bm, hw, hw)
+    gen = torch.Generator().manual_seed(8)
+    cond = torch.randn(Bm, 77, D, generator=gen).half().float()
+    uncond = torch.randn(Bm, 77, D, generator=gen).half().float() * 0.5
+    lat = torch.randn(Bm, 4, hw, hw, generator=gen)
+    noise = [torch.randn(Bm, 4, hw, hw, generator=gen) for _ in range(steps)]
+    with torch.no_grad():
+        xr = sample_latents_ddpm(lambda x_, t_, e_: ref_unet(x_.half().float(), t_, e_), cond, uncond, lat, noise, steps=steps, guidance=7.5)
+    smp = HipSampler(hip_unet, hip_dec, steps=steps, guidance=7.5, scheduler="DDPMScheduler")
+    xs = smp.denoise(cond.view(Bm * 77, D).to(dev), uncond.view(Bm * 77, D).to(dev), latents=lat.to(dev), step_noise=[z.to(dev) for z in noise])
+    assert rel_err(xs, xr) < 3e-2
+    img = smp.sample(cond.view(Bm * 77, D).to(dev), uncond.view(Bm * 77, D).to(dev), latents=lat.to(dev))   # noise from the sampler's generator
+    assert torch.isfinite(img).all()
+
+
 def test_cli_validation_writes_image_grid(tmp_path):
     """--validation_prompts with tokenised prompts: 25-step guided sampling + VAE decode every --validation_steps, validation_{step}.jpg."""
     import os

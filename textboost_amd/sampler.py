@@ -96,15 +96,72 @@ class DPMSolverPP2M:
         return ca, -a1 * e * (1.0 + 0.5 / r0), a1 * e * (0.5 / r0)
 
 
+class DDPMAncestral:
+    """--validation_scheduler DDPMScheduler (train_textboost.py:341-345, :483-495): diffusers DDPMScheduler built from the model's scheduler config
+    with variance_type "fixed_small" -- SD's betas, clip_sample false, timestep_spacing "leading" (timesteps arange(n) * (T // n), reversed,
+    + steps_offset), the ancestral step  x_prev = c_x0 x0 + c_x x + sqrt(var) z.  In `tb_dpm_step`'s form (x = ca x + cb m0 + cc m_prev, m0 the
+    data prediction) the variance noise z rides in the m_prev operand: (ca, cb, cc) = (c_x, c_x0, sqrt(var)).  [3P restated]"""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon",
+                 steps_offset=1):
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"beta_schedule {beta_schedule}")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type {prediction_type}")
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double()
+        self.T, self.prediction_type, self.steps_offset = num_train_timesteps, prediction_type, int(steps_offset)
+        self.init_noise_sigma = 1.0
+        self.needs_noise = True
+
+    @classmethod
+    def from_config(cls, cfg: Optional[dict]):
+        cfg = cfg or {}
+        if cfg.get("clip_sample", False):
+            raise NotImplementedError("DDPMScheduler with clip_sample = true (SD's scheduler configs say false)")
+        return cls(num_train_timesteps=cfg.get("num_train_timesteps", 1000), beta_start=cfg.get("beta_start", 0.00085),
+                   beta_end=cfg.get("beta_end", 0.012), beta_schedule=cfg.get("beta_schedule", "scaled_linear"),
+                   prediction_type=cfg.get("prediction_type", "epsilon"), steps_offset=cfg.get("steps_offset", 1))
+
+    def set_timesteps(self, n: int) -> List[int]:
+        self.n = n
+        self.timesteps = ((torch.arange(0, n, dtype=torch.float64) * (self.T // n)).round().flip(0).long() + self.steps_offset).tolist()
+        return self.timesteps
+
+    def data_prediction_scalars(self, i: int) -> Tuple[float, float]:
+        ab = float(self.alphas_cumprod[self.timesteps[i]])
+        a_t, s_t = math.sqrt(ab), math.sqrt(1.0 - ab)
+        return (a_t, s_t) if self.prediction_type == "epsilon" else (1.0 / a_t, s_t / a_t)
+
+    def coefficients(self, i: int) -> Tuple[float, float, float]:
+        t = self.timesteps[i]
+        prev_t = t - self.T // self.n
+        ab_t = float(self.alphas_cumprod[t])
+        ab_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        alpha = ab_t / ab_p
+        beta = 1.0 - alpha
+        var = max((1.0 - ab_p) / (1.0 - ab_t) * beta, 1e-20)
+        return math.sqrt(alpha) * (1.0 - ab_p) / (1.0 - ab_t), math.sqrt(ab_p) * beta / (1.0 - ab_t), (math.sqrt(var) if t > 0 else 0.0)
+
+
 class HipSampler:
     """`sample(cond_ehs, uncond_ehs, latents=None) -> images [B,3,8h,8w] in [0,1]`.  `unet` must be built for batch 2B (guidance runs the
     unconditional and conditional rows in one call, as the pipeline does), `vae_decoder` for batch B."""
 
-    def __init__(self, unet, vae_decoder, steps: int = 25, guidance: float = 7.5, scheduler_config: Optional[dict] = None):
+    def __init__(self, unet, vae_decoder, steps: int = 25, guidance: float = 7.5, scheduler_config: Optional[dict] = None,
+                 scheduler: str = "DPMSolverMultistepScheduler"):
         assert unet.B == 2 * vae_decoder.B and unet.H == vae_decoder.h and unet.W == vae_decoder.w
         self.unet, self.vae, self.steps, self.g = unet, vae_decoder, steps, guidance
         self.B = vae_decoder.B
-        self.sch = DPMSolverPP2M.from_config(scheduler_config)
+        if scheduler == "DPMSolverMultistepScheduler":
+            self.sch = DPMSolverPP2M.from_config(scheduler_config)
+        elif scheduler == "DDPMScheduler":  # --validation_scheduler DDPMScheduler (:341-345)
+            self.sch = DDPMAncestral.from_config(scheduler_config)
+        else:
+            raise ValueError(f"validation scheduler {scheduler}")
         self.timesteps = self.sch.set_timesteps(steps)
         dev = unet.dev
         B, h, w = self.B, unet.H, unet.W
@@ -114,8 +171,9 @@ class HipSampler:
         self.t_dev = [torch.full((2 * B,), t, dtype=torch.int64, device=dev) for t in self.timesteps]
         self.generator: Optional[torch.Generator] = None
 
-    def denoise(self, cond_ehs, uncond_ehs, latents=None):
-        """cond / uncond: fp16 or fp32 [B*77, D] text-encoder outputs.  Returns the final latents fp32 [B,4,h,w]."""
+    def denoise(self, cond_ehs, uncond_ehs, latents=None, step_noise=None):
+        """cond / uncond: fp16 or fp32 [B*77, D] text-encoder outputs.  Returns the final latents fp32 [B,4,h,w].
+        step_noise (ancestral schedulers only): one [B,4,h,w] tensor per step instead of drawing from `self.generator`."""
         B, sch = self.B, self.sch
         if latents is None:
             latents = torch.randn(self.x.shape, device=self.x.device, generator=self.generator)
@@ -129,6 +187,11 @@ class HipSampler:
             eps2 = self.unet.forward(self.x2, self.t_dev[i], ehs)
             a_t, s_t = sch.data_prediction_scalars(i)
             ca, cb, cc = sch.coefficients(i)
+            if getattr(sch, "needs_noise", False):  # the variance noise of the ancestral step rides in the m_prev operand
+                if step_noise is not None:
+                    self.m_prev.copy_(step_noise[i])
+                else:
+                    self.m_prev.normal_(generator=self.generator)
             ops.dpm_step(self.x, eps2, self.m_prev, self.x2, n, B, self.g, a_t, s_t, ca, cb, cc)
         return self.x
 

@@ -168,7 +168,7 @@ def main(args):
         scfg = json.load(open(scfg_path)) if os.path.exists(scfg_path) else None
         sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),  # (validation images: fp16 pipeline in both modes)
                              HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5,
-                             scheduler_config=scfg)
+                             scheduler_config=scfg, scheduler=args.validation_scheduler)
         del dsd
     del usd
     te_mode = "fp32" if fp32_mode else "autocast"
@@ -253,9 +253,9 @@ def main(args):
         raise NotImplementedError("--mixed_precision bf16 is not built: fp16 (the reference driver's setting, run_textboost_db.py:150) and the "
                                   "default no-AMP fp32 mode (:298-308, the README command) are")
     if args.text_encoder_use_attention_mask:
-        raise NotImplementedError("--text_encoder_use_attention_mask is not built (off in the reference defaults, utils.py:14-17)")
-    if args.validation_prompts and args.validation_scheduler != "DPMSolverMultistepScheduler":
-        raise NotImplementedError("validation sampling implements DPMSolverMultistepScheduler only")
+        raise NotImplementedError("--text_encoder_use_attention_mask has no runnable reference behaviour: the collate function hands "
+                                  "encode_prompt a Python LIST of masks (textboost/dataset.py:427-454) and `attention_mask.to(device)` "
+                                  "(textboost/utils.py:14-15) raises AttributeError in the reference itself")
     step = TextBoostStep(unet, te, teacher, hp, (B, 4, latent, latent), device=dev, world_size=world)
     if pixels is not None or use_images:  # :651-656, :938: the (frozen) VAE; the step then starts from pixel_values (:1027-1037)
         from textboost_amd.vae import HipVAEEncoder, VAEGeometry, vae_encoder_shapes
