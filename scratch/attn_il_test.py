@@ -62,3 +62,40 @@ if __name__ == "__main__":
             t = timeit(lambda: ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd))
             print(f"round {rnd} {name:4s}: fwd {t:7.1f} us  {fl/t/1e6:6.1f} TF/s")
     L.lib().tb_attention_set_variant(1)
+
+    # ---- backward: software-pipelined dK/dV (and dQ) kernels vs the LDS-DMA ones and fp32 autograd
+    def bwd_check(B, H, S, hd=40, seed=1):
+        torch.manual_seed(seed)
+        C = H * hd
+        qkv = torch.randn(B * S, 3 * C, device=dev).half()
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        o = torch.empty(B * S, C, device=dev, dtype=torch.float16); lse = torch.empty(B, H, S, device=dev)
+        L.lib().tb_attention_set_variant(1)
+        ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd)
+        do = torch.randn(B * S, C, device=dev).half()
+        qr, kr, vr = [t.float().view(B, S, H, hd).transpose(1, 2).requires_grad_(True) for t in (q, k, v)]
+        sc = qr @ kr.transpose(-1, -2) * hd ** -0.5
+        (torch.softmax(sc, -1) @ vr).backward(do.float().view(B, S, H, hd).transpose(1, 2))
+        refs = [t.grad.transpose(1, 2).reshape(B * S, C) for t in (qr, kr, vr)]
+        for name, var in (("il", 1), ("dma", 1 | 2048 | 4096)):
+            L.lib().tb_attention_set_variant(var)
+            delta = torch.empty(B, H, S, device=dev)
+            dqkv = torch.zeros(B * S, 3 * C, device=dev, dtype=torch.float16)
+            ws = torch.empty(2 * B * H * S, device=dev)
+            ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws)
+            torch.cuda.synchronize()
+            errs = [((dqkv[:, i * C:(i + 1) * C].float() - refs[i]).norm() / refs[i].norm()).item() for i in range(3)]
+            print(f"bwd B={B} H={H} S={S} {name}: dq {errs[0]:.2e} dk {errs[1]:.2e} dv {errs[2]:.2e}")
+            assert max(errs) < 4e-3, errs
+        L.lib().tb_attention_set_variant(1)
+    bwd_check(8, 8, 512)
+    bwd_check(1, 8, 4096)
+    B, H, S, hd = 8, 8, 4096, 40; C = H * hd
+    do = torch.randn(B * S, C, device=dev).half(); delta = torch.empty(B, H, S, device=dev)
+    dqkv = torch.zeros(B * S, 3 * C, device=dev, dtype=torch.float16); ws = torch.empty(2 * B * H * S, device=dev)
+    for rnd in range(3):
+        for name, var in (("il", 1), ("dma", 1 | 2048 | 4096)):
+            L.lib().tb_attention_set_variant(var)
+            t = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws))
+            print(f"round {rnd} {name:4s}: bwd {t:7.1f} us  {2.5*fl/t/1e6:6.1f} TF/s")
+    L.lib().tb_attention_set_variant(1)

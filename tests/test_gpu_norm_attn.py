@@ -292,3 +292,39 @@ def test_attention_backward_dma_staged_dkv(B, H, S, hd):
         assert not torch.equal(res[0][:, C:], res[1][:, C:]), "the DMA-staged dK/dV kernel did not run"
     assert not torch.equal(res[0][:, :C], res[1][:, :C]), "the DMA-staged dQ kernel did not run"
     assert rel_err(res[0], res[1]) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,S", [(8, 8, 1024), (2, 8, 4096), (16, 4, 1024)])
+def test_attention_backward_software_pipelined_dkv(B, H, S):
+    """attn_bwd_dkv_il_kernel (hd = 40, >= 512 key blocks: the SD1.x 64x64-map self-attention backward at the metric batch): a three-stage
+    pipeline over 32-query halves inside a wave -- prologue, the 4-slot ring wrapping (16 / 64 query tiles), epilogue.  Against fp32 autograd
+    (rel-L2 / max-abs / worst channel) and against the LDS-DMA kernel it replaces (bit 2048 of tb_attention_set_variant): same arithmetic in
+    the same order, so bit-equal."""
+    ops = _ops()
+    from textboost_amd import _lib as L
+    torch.manual_seed(6)
+    hd = 40
+    C = H * hd
+    qkv = torch.randn(B * S, 3 * C, device="cuda").half()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o = torch.empty(B * S, C, device="cuda", dtype=torch.float16)
+    lse = torch.empty(B, H, S, device="cuda")
+    ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd)
+    do = torch.randn(B * S, C, device="cuda").half()
+    res = []
+    old = L.lib().tb_attention_set_variant(1)
+    for bits in (1, 1 | 2048):
+        L.lib().tb_attention_set_variant(bits)
+        delta = torch.empty(B, H, S, device="cuda")
+        dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16)
+        ws = torch.empty(2 * B * H * S, device="cuda")
+        ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws)
+        res.append(dqkv)
+    L.lib().tb_attention_set_variant(old)
+    assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1])
+    if S <= 1024:
+        qr, kr, vr = [t.float().reshape(B, S, C).requires_grad_(True) for t in (q, k, v)]
+        oref, _ = ref_attention(qr, kr, vr, H, False)
+        oref.backward(do.float().view(B, S, C))
+        parity("pipelined dK", res[0][:, C:2 * C].reshape(B, S, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+        parity("pipelined dV", res[0][:, 2 * C:].reshape(B, S, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)

@@ -1618,6 +1618,9 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     if (!dq_dma) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
   }
   if (dkv_dma) {
+    if constexpr (DT == 2 && KS == 3) {  // hd = 40: the software-pipelined kernel (attention_il.hip)
+      if (!(g_attn_dma & 2048) && tb_attn_il_dkv_ok(d)) return tb_attn_il_dkv(d, s, (g_attn_dma >> 6) & 1);
+    }
     if constexpr ((DT == 2 && KS == 3) || (DT == 2 && KS == 4) || (DT == 3 && KS == 5)) {
       constexpr int PC = KS == 3 ? 6 : (KS == 4 ? 9 : 11), NST = DT == 2 ? 4 : 3;
       const size_t lds = NST * (2 * KVT * PC * 16 + 2 * KVT * 4 + 64);

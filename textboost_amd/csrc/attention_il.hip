@@ -427,7 +427,270 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_il_kernel(const tb_attn_desc 
   store(Bg, qblk + wave * 64 + 32 + l31);
 }
 
+// ------------------------------------------------------------------------------------------------ dK, dV
+// attn_bwd_dkv_dma_kernel's arithmetic (attention.hip: a lane owns a key; streamed Q / dO tiles row-major by LDS-DMA, S^T and dP^T from
+// b128 row reads, dV += P^T dO and dK += dS^T Q from the same rows through the transposing read; the per-query -lse log2(e) / -delta the dQ
+// kernel published enter as accumulator inputs) as a THREE-STAGE pipeline over 32-query halves inside one wave:
+//     phase k:   matrix pipe  = dV, dK of half k-1 (8 MFMAs)  +  S^T, dP^T of half k+1 (6 MFMAs)
+//                vector ALU   = p = exp2(s), ds = p * dp, fp16 packing of half k (48 instructions, 3.4 per MFMA)
+// so every MFMA is followed by a slice of the softmax work of the half in between; score registers and packed fragments are double-buffered
+// by the half's parity.  One barrier per 64-query tile, placed where the pipeline first touches the next tile.
+constexpr int D_PCB = 96, D_TILE_B = KVT * D_PCB, D_STAGE_B = 2 * D_TILE_B + 2 * KVT * 4 + 64, D_NST = 4;
+
+struct DkvState {
+  f32x16 dk[2], dv[2];
+  f32x16 s[2], dp[2];        // [parity of the half]
+  f16x8 pp[2][2], ds[2][2];  // [parity][16-query quarter]: P^T and dS^T as B-operand fragments
+  f16x8 kf[3], vf[3];        // lane-owned K (pre-scaled by scale * log2 e) and V rows
+};
+template <int U, int PAR>
+__device__ __forceinline__ void dkv_unit(DkvState& st) {  // registers 2U, 2U+1 of the half with parity PAR
+  constexpr int r = 2 * U;
+  const float p0 = fast_exp2(st.s[PAR][r]), p1 = fast_exp2(st.s[PAR][r + 1]);
+  const float d0 = p0 * st.dp[PAR][r], d1 = p1 * st.dp[PAR][r + 1];
+  st.pp[PAR][r >> 3][r & 7] = (f16)p0;
+  st.pp[PAR][r >> 3][(r & 7) + 1] = (f16)p1;
+  st.ds[PAR][r >> 3][r & 7] = (f16)d0;
+  st.ds[PAR][r >> 3][(r & 7) + 1] = (f16)d1;
+}
+template <int SLOT, int PAR>
+__device__ __forceinline__ void dkv_slice(DkvState& st) {  // 8 units over the 14 MFMA slots of a phase
+  if constexpr (SLOT == 0) dkv_unit<0, PAR>(st);
+  else if constexpr (SLOT == 2) dkv_unit<1, PAR>(st);
+  else if constexpr (SLOT == 4) dkv_unit<2, PAR>(st);
+  else if constexpr (SLOT == 6) dkv_unit<3, PAR>(st);
+  else if constexpr (SLOT == 8) dkv_unit<4, PAR>(st);
+  else if constexpr (SLOT == 10) dkv_unit<5, PAR>(st);
+  else if constexpr (SLOT == 12) dkv_unit<6, PAR>(st);
+  else if constexpr (SLOT == 13) dkv_unit<7, PAR>(st);
+}
+// operand fetch of MFMA N of a phase whose halves k-1 / k+1 are the 32-query half KT of their tiles:
+//   N = 0..7  (half k-1): (jj, d, which) = (N >> 2, (N >> 1) & 1, N & 1); which 0: dO^T fragment (dV), 1: Q^T fragment (dK): transposing reads
+//   N = 8..13 (half k+1): (j, which) = ((N - 8) >> 1, (N - 8) & 1);       which 0: Q rows (S^T), 1: dO rows (dP^T): b128 reads
+template <int N, int KT>
+__device__ __forceinline__ f16x8 dkv_fetch(uint32_t prev_tr, uint32_t next_rm) {
+  if constexpr (N < 8) {
+    constexpr int jj = N >> 2, d = (N >> 1) & 1, which = N & 1;
+    constexpr int off = (which ? 0 : D_TILE_B) + (KT * 32 + 16 * jj) * D_PCB + d * 64;
+    return join8(tr_read<off>(prev_tr), tr_read<off + 8 * D_PCB>(prev_tr));
+  } else {
+    constexpr int j = (N - 8) >> 1, which = (N - 8) & 1;
+    return rm_read(next_rm + (which ? D_TILE_B : 0) + KT * 32 * D_PCB + j * 32);
+  }
+}
+template <int N, int PAR>
+__device__ __forceinline__ void dkv_mfma(DkvState& st, const f16x8& a, const f32x16& s_init, const f32x16& dp_init) {
+  constexpr int Q = PAR ^ 1;  // halves k-1 and k+1 have the other parity
+  if constexpr (N < 8) {
+    constexpr int jj = N >> 2, d = (N >> 1) & 1, which = N & 1;
+    if constexpr (which == 0) st.dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.pp[Q][jj], st.dv[d], 0, 0, 0);
+    else st.dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.ds[Q][jj], st.dk[d], 0, 0, 0);
+  } else {
+    constexpr int j = (N - 8) >> 1, which = (N - 8) & 1;
+    if constexpr (which == 0) st.s[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.kf[j], j == 0 ? s_init : st.s[Q], 0, 0, 0);
+    else st.dp[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.vf[j], j == 0 ? dp_init : st.dp[Q], 0, 0, 0);
+  }
+}
+template <int N, int LO, int HI, int PAR, bool SM>
+__device__ __forceinline__ void dkv_step(DkvState& st, f16x8& a0, f16x8& a1, uint32_t prev_tr, uint32_t next_rm, const f32x16& s_init,
+                                         const f32x16& dp_init) {
+  if constexpr (N <= HI) {
+    constexpr int KT = PAR ^ 1;
+    f16x8 nxt;
+    if constexpr (N + 2 <= HI) nxt = dkv_fetch<N + 2, KT>(prev_tr, next_rm);
+    if constexpr (N < 8) {
+      constexpr int later = ((N + 1 <= HI && N + 1 < 8) ? 2 : 0) + ((N + 2 <= HI && N + 2 < 8) ? 2 : 0);
+      frag_wait<later>(a0);
+    }
+    dkv_mfma<N, PAR>(st, a0, s_init, dp_init);
+    if constexpr (SM) dkv_slice<N, PAR>(st);
+    SB();
+    a0 = a1;
+    if constexpr (N + 2 <= HI) a1 = nxt;
+    dkv_step<N + 1, LO, HI, PAR, SM>(st, a0, a1, prev_tr, next_rm, s_init, dp_init);
+  }
+}
+// PAR = parity of the half whose softmax runs (k & 1); PREV / NEXT: the matrix work of halves k-1 / k+1 exists
+template <int PAR, bool PREV, bool NEXT, bool SM>
+__device__ __forceinline__ void dkv_phase(DkvState& st, uint32_t prev_tr, uint32_t next_rm, uint32_t next_stat, int hi) {
+  constexpr int LO = PREV ? 0 : 8, HI = NEXT ? 13 : 7, KT = PAR ^ 1;
+  f32x16 s_init, dp_init;
+  if constexpr (NEXT) {  // -lse log2(e) / -delta of the next half's queries: rows of register quad g are 8 g + 4 hi + {0..3}
+    const uint32_t sa = next_stat + (KT * 32 + 4 * hi) * 4;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 lq = *(__attribute__((address_space(3))) const f32x4*)(uintptr_t)(sa + q4 * 32);
+      const f32x4 dq = *(__attribute__((address_space(3))) const f32x4*)(uintptr_t)(sa + KVT * 4 + q4 * 32);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_init[4 * q4 + e] = lq[e], dp_init[4 * q4 + e] = dq[e];
+    }
+  }
+  f16x8 a0 = dkv_fetch<LO, KT>(prev_tr, next_rm), a1 = dkv_fetch<LO + 1, KT>(prev_tr, next_rm);
+  SB();
+  if constexpr (SM && LO > 0) {  // no MFMAs 0..7 to ride behind
+    dkv_unit<0, PAR>(st); dkv_unit<1, PAR>(st); dkv_unit<2, PAR>(st); dkv_unit<3, PAR>(st);
+    SB();
+  }
+  dkv_step<LO, LO, HI, PAR, SM>(st, a0, a1, prev_tr, next_rm, s_init, dp_init);
+  if constexpr (SM && HI < 13) {
+    dkv_unit<4, PAR>(st); dkv_unit<5, PAR>(st); dkv_unit<6, PAR>(st); dkv_unit<7, PAR>(st);
+    SB();
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_desc p, int remap) {
+  constexpr int PC = 6, NI = 2 * PC + 2, WI = (NI + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Blk blk = block_of(remap);
+  const int b = blk.b, h = blk.h, hd = p.hd;
+  const int key = blk.x * 128 + wave * 32 + l31;
+  const int64_t ldq = p.ldq, lddo = p.lddo;
+  const char* Qg = (const char*)((const f16*)p.Q + (int64_t)b * p.Sq * ldq + h * hd);
+  const char* dOg = (const char*)((const f16*)p.dO + (int64_t)b * p.Sq * lddo + h * hd);
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * hd;
+  const int64_t BHS = (int64_t)p.B * p.H * p.Sq;
+  const char* NLg = (const char*)(p.ws + ((int64_t)b * p.H + h) * p.Sq);        // -lse * log2(e), written by the dQ kernel
+  const char* NDg = (const char*)(p.ws + BHS + ((int64_t)b * p.H + h) * p.Sq);  // -delta
+  DkvState st;
+  {
+    const float c = p.scale * LOG2E;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = 16 * j + 8 * hi;
+      const bool ok = key < p.Skv && col < hd;
+      st.kf[j] = *(ok ? (gvec8_t)(Kg + (int64_t)key * p.ldk + col) : (gvec8_t)g_zero8_il);
+      st.vf[j] = *(ok ? (gvec8_t)(Vg + (int64_t)key * p.ldv + col) : (gvec8_t)g_zero8_il);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st.kf[j][e] = (f16)((float)st.kf[j][e] * c);
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.dk[d][r] = 0.f, st.dv[d][r] = 0.f;
+  }
+  // ---- this lane's part of a stage's loads: instruction t = wave + 4 i; t < PC: Q rows, t < 2 PC: dO rows, then the two stat rows
+  uint32_t g_off[WI];
+  bool g_on[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave + 4 * i;
+    const int tensor = t >= PC ? 1 : 0;
+    const int f = (t - tensor * PC) * 64 + lane;
+    const int row = f / PC, cc = f - row * PC;
+    g_on[i] = t < 2 * PC && cc < PC - 1;
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? lddo : ldq) * 2 + cc * 16);
+  }
+  int n_issued = 0;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) n_issued += (wave + 4 * i < NI) ? 1 : 0;
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * D_STAGE_B;
+    const char* qb = Qg + (int64_t)tile * KVT * ldq * 2;
+    const char* ob = dOg + (int64_t)tile * KVT * lddo * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave + 4 * i;
+      if (t < 2 * PC) {
+        const char* src = (t >= PC ? ob : qb) + g_off[i];
+        if (g_on[i]) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + t * 1024), 16, 0, 0);
+      } else if (t < NI) {  // 64 floats = one dword per lane
+        const char* src = (t == 2 * PC ? NLg : NDg) + ((int64_t)tile * KVT + lane) * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + 2 * D_TILE_B + (t - 2 * PC) * 256), 4, 0, 0);
+      }
+    }
+  };
+  for (int u = threadIdx.x; u < 2 * KVT * D_NST; u += 256) {  // pad chunks of every row of every stage: zeros (finite)
+    const int s_ = u / (2 * KVT), r = u - s_ * 2 * KVT;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + s_ * D_STAGE_B + (r >= KVT ? D_TILE_B : 0) + (r & (KVT - 1)) * D_PCB + (PC - 1) * 16) = z;
+  }
+  const int n = p.Sq / KVT;  // >= 2 (launcher)
+#pragma unroll
+  for (int t = 0; t < D_NST - 1; ++t)
+    if (t < n) stage_loads(t, t);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem_raw;
+  const uint32_t rm_lane = lds0 + l31 * D_PCB + hi * 16;
+  const int g4 = lane >> 4, j16 = lane & 15;
+  const uint32_t tr_lane = lds0 + (4 * (g4 >> 1) + (j16 >> 2)) * D_PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
+  const uint32_t stat0 = lds0 + 2 * D_TILE_B;
+  // tile t in slot t & 3.  `sync(t)`: tile t has landed for every wave, every wave is done with tile t - 2 (-> the loads of tile t + 2 go there)
+  auto sync = [&](int t) {
+    int later = n - 1 - t;
+    later = later > 1 ? 1 : later;      // loads issued after tile t's that may stay in flight: tile t + 1's
+    if (t == 0) later = n - 1 > 2 ? 2 : n - 1;  // the prologue issued tiles 0, 1, 2
+    switch (later * n_issued) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t >= 1 && t + 2 < n) stage_loads(t + 2, (t + 2) & 3);
+  };
+#define TR_OF(t) (tr_lane + ((t) & 3) * D_STAGE_B)
+#define RM_OF(t) (rm_lane + ((t) & 3) * D_STAGE_B)
+#define ST_OF(t) (stat0 + ((t) & 3) * D_STAGE_B)
+#ifdef TB_IL_PROF
+  const unsigned long long pfd_t0 = __builtin_amdgcn_s_memtime(), pfd_r0 = wall_clock64();
+#endif
+  sync(0);
+  dkv_phase<1, false, true, false>(st, 0, RM_OF(0), ST_OF(0), hi);          // k = -1: S, dP of half 0
+  dkv_phase<0, false, true, true>(st, 0, RM_OF(0), ST_OF(0), hi);           // k = 0 : softmax(0); S, dP of half 1
+  for (int t = 0; t + 1 < n; ++t) {
+    sync(t + 1);
+    dkv_phase<1, true, true, true>(st, TR_OF(t), RM_OF(t + 1), ST_OF(t + 1), hi);       // k = 2t+1: dV dK(2t) | softmax(2t+1) | S dP(2t+2)
+    dkv_phase<0, true, true, true>(st, TR_OF(t), RM_OF(t + 1), ST_OF(t + 1), hi);       // k = 2t+2: dV dK(2t+1) | softmax(2t+2) | S dP(2t+3)
+  }
+  dkv_phase<1, true, false, true>(st, TR_OF(n - 1), 0, 0, hi);              // k = 2n-1: dV dK(2n-2) | softmax(2n-1)
+  dkv_phase<0, true, false, false>(st, TR_OF(n - 1), 0, 0, hi);             // k = 2n  : dV dK(2n-1)
+#ifdef TB_IL_PROF
+  if (p.Delta && threadIdx.x == 0) {  // per block: shader-clock ticks and 100 MHz ticks of the main loop (the dQ kernel is done with Delta)
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    p.Delta[2 * lin] = (float)(__builtin_amdgcn_s_memtime() - pfd_t0);
+    p.Delta[2 * lin + 1] = (float)(wall_clock64() - pfd_r0);
+  }
+#endif
+#undef TR_OF
+#undef RM_OF
+#undef ST_OF
+  if (key < p.Skv) {
+    f16* dKg = (f16*)p.dK + ((int64_t)b * p.Skv + key) * p.lddk + h * hd;
+    f16* dVg = (f16*)p.dV + ((int64_t)b * p.Skv + key) * p.lddv + h * hd;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < hd) {
+          f16x4 a, bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = (f16)(st.dk[d][4 * r4 + e] * p.scale);
+            bb[e] = (f16)st.dv[d][4 * r4 + e];
+          }
+          *(f16x4*)(dKg + col) = a;
+          *(f16x4*)(dVg + col) = bb;
+        }
+      }
+  }
+}
+
 }  // namespace
+
+bool tb_attn_il_dkv_ok(const tb_attn_desc& d) {
+  return !d.causal && d.hd == 40 && d.Sq % KVT == 0 && d.Sq >= 2 * KVT && d.Skv % 128 == 0 && d.ws && d.ws_floats >= 2 * (int64_t)d.B * d.H * d.Sq &&
+         d.ldq % 8 == 0 && d.lddo % 8 == 0 && (int64_t)KVT * (d.ldq > d.lddo ? d.ldq : d.lddo) * 2 < ((int64_t)1 << 31);
+}
+int tb_attn_il_dkv(const tb_attn_desc& d, hipStream_t s, int remap) {
+  const size_t lds = D_NST * D_STAGE_B;
+  hipLaunchKernelGGL(attn_bwd_dkv_il_kernel, dim3(d.Skv / 128, d.H, d.B), dim3(256), lds, s, d, remap);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
 
 bool tb_attn_il_fwd_ok(const tb_attn_desc& d) {
   return !d.causal && d.hd == 40 && d.Sq % 256 == 0 && d.Skv % KVT == 0 && d.Skv >= 2 * KVT && d.ldk % 8 == 0 && d.ldv % 8 == 0 && !d.fp8_ws &&
