@@ -295,8 +295,8 @@ def test_attention_backward_dma_staged_dkv(B, H, S, hd):
 
 
 @pytest.mark.parametrize("B,H,S", [(8, 8, 1024), (2, 8, 4096), (16, 4, 1024)])
-def test_attention_backward_software_pipelined_dkv(B, H, S):
-    """attn_bwd_dkv_il_kernel (hd = 40, >= 512 key blocks: the SD1.x 64x64-map self-attention backward at the metric batch): a three-stage
+def test_attention_backward_software_pipelined_kernels(B, H, S):
+    """attn_bwd_dq_il_kernel / attn_bwd_dkv_il_kernel (hd = 40, >= 512 key blocks: the SD1.x 64x64-map self-attention backward at the metric batch): a three-stage
     pipeline over 32-query halves inside a wave -- prologue, the 4-slot ring wrapping (16 / 64 query tiles), epilogue.  Against fp32 autograd
     (rel-L2 / max-abs / worst channel) and against the LDS-DMA kernel it replaces (bit 2048 of tb_attention_set_variant): same arithmetic in
     the same order, so bit-equal."""
@@ -313,18 +313,20 @@ def test_attention_backward_software_pipelined_dkv(B, H, S):
     do = torch.randn(B * S, C, device="cuda").half()
     res = []
     old = L.lib().tb_attention_set_variant(1)
-    for bits in (1, 1 | 2048):
+    for bits in (1, 1 | 2048 | 4096):   # both pipelined kernels (dQ, dK/dV), then the LDS-DMA kernels they replace
         L.lib().tb_attention_set_variant(bits)
         delta = torch.empty(B, H, S, device="cuda")
         dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16)
         ws = torch.empty(2 * B * H * S, device="cuda")
         ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws)
-        res.append(dqkv)
+        res.append((dqkv, delta))
     L.lib().tb_attention_set_variant(old)
-    assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1])
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    res = [r[0] for r in res]
     if S <= 1024:
         qr, kr, vr = [t.float().reshape(B, S, C).requires_grad_(True) for t in (q, k, v)]
         oref, _ = ref_attention(qr, kr, vr, H, False)
         oref.backward(do.float().view(B, S, C))
+        parity("pipelined dQ", res[0][:, :C].reshape(B, S, C), qr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
         parity("pipelined dK", res[0][:, C:2 * C].reshape(B, S, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
         parity("pipelined dV", res[0][:, 2 * C:].reshape(B, S, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)

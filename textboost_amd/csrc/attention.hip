@@ -1603,7 +1603,10 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
       dq_dma = d.hd == (KS == 3 ? 40 : (KS == 4 ? 64 : 80)) && !(KS != 3 && (g_attn_dma & 512)) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 &&
                !(g_attn_dma & 256) && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
                (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31) && d.Skv >= 512;
-      if (dq_dma) {
+      if (dq_dma && DT == 2 && KS == 3 && !(g_attn_dma & 4096) && tb_attn_il_dq_ok(d)) {  // hd = 40: the software-pipelined kernel
+        const int rc = tb_attn_il_dq(d, s, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
+        if (rc) return rc;
+      } else if (dq_dma) {
         const size_t ldsq = NST * (2 * KVT * PC * 16 + 64);
         static bool attr_q = false;
         if (!attr_q && ldsq > 65536) {

@@ -679,7 +679,235 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_d
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ
+// attn_bwd_dq_dma_kernel's arithmetic (a lane owns a query; K / V tiles row-major by LDS-DMA; S^T = K Q^T and dP^T = V dO^T from b128 row
+// reads with -lse log2(e) / -delta as accumulator inputs; dQ^T += K^T dS^T through the transposing read; also delta = rowsum(dO * O) and the
+// statistics the dK/dV kernel reads) as the same three-stage pipeline over 32-key halves:
+//     phase k:   matrix pipe = dQ of half k-1 (4 MFMAs) + S^T, dP^T of half k+1 (6 MFMAs);   vector ALU = dS = exp2(s) * dp, packing of half k
+constexpr int Q_STAGE_B = 2 * D_TILE_B + 64;
+struct DqState {
+  f32x16 dq[2];
+  f32x16 s[2], dp[2];   // [parity of the half]
+  f16x8 ds[2][2];       // [parity][16-key quarter]
+  f16x8 qf[3], dof[3];  // lane-owned Q (pre-scaled) and dO rows
+  f32x16 neg_lse, neg_delta;
+};
+template <int U, int PAR>
+__device__ __forceinline__ void dq_unit(DqState& st) {
+  constexpr int r = 2 * U;
+  const float d0 = fast_exp2(st.s[PAR][r]) * st.dp[PAR][r], d1 = fast_exp2(st.s[PAR][r + 1]) * st.dp[PAR][r + 1];
+  st.ds[PAR][r >> 3][r & 7] = (f16)d0;
+  st.ds[PAR][r >> 3][(r & 7) + 1] = (f16)d1;
+}
+template <int SLOT, int PAR>
+__device__ __forceinline__ void dq_slice(DqState& st) {  // 8 units over the 10 MFMA slots of a phase
+  if constexpr (SLOT == 0) dq_unit<0, PAR>(st);
+  else if constexpr (SLOT == 1) dq_unit<1, PAR>(st);
+  else if constexpr (SLOT == 2) dq_unit<2, PAR>(st);
+  else if constexpr (SLOT == 3) dq_unit<3, PAR>(st);
+  else if constexpr (SLOT == 5) dq_unit<4, PAR>(st);
+  else if constexpr (SLOT == 6) dq_unit<5, PAR>(st);
+  else if constexpr (SLOT == 8) dq_unit<6, PAR>(st);
+  else if constexpr (SLOT == 9) dq_unit<7, PAR>(st);
+}
+//   N = 0..3 (half k-1): (jj, d) = (N >> 1, N & 1): K^T fragment, transposing reads;   N = 4..9 (half k+1): (j, which) = ((N-4) >> 1, (N-4) & 1):
+//   which 0: K rows (S^T), 1: V rows (dP^T)
+template <int N, int KT>
+__device__ __forceinline__ f16x8 dq_fetch(uint32_t prev_tr, uint32_t next_rm) {
+  if constexpr (N < 4) {
+    constexpr int jj = N >> 1, d = N & 1;
+    constexpr int off = (KT * 32 + 16 * jj) * D_PCB + d * 64;
+    return join8(tr_read<off>(prev_tr), tr_read<off + 8 * D_PCB>(prev_tr));
+  } else {
+    constexpr int j = (N - 4) >> 1, which = (N - 4) & 1;
+    return rm_read(next_rm + (which ? D_TILE_B : 0) + KT * 32 * D_PCB + j * 32);
+  }
+}
+template <int N, int PAR>
+__device__ __forceinline__ void dq_mfma(DqState& st, const f16x8& a) {
+  constexpr int Q = PAR ^ 1;
+  if constexpr (N < 4) {
+    constexpr int jj = N >> 1, d = N & 1;
+    st.dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.ds[Q][jj], st.dq[d], 0, 0, 0);
+  } else {
+    constexpr int j = (N - 4) >> 1, which = (N - 4) & 1;
+    if constexpr (which == 0) st.s[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.qf[j], j == 0 ? st.neg_lse : st.s[Q], 0, 0, 0);
+    else st.dp[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.dof[j], j == 0 ? st.neg_delta : st.dp[Q], 0, 0, 0);
+  }
+}
+template <int N, int LO, int HI, int PAR, bool SM>
+__device__ __forceinline__ void dq_step(DqState& st, f16x8& a0, f16x8& a1, uint32_t prev_tr, uint32_t next_rm) {
+  if constexpr (N <= HI) {
+    constexpr int KT = PAR ^ 1;
+    f16x8 nxt;
+    if constexpr (N + 2 <= HI) nxt = dq_fetch<N + 2, KT>(prev_tr, next_rm);
+    if constexpr (N < 4) {
+      constexpr int later = ((N + 1 <= HI && N + 1 < 4) ? 2 : 0) + ((N + 2 <= HI && N + 2 < 4) ? 2 : 0);
+      frag_wait<later>(a0);
+    }
+    dq_mfma<N, PAR>(st, a0);
+    if constexpr (SM) dq_slice<N, PAR>(st);
+    SB();
+    a0 = a1;
+    if constexpr (N + 2 <= HI) a1 = nxt;
+    dq_step<N + 1, LO, HI, PAR, SM>(st, a0, a1, prev_tr, next_rm);
+  }
+}
+template <int PAR, bool PREV, bool NEXT, bool SM>
+__device__ __forceinline__ void dq_phase(DqState& st, uint32_t prev_tr, uint32_t next_rm) {
+  constexpr int LO = PREV ? 0 : 4, HI = NEXT ? 9 : 3, KT = PAR ^ 1;
+  f16x8 a0 = dq_fetch<LO, KT>(prev_tr, next_rm), a1 = dq_fetch<LO + 1, KT>(prev_tr, next_rm);
+  SB();
+  if constexpr (SM && LO > 0) {
+    dq_unit<0, PAR>(st); dq_unit<1, PAR>(st); dq_unit<2, PAR>(st); dq_unit<3, PAR>(st);
+    SB();
+  }
+  dq_step<LO, LO, HI, PAR, SM>(st, a0, a1, prev_tr, next_rm);
+  if constexpr (SM && HI < 9) {
+    dq_unit<4, PAR>(st); dq_unit<5, PAR>(st); dq_unit<6, PAR>(st); dq_unit<7, PAR>(st);
+    SB();
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_il_kernel(const tb_attn_desc p, int remap, int publish) {
+  constexpr int PC = 6, NI = 2 * PC, WI = NI / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Blk blk = block_of(remap);
+  const int b = blk.b, h = blk.h, hd = p.hd, Skv = p.Skv;
+  const int q = blk.x * 128 + wave * 32 + l31;
+  const int64_t ldk = p.ldk, ldv = p.ldv;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * hd;
+  const f16* dOg = (const f16*)p.dO + (int64_t)b * p.Sq * p.lddo + h * hd;
+  const char* Kg = (const char*)((const f16*)p.K + (int64_t)b * Skv * ldk + h * hd);
+  const char* Vg = (const char*)((const f16*)p.V + (int64_t)b * Skv * ldv + h * hd);
+  DqState st;
+  {
+    const float c = p.scale * LOG2E;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = 16 * j + 8 * hi;
+      const bool ok = col < hd;  // (Sq % 128 == 0: every query row exists)
+      st.qf[j] = *(ok ? (gvec8_t)(Qg + (int64_t)q * p.ldq + col) : (gvec8_t)g_zero8_il);
+      st.dof[j] = *(ok ? (gvec8_t)(dOg + (int64_t)q * p.lddo + col) : (gvec8_t)g_zero8_il);
+    }
+    const int64_t sidx = ((int64_t)b * p.H + h) * p.Sq + q;
+    const float lse2 = p.LSE[sidx] * LOG2E;
+    const f16* Og = (const f16*)p.O + (int64_t)b * p.Sq * p.ldo + h * hd;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = 16 * j + 8 * hi;
+      if (col < hd) {
+        const f16x8 ov = *(const f16x8*)(Og + (int64_t)q * p.ldo + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)ov[e] * (float)st.dof[j][e];
+      }
+    }
+    const float delta = a + __shfl_xor(a, 32, 64);
+    if (hi == 0) {
+      p.Delta[sidx] = delta;
+      if (publish) {
+        p.ws[sidx] = -lse2;
+        p.ws[(int64_t)p.B * p.H * p.Sq + sidx] = -delta;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st.qf[j][e] = (f16)((float)st.qf[j][e] * c);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st.neg_lse[r] = -lse2, st.neg_delta[r] = -delta, st.dq[0][r] = 0.f, st.dq[1][r] = 0.f;
+  }
+  uint32_t g_off[WI];
+  bool g_on[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave + 4 * i;
+    const int tensor = t >= PC ? 1 : 0;
+    const int f = (t - tensor * PC) * 64 + lane;
+    const int row = f / PC, cc = f - row * PC;
+    g_on[i] = cc < PC - 1;
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + cc * 16);
+  }
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * Q_STAGE_B;
+    const char* kb = Kg + (int64_t)tile * KVT * ldk * 2;
+    const char* vb = Vg + (int64_t)tile * KVT * ldv * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave + 4 * i;
+      const char* src = (t >= PC ? vb : kb) + g_off[i];
+      if (g_on[i]) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + t * 1024), 16, 0, 0);
+    }
+  };
+  for (int u = threadIdx.x; u < 2 * KVT * D_NST; u += 256) {  // pad chunks: zeros (finite)
+    const int s_ = u / (2 * KVT), r = u - s_ * 2 * KVT;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + s_ * Q_STAGE_B + (r >= KVT ? D_TILE_B : 0) + (r & (KVT - 1)) * D_PCB + (PC - 1) * 16) = z;
+  }
+  const int n = Skv / KVT;  // >= 2 (launcher)
+#pragma unroll
+  for (int t = 0; t < D_NST - 1; ++t)
+    if (t < n) stage_loads(t, t);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem_raw;
+  const uint32_t rm_lane = lds0 + l31 * D_PCB + hi * 16;
+  const int g4 = lane >> 4, j16 = lane & 15;
+  const uint32_t tr_lane = lds0 + (4 * (g4 >> 1) + (j16 >> 2)) * D_PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
+  auto sync = [&](int t) {
+    int later = n - 1 - t;
+    later = later > 1 ? 1 : later;
+    if (t == 0) later = n - 1 > 2 ? 2 : n - 1;
+    switch (later) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t >= 1 && t + 2 < n) stage_loads(t + 2, (t + 2) & 3);
+  };
+#define TR_OF(t) (tr_lane + ((t) & 3) * Q_STAGE_B)
+#define RM_OF(t) (rm_lane + ((t) & 3) * Q_STAGE_B)
+  sync(0);
+  dq_phase<1, false, true, false>(st, 0, RM_OF(0));
+  dq_phase<0, false, true, true>(st, 0, RM_OF(0));
+  for (int t = 0; t + 1 < n; ++t) {
+    sync(t + 1);
+    dq_phase<1, true, true, true>(st, TR_OF(t), RM_OF(t + 1));
+    dq_phase<0, true, true, true>(st, TR_OF(t), RM_OF(t + 1));
+  }
+  dq_phase<1, true, false, true>(st, TR_OF(n - 1), 0);
+  dq_phase<0, true, false, false>(st, TR_OF(n - 1), 0);
+#undef TR_OF
+#undef RM_OF
+  f16* dQg = (f16*)p.dQ + ((int64_t)b * p.Sq + q) * p.lddq + h * hd;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int col = d * 32 + 8 * r4 + 4 * hi;
+      if (col < hd) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(st.dq[d][4 * r4 + e] * p.scale);
+        *(f16x4*)(dQg + col) = v;
+      }
+    }
+}
+
 }  // namespace
+
+bool tb_attn_il_dq_ok(const tb_attn_desc& d) {
+  return !d.causal && d.hd == 40 && d.Sq % 128 == 0 && d.Skv % KVT == 0 && d.Skv >= 512 && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
+         (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31);
+}
+int tb_attn_il_dq(const tb_attn_desc& d, hipStream_t s, int remap, int publish) {
+  const size_t lds = D_NST * Q_STAGE_B;
+  hipLaunchKernelGGL(attn_bwd_dq_il_kernel, dim3(d.Sq / 128, d.H, d.B), dim3(256), lds, s, d, remap, publish);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
 
 bool tb_attn_il_dkv_ok(const tb_attn_desc& d) {
   return !d.causal && d.hd == 40 && d.Sq % KVT == 0 && d.Sq >= 2 * KVT && d.Skv % 128 == 0 && d.ws && d.ws_floats >= 2 * (int64_t)d.B * d.H * d.Sq &&

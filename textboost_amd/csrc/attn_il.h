@@ -7,3 +7,5 @@ bool tb_attn_il_fwd_ok(const tb_attn_desc& d);
 int tb_attn_il_fwd(const tb_attn_desc& d, hipStream_t s, int remap);
 bool tb_attn_il_dkv_ok(const tb_attn_desc& d);
 int tb_attn_il_dkv(const tb_attn_desc& d, hipStream_t s, int remap);
+bool tb_attn_il_dq_ok(const tb_attn_desc& d);
+int tb_attn_il_dq(const tb_attn_desc& d, hipStream_t s, int remap, int publish);
