@@ -88,7 +88,7 @@ def roofline_leg(step):
     # HBM traffic per launch of that kernel: PMC passes cannot run inside this process (separate rocprofv3 --pmc runs, FETCH_SIZE and
     # WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md); the committed summary of those passes (scratch/pmc_bench.sh ->
     # scratch/pmc_traffic.py) is quoted when it has the same kernel symbol
-    for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for pf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
             if name in pmc:

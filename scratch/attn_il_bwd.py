@@ -20,7 +20,7 @@ def bwd_check(B, H, S, hd=40, seed=1):
     ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd)
     do = torch.randn(B * S, C, device=dev).half()
     res = {}
-    for name, var in (("il", 1), ("dma", 1 | 2048 | 4096), ("reg", 1 | 128 | 256)):
+    for name, var in (("il", 1 | 4096), ("dma", 1 | 2048), ("reg", 1 | 128 | 256)):
         L.lib().tb_attention_set_variant(var)
         delta = torch.empty(B, H, S, device=dev)
         dqkv = torch.zeros(B * S, 3 * C, device=dev, dtype=torch.float16)
@@ -46,7 +46,7 @@ for fill in ("randn", "zeros"):
     do = (torch.randn(B * S, C, device=dev) if fill == "randn" else torch.zeros(B * S, C, device=dev)).half(); delta = torch.empty(B, H, S, device=dev)
     dqkv = torch.zeros(B * S, 3 * C, device=dev, dtype=torch.float16); ws = torch.empty(2 * B * H * S, device=dev)
     for rnd in range(2):
-        for name, var in (("il", 1), ("dma", 1 | 2048 | 4096)):
+        for name, var in (("il", 1 | 4096), ("dma", 1 | 2048)):
             L.lib().tb_attention_set_variant(var)
             t = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, ws=ws))
             print(f"{fill} round {rnd} {name:4s}: bwd {t:7.1f} us")

@@ -313,7 +313,7 @@ def test_attention_backward_software_pipelined_kernels(B, H, S):
     do = torch.randn(B * S, C, device="cuda").half()
     res = []
     old = L.lib().tb_attention_set_variant(1)
-    for bits in (1, 1 | 2048 | 4096):   # both pipelined kernels (dQ, dK/dV), then the LDS-DMA kernels they replace
+    for bits in (1 | 4096, 1 | 2048):   # both pipelined kernels (dQ is opt-in: bit 4096), then the LDS-DMA kernels
         L.lib().tb_attention_set_variant(bits)
         delta = torch.empty(B, H, S, device="cuda")
         dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16)

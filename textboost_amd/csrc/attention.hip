@@ -1508,6 +1508,8 @@ __global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __r
 }
 
 int g_attn_dma = 1;  // tb_attention_set_variant(bits): 1 = LDS-DMA staged forward kernel, 2 = also for hd 80, 4 = NO XCD-aware block remap,
+                     // 1024 / 2048 = LDS-DMA kernels instead of the software-pipelined forward / dK-dV kernels (attention_il.hip), 4096 = the
+                     // software-pipelined dQ kernel (opt-in),
                      // 32 = one query group per wave, 64 = XCD remap also in the backward kernels (measured: forward +14 %, backward -5 %)
                      // (A/B knobs; 8 / 16 = load-path ablations of the DMA kernel)
 
@@ -1603,7 +1605,8 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
       dq_dma = d.hd == (KS == 3 ? 40 : (KS == 4 ? 64 : 80)) && !(KS != 3 && (g_attn_dma & 512)) && !d.causal && d.Sq % 128 == 0 && d.Skv % KVT == 0 &&
                !(g_attn_dma & 256) && d.ldk % 8 == 0 && d.ldv % 8 == 0 &&
                (int64_t)KVT * (d.ldk > d.ldv ? d.ldk : d.ldv) * 2 < ((int64_t)1 << 31) && d.Skv >= 512;
-      if (dq_dma && DT == 2 && KS == 3 && !(g_attn_dma & 4096) && tb_attn_il_dq_ok(d)) {  // hd = 40: the software-pipelined kernel
+      if (dq_dma && DT == 2 && KS == 3 && (g_attn_dma & 4096) && tb_attn_il_dq_ok(d)) {  // hd = 40: the software-pipelined dQ kernel, opt-in
+        // (bit-equal results; PMC: 714 k cycles vs the LDS-DMA kernel's 697 k per launch at S = 4096, B = 8 -- no gain for this product mix)
         const int rc = tb_attn_il_dq(d, s, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
         if (rc) return rc;
       } else if (dq_dma) {
