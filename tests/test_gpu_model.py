@@ -482,3 +482,60 @@ def test_resume_from_checkpoint_is_bit_exact_under_an_lr_schedule(tmp_path):
     _, untouched, _ = build_step(B, hw, D)
     ratio = (ref.te.token_table[100] / untouched.te.token_table[100]).mean().item()
     assert abs(ratio - expect) < 1e-6 and abs(ratio - (1.0 - hp.emb_lr * hp.wd) ** 4) > 1e-7
+
+
+def test_split_text_encoder_schedule_equals_the_merged_one():
+    """round 3: instance rows / prior + teacher rows of the text encoder as concurrent branches beside the UNet (trainer `split_te`) against all
+    rows in one pass on the main stream: the same losses and the same gradients (row-wise arithmetic is identical; only the fp32 order of the
+    LoRA-gradient row sums and the two-buffer accumulation differ), eagerly and as a captured graph."""
+    B, hw, D = 2, 16, 64
+    res = {}
+    for split in (False, True):
+        _, step, added = build_step(B, hw, D)
+        assert step.merge_teacher
+        step.split_te = split
+        step.te_fwd_side = False
+        _fill_inputs(step, added, B, hw, seed=33)
+        step.forward_backward()
+        torch.cuda.synchronize()
+        res[split] = (step.flat_grad.clone(), step.state.clone(), step.d_all.clone())
+        if split:  # graph replay of the three-branch step == its eager run, bit for bit
+            _, st2, _ = build_step(B, hw, D)
+            st2.split_te = True
+            _fill_inputs(st2, added, B, hw, seed=33)
+            st2.capture(warmup=0)
+            st2.replay()
+            _, st3, _ = build_step(B, hw, D)
+            st3.split_te = True
+            _fill_inputs(st3, added, B, hw, seed=33)
+            st3.step_eager()
+            torch.cuda.synchronize()
+            for a, b in ((st2.flat_grad, st3.flat_grad), (st2.te.lora_A, st3.te.lora_A), (st2.te.token_table[49408:], st3.te.token_table[49408:]),
+                         (st2.state, st3.state)):
+                torch.testing.assert_close(a, b, rtol=0, atol=0)
+    (g0, s0, d0), (g1, s1, d1) = res[False], res[True]
+    torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-7)        # both losses
+    assert rel_err(d1, d0) < 1e-5, rel_err(d1, d0)                  # d ehs and d prior rows: the same arithmetic per row (tile choice may follow M)
+    assert rel_err(g1, g0) < 1e-5, rel_err(g1, g0)
+
+
+def test_encoder_forward_as_a_branch_beside_the_unet_head_is_bit_equal():
+    """`te_fwd_side` (opt-in A/B knob): the merged encoder forward on a second stream, joined in front of the hoisted K/V projection -- the same
+    kernels on the same data, so gradients and losses are bit-equal to the single-stream order, eagerly and replayed."""
+    B, hw, D = 2, 16, 64
+    res = []
+    for side, graph in ((False, False), (True, False), (True, True)):
+        _, step, added = build_step(B, hw, D)
+        assert step.merge_teacher and not step.te_fwd_side   # opt-in (measured slower: DESIGN section 4)
+        step.te_fwd_side = side
+        _fill_inputs(step, added, B, hw, seed=34)
+        if graph:
+            step.capture(warmup=0)
+            step.replay()
+        else:
+            step.step_eager()
+        torch.cuda.synchronize()
+        res.append((step.flat_grad.clone(), step.state.clone(), step.te.lora_A.clone(), step.te.token_table[49408:].clone()))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            torch.testing.assert_close(a, b, rtol=0, atol=0)

@@ -467,7 +467,7 @@ def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None, w2_fw
         gemm_f32_t(dt, x, dAv, P * r, K, M, a_trans=True, w_trans=True, R=dAv)
         return
     if ws is None:
-        key = (M, D, K, r, P, x.device)
+        key = (M, D, K, r, P, x.device, _ws_slot)  # one per concurrently running stream (workspace_slot)
         ws = _lora_ws.get(key)
         if ws is None:
             ws = _lora_ws[key] = torch.empty(int(L.lib().tb_lora_bwd_ws_floats(M, D, K, r, P)), device=x.device)

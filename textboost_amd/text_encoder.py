@@ -217,10 +217,14 @@ class HipTextEncoder:
         if self.n_added:
             self.grad_added.zero_()
 
-    def backward(self, d_out, slot=0, pins=True):
+    def backward(self, d_out, slot=0, pins=True, grads=None):
         """d_out: fp32 [B*T, D] gradient of the (scaled) loss w.r.t. forward(slot)'s output. Accumulates into
-        grad_A / grad_B / grad_added."""
+        grad_A / grad_B / grad_added -- or into `grads` = (grad_A, grad_B, grad_added) when given: two backward passes that run
+        CONCURRENTLY on two streams (the trainer's instance-prompt and prior-prompt chains) must not add into the same buffers.
+        All scratch is keyed by `slot` for the same reason."""
         assert self.mode in ("autocast", "fp32")
+        grad_A, grad_B, grad_added = grads if grads is not None else (self.grad_A if self.r else None, self.grad_B if self.r else None,
+                                                                      self.grad_added if self.n_added else None)
         full32 = self.mode == "fp32"
         geo, T = self.geo, self.T
         D, I, H = geo.hidden_size, geo.intermediate_size, geo.num_heads
@@ -230,14 +234,15 @@ class HipTextEncoder:
         M = ids.numel()
         B = M // T
         f16, f32 = self.op_dtype, torch.float32
+        gs = f"g{slot}."
         if pins:
             ops.pin_bwd(d_out, ids, B, T, self.use_fixed_special_embedding, EOS_ID)
         h_last = self._bufs[f"{s}l{geo.num_layers - 1}.h3"][:M]
-        dh = self.buf("g.dh_a", M, D, f32)
+        dh = self.buf(gs + "dh_a", M, D, f32)
         # fp16 copy of the running residual gradient, written by the LayerNorm backward (fp32 mode: the fp32 gradient itself feeds the GEMMs)
-        dh16 = None if full32 else self.buf("g.dh16", M, D, f16)
+        dh16 = None if full32 else self.buf(gs + "dh16", M, D, f16)
         ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh, dx16=dh16)
-        dh_other = self.buf("g.dh_b", M, D, f32)
+        dh_other = self.buf(gs + "dh_b", M, D, f32)
         for i in reversed(range(geo.num_layers)):
             W = self.Wl[i]
             p = f"{s}l{i}."
@@ -246,22 +251,22 @@ class HipTextEncoder:
             h2, pre, qkv, o = (self._bufs[p + n][:M] for n in ("h2", "pre", "qkv", "o"))
             lse = self._bufs[p + "lse"][:B * H]
             x1 = self._bufs[p + "x1"][:M]
-            dpre = self.buf("g.dpre", M, I, f16)
+            dpre = self.buf(gs + "dpre", M, I, f16)
             ops.gemm(dh if full32 else dh16, W["fc2.wd"], dpre, act=self.act_bwd, C2=pre)
-            dx2 = self.buf("g.dx", M, D, f16)
+            dx2 = self.buf(gs + "dx", M, D, f16)
             ops.gemm(dpre, W["fc1.wd"], dx2)
             dh2 = dh_other
             ops.layernorm_bwd(dx2, h2, W["ln2.g"], self._bufs[p + "ls2"], dh2, add=dh, dx16=dh16)
-            do = self.buf("g.do", M, D, f16)
+            do = self.buf(gs + "do", M, D, f16)
             ops.gemm(dh2 if full32 else dh16, W["out.wd"], do)
-            dqkv = self.buf("g.dqkv", M, 3 * D, f16)
-            delta = self.buf("g.delta", B * H, T, f32)
+            dqkv = self.buf(gs + "dqkv", M, 3 * D, f16)
+            delta = self.buf(gs + "delta", B * H, T, f32)
             ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, do, delta, dqkv[:, :D], dqkv[:, D:2 * D],
                               dqkv[:, 2 * D:], B, H, T, T, hd, causal=True)
-            dx1 = self.buf("g.dx", M, D, f16)
+            dx1 = self.buf(gs + "dx", M, D, f16)
             if self.r:
-                dt = self.buf("g.dt", M, 64, f16)
-                ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, self.grad_A[i], self.grad_B[i], D, D, self.r, 3,
+                dt = self.buf(gs + "dt", M, 64, f16)
+                ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, grad_A[i], grad_B[i], D, D, self.r, 3,
                              self.scaling, w2_fwd=self.w2_fwd[i])
                 ops.gemm(dqkv, W["qkv.wd"], dx1, A2=dt, W2=self.w2_dgrad[i])
             else:
@@ -269,5 +274,5 @@ class HipTextEncoder:
             ops.layernorm_bwd(dx1, h_in, W["ln1.g"], self._bufs[p + "ls1"], dh, add=dh2, dx16=dh16 if (i > 0 and not full32) else None)
             # dh (buffer a) now holds the gradient w.r.t. this layer's input; dh2 (buffer b) is free again
         if self.n_added:
-            ops.embed_bwd(dh, ids, self.grad_added, self.first_added)
+            ops.embed_bwd(dh, ids, grad_added, self.first_added)
         return dh

@@ -217,6 +217,25 @@ class TextBoostStep:
         # to the separate pass (TB_SEPARATE_TEACHER=1 keeps that pass).
         self.merge_teacher = self.kpl and text_encoder.r > 0 and os.environ.get("TB_SEPARATE_TEACHER", "0") != "1"
         self.teacher_table32 = teacher.token_table.float().contiguous() if self.merge_teacher else None
+        # Split text-encoder schedule (round 3): the encoder's ~250 launches per step are latency-bound (a fraction of one chip round each), and
+        # only the INSTANCE rows' forward feeds the UNet / only their backward waits for it.  The prior-prompt rows + the frozen teacher rows, the
+        # KPL loss and the prior rows' whole backward run as a second branch of the step graph beside the UNet (branches of one HIP graph do run
+        # concurrently on ROCm 7: scratch/graph_branches.py), and the instance rows' forward runs beside the UNet layers in front of the first
+        # cross-attention.  Gradients of the two backward passes go to separate buffers, summed once (fixed order: deterministic).
+        # Measured (scratch/ab_split.py, one process, one box): everything on the main stream 31.68-31.75 ms per step; the merged forward as a branch
+        # beside the UNet head 31.93-32.00 (+0.25); split with the four smaller passes serial 33.6-33.7 (+2.0: latency-bound launches do not get
+        # cheaper with fewer rows), branch P 32.04-32.16, both branches 31.97-32.07.  A latency-bound side chain hides only ~55 % of itself under
+        # the one-round UNet kernels (a side workgroup delays the tile that wanted its CU by its whole duration) and every fork / join of the graph
+        # costs a cross-stream dependency: both schedules are net LOSSES and stay opt-in (TB_SPLIT_TE=1, TB_TE_FWD_SIDE=1) as tested A/B knobs.
+        self.split_te = self.merge_teacher and os.environ.get("TB_SPLIT_TE", "0") == "1"
+        self.te_fwd_side = self.merge_teacher and os.environ.get("TB_TE_FWD_SIDE", "0") == "1"
+        if self.merge_teacher:  # (allocated whenever the split is possible, so that tests can toggle `split_te` on one object)
+            prio = int(os.environ.get("TB_SIDE_PRIORITY", "0"))
+            self.side2 = torch.cuda.Stream(device=device, priority=prio)
+            self.side = torch.cuda.Stream(device=device, priority=prio)
+            self.flat_grad_p = torch.zeros(nA + nB + nE, device=device)
+            self.grads_p = ((self.flat_grad_p[:nA].view_as(te.lora_A), self.flat_grad_p[nA:nA + nB].view_as(te.lora_B)) if has_lora else (None, None)) \
+                + (self.flat_grad_p[nA + nB:].view(te.n_added, D),)
         self.vae = None  # attach_vae(): the step then starts from pixels (:1027-1037) instead of latents
         self.lr_table = None  # set_lr_table(): lambda(k) of --lr_scheduler on the device, indexed by the successful-step count
 
@@ -240,13 +259,14 @@ class TextBoostStep:
         self.timesteps.random_(0, self.hp.num_train_timesteps, generator=self.gen)
 
     # the step body in four phases; `forward_backward` runs them in the reference's order on one stream (teacher on a forked side stream)
-    def _phase_student(self):
+    def _phase_student(self, encoder_only=False):
         hp, te, B = self.hp, self.te, self.B
-        if self.vae is not None:
-            self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))                  # :1027-1037
-        ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
-        te.pack_lora()
-        self.unet.pack_kv_lora()
+        if not encoder_only:
+            if self.vae is not None:
+                self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))              # :1027-1037
+            ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
+            te.pack_lora()
+            self.unet.pack_kv_lora()
         if self.merge_teacher:
             nb = self.ids_all.shape[0]
             out = te.forward(self.ids_all, slot=0, extra_ids=self.prior_ids, extra_table=self.teacher_table32)
@@ -280,9 +300,69 @@ class TextBoostStep:
             gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
             gB[:, :, (1 if hp.mixing == "object" else 0)::2, :].zero_()
 
-    def forward_backward(self):
-        self._phase_student()
+    def _forward_backward_split(self):
+        """the step body with the text encoder split over three branches (see `split_te` in __init__)"""
+        hp, te, B, st = self.hp, self.te, self.B, self.state
+        BT = B * te.T
         main = torch.cuda.current_stream()
+        if self.vae is not None:
+            self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))                  # :1027-1037
+        ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
+        te.pack_lora()
+        self.unet.pack_kv_lora()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        # branch P: prior prompts through the trainable encoder (:1099) + the frozen teacher on the same prompts (:1096-1100), the KPL loss
+        # (:1101-1106) and the backward of its term -- nothing here touches the UNet
+        conc = getattr(self, "split_conc", 3)   # A/B knob: bit 0 = branch P on its own stream, bit 1 = branch I on its own stream
+        sP = self.side if conc & 1 else main
+        sI = self.side2 if conc & 2 else main
+        sP.wait_event(fork)
+        with torch.cuda.stream(sP), ops.workspace_slot(1):
+            out = te.forward(self.prior_ids, slot=1, extra_ids=self.prior_ids, extra_table=self.teacher_table32)
+            self.h_prior, self.h_teacher = out[:BT], out[BT:]
+            kpl = ops.kpl_cos if hp.kpl_type == "cos" else ops.kpl_mse
+            kpl(self.h_prior, self.h_teacher, self.d_prior, self.kpl_partial, st[L.ST_LOSS_KPL:], st[L.ST_LOSS_SCALE:], hp.kpl_weight)
+            self.flat_grad_p.zero_()
+            te.backward(self.d_prior, slot=1, grads=self.grads_p)
+        # branch I: instance prompts -> encoder_hidden_states (:1054-1059), beside the UNet layers in front of the first cross-attention
+        sI.wait_event(fork)
+        with torch.cuda.stream(sI), ops.workspace_slot(2):
+            self.h_inst = te.forward(self.input_ids, slot=0)
+            ops.convert(self.h_inst, self.ehs16)                                                  # .to(unet.dtype) :1066
+        self.pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16, ehs_ready=lambda: main.wait_stream(sI))
+        main.wait_stream(sI)
+        self._phase_unet_backward()
+        te.backward(self.d_ehs, slot=0)
+        main.wait_stream(sP)
+        n = self.flat_grad_p.numel()
+        ops.add_f16(self.flat_grad[:n].view(1, n), self.flat_grad_p.view(1, n), self.flat_grad[:n].view(1, n))
+        if hp.mixing is not None and te.r:  # :1119-1126
+            gB = te.grad_B.view(te.geo.num_layers, 3, te.geo.hidden_size, te.r)
+            gB[:, :, (1 if hp.mixing == "object" else 0)::2, :].zero_()
+
+    def forward_backward(self):
+        if self.split_te:
+            return self._forward_backward_split()
+        main = torch.cuda.current_stream()
+        if self.te_fwd_side:
+            # the encoder forward as a graph branch beside the UNet layers in front of the first cross-attention (conv_in, the first ResNet block,
+            # the first self-attention: ~0.75 ms of chip-filling kernels next to ~90 latency-bound launches); joined by `ehs_ready`
+            if self.vae is not None:
+                self.x0.copy_(self.vae.encode(self.pixel_values, noise=self.vae_eps))              # :1027-1037
+            ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
+            self.te.pack_lora()
+            self.unet.pack_kv_lora()
+            self.side2.wait_stream(main)
+            with torch.cuda.stream(self.side2), ops.workspace_slot(2):
+                self._phase_student(encoder_only=True)
+            self.pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16, ehs_ready=lambda: main.wait_stream(self.side2))
+            main.wait_stream(self.side2)
+            self._phase_teacher()
+            self._phase_unet_backward()
+            self._phase_encoder_backward()
+            return
+        self._phase_student()
         fork = None
         if self.kpl:
             fork = torch.cuda.Event()

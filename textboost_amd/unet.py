@@ -350,6 +350,7 @@ class HipUNet:
         ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
         q2 = self.buf(prefix + ".q2", M, C)
         ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
+        self._ensure_kv()
         ko = self.kv_off[tb + ".attn2"]
         k2, v2 = self.kv_all[:, ko:ko + C], self.kv_all[:, ko + C:ko + 2 * C]
         o2 = self.buf(prefix + ".o2", M, C)
@@ -414,7 +415,24 @@ class HipUNet:
         return bwd, stop_after_cross
 
     # ------------------------------------------------------------------ forward
-    def forward(self, sample, timesteps, ehs16):
+    def _ensure_kv(self):
+        if self._kv_pending is None:
+            return
+        (ehs16, ehs_ready), self._kv_pending = self._kv_pending, None
+        if ehs_ready is not None:
+            ehs_ready()   # e.g. torch.cuda.current_stream().wait_stream(text-encoder stream)
+        B, P = self.B, self.P
+        if getattr(self, "kv_r", 0):  # adapters: kv = ehs W^T + (ehs A_all^T) W2^T, W2 = block-structured scaling * B (pack_kv_lora)
+            n2r = self.kv_w2.shape[1]
+            self.kv_t = self.buf("kv_t", B * self.T, n2r)
+            ops.gemm(ehs16, self.kv_lora_A.view(n2r, -1), self.kv_t)
+            ops.gemm(ehs16, P["kv_all.w"], self.kv_all, A2=self.kv_t, W2=self.kv_w2)
+        else:
+            ops.gemm(ehs16, P["kv_all.w"], self.kv_all)
+
+    def forward(self, sample, timesteps, ehs16, ehs_ready=None):
+        """ehs_ready: optional callable run right before the first kernel that reads `ehs16` (the hoisted K/V projection, in front of the first
+        cross-attention): lets the caller produce `ehs16` on another stream while the layers in front of it already run."""
         geo, B, P = self.geo, self.B, self.P
         ch = geo.block_out_channels
         nl = len(ch)
@@ -431,16 +449,11 @@ class HipUNet:
         ops.gemm(te1, P["time_embedding.linear_2.w"], te2, bias=P["time_embedding.linear_2.b"], act=L.ACT_SILU)  # silu(temb)
         self.rowbias = self.buf("temb.rowbias", B, self.temb_total, torch.float32)
         ops.gemm(te2, P["temb_all.w"], self.rowbias, bias=P["temb_all.b"])
-        # ---- hoisted cross-attention K/V projections of the text states
+        # ---- hoisted cross-attention K/V projections of the text states: issued by `_ensure_kv` in front of the first cross-attention, the
+        # first consumer of `ehs16` -- so that a caller whose text encoder still runs on another stream (`ehs_ready`) joins as late as possible
         self.kv_all = self.buf("kv_all", B * self.T, self.kv_total)
         self.dkv_all = self.buf("dkv_all", B * self.T, self.kv_total)
-        if getattr(self, "kv_r", 0):  # adapters: kv = ehs W^T + (ehs A_all^T) W2^T, W2 = block-structured scaling * B (pack_kv_lora)
-            n2r = self.kv_w2.shape[1]
-            self.kv_t = self.buf("kv_t", B * self.T, n2r)
-            ops.gemm(ehs16, self.kv_lora_A.view(n2r, -1), self.kv_t)
-            ops.gemm(ehs16, P["kv_all.w"], self.kv_all, A2=self.kv_t, W2=self.kv_w2)
-        else:
-            ops.gemm(ehs16, P["kv_all.w"], self.kv_all)
+        self._kv_pending = (ehs16, ehs_ready)
         # ---- concat buffers of the up path (hidden part first, skip part second)
         skip_level = [0]
         for i in range(nl):
