@@ -26,7 +26,14 @@ typedef void* tb_stream_t; /* hipStream_t */
 /* ---- dtype / activation codes ------------------------------------------------------------- */
 enum { TB_F16 = 0, TB_F32 = 1 };
 enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2, TB_ACT_SILU = 3, TB_ACT_QUICK_GELU_GRAD = 4, TB_ACT_GELU = 5,
-       TB_ACT_GELU_GRAD = 6, TB_ACT_GEGLU_GRAD = 7 };
+       TB_ACT_GELU_GRAD = 6, TB_ACT_GEGLU_GRAD = 7,
+       /* LayerNorm fused into the epilogue of a Linear whose tile spans the whole output row (N = 320: the 64x64-map transformer blocks of
+        * diffusers BasicTransformerBlock, train_textboost.py:1063-1067 / :1108); only where tb_gemm_ln_epilogue_ok() says so:
+        *   LN_FWD: t = alpha*acc + bias + R -> C (fp16);  ln_stats[m] = (mean, rstd) of the fp16 row t;  C2 = fp16 LN(t) = (t - mean) rstd ln_gamma + ln_beta
+        *           (the producer of the residual stream writes the next layer's normalised input: no tb_layernorm_fwd launch, t is not re-read)
+        *   LN_BWD: g = (alpha*acc) ln_gamma, xhat = (C2[m,n] - mean) rstd with (mean, rstd) = ln_stats[m] (READ), C2 = the LayerNorm's fp16 INPUT (READ);
+        *           C = fp16( rstd (g - mean_n g - xhat mean_n(g xhat)) + R )  -- tb_layernorm_bwd applied to the dgrad GEMM's fp32 accumulators */
+       TB_ACT_LN_FWD = 8, TB_ACT_LN_BWD = 9 };
 enum { TB_A_LINEAR = 0, TB_A_CONV3X3 = 1 };
 
 /* ---- MFMA GEMM family: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), fp16 in, fp32 accumulate ------
@@ -64,9 +71,16 @@ typedef struct tb_gemm_desc {
                                   * GEGLU_GRAD: packed pre-gate [M,2N], READ; C becomes d(proj) [M,2N] fp16 (packed) */
   void* ws; int64_t ws_bytes;    /* optional scratch: lets small-M / long-K problems split K over blocks (fp32 partials,
                                   * fixed-order reduction => deterministic); NULL disables */
+  /* TB_ACT_LN_FWD / TB_ACT_LN_BWD only (torch.nn.LayerNorm of BasicTransformerBlock fused into the neighbouring Linear) */
+  const float* ln_gamma; const float* ln_beta; /* fp32 [N]; ln_beta unused by LN_BWD */
+  float* ln_stats;               /* fp32 [M, 2] (mean, rstd): written by LN_FWD, read by LN_BWD */
+  float ln_eps;
 } tb_gemm_desc;
 
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
+/* 1 when a fp16 Linear of this shape takes a tile that spans the whole output row, i.e. TB_ACT_LN_FWD / TB_ACT_LN_BWD are available for it
+ * (N == 320, K % 64 == 0, M a multiple of the tile height with at least one chip round of tiles); tb_gemm returns -22 for them otherwise */
+int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K);
 /* tuning knob for the k-tile / pipeline-depth variant of tb_gemm (returns the previous value); 0 is the default */
 int tb_gemm_set_variant(int v);
 /* {BM, BN, a_mode, k_tile*10 + stages, split_k} of the most recent tb_gemm launch (profiling aid) */

@@ -278,3 +278,75 @@ def test_conv3x3_wide_tile_split_k(B, Cin, Cout, H):
     L.lib().tb_gemm8_set(default_bits)
     refd = nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1))
     assert rel_err(dx.view(B, H, H, Cin), refd) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,res", [(32768, 320, True), (32768, 960, False), (16384, 320, True), (25600, 640, True)])
+def test_layernorm_fused_into_the_linear_epilogue_forward(M, K, res):
+    """TB_ACT_LN_FWD (round 3): the Linear that produces the residual stream also writes LayerNorm(row) and its statistics -- against
+    torch.nn.functional.layer_norm of the fp16 row it stored, and against the separate tb_layernorm_fwd launch.  128 x 320 tiles (M / 128 >= 200)
+    and 64 x 320 tiles; with and without residual; strided outputs."""
+    from parity import parity
+    ops, L = _ops()
+    torch.manual_seed(3)
+    N = 320
+    assert ops.gemm_ln_ok(M, N, K) and not ops.gemm_ln_ok(4096, N, K) and not ops.gemm_ln_ok(M, 640, K)
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    bias = torch.randn(N, device="cuda")
+    R = (torch.randn(M, N, device="cuda") * 2 + 0.5).half() if res else None
+    gamma, beta = torch.randn(N, device="cuda") * 0.5 + 1, torch.randn(N, device="cuda") * 0.1
+    tbuf = torch.zeros(M, N + 8, device="cuda", dtype=torch.float16)
+    t, y = tbuf[:, :N], torch.empty(M, N, device="cuda", dtype=torch.float16)
+    stats = torch.empty(M, 2, device="cuda")
+    ops.gemm(A, W, t, bias=bias, R=R, ln_fwd=(gamma, beta, stats, y, 1e-5))
+    # the Linear itself
+    t_ref = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    ops.gemm(A, W, t_ref, bias=bias, R=R)
+    assert torch.equal(t, t_ref) and tbuf[:, N:].abs().max() == 0
+    # statistics and the normalised row, from the stored fp16 row
+    tf = t.float()
+    mean, var = tf.mean(1), tf.var(1, unbiased=False)
+    torch.testing.assert_close(stats[:, 0], mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[:, 1], torch.rsqrt(var + 1e-5), rtol=1e-5, atol=0)
+    parity("fused LN forward vs torch", y, F.layer_norm(tf, (N,), gamma, beta, 1e-5), rel=6e-4, maxabs=1e-3, ch_dim=1, ch_rel=1e-3)
+    y2, st2 = torch.empty_like(y), torch.empty_like(stats)
+    ops.layernorm_fwd(t_ref, y2, gamma, beta, st2)
+    torch.testing.assert_close(stats, st2, rtol=1e-5, atol=1e-5)
+    assert (y.float() - y2.float()).abs().max().item() <= 2e-3 * y2.float().abs().max().item()   # one fp16 ulp where a value sits on a rounding edge
+
+
+@pytest.mark.parametrize("M,K,res", [(32768, 320, True), (32768, 2560, True), (16384, 960, False)])
+def test_layernorm_backward_fused_into_the_dgrad_epilogue(M, K, res):
+    """TB_ACT_LN_BWD: dx = LN'(dy = A W^T) + add on the GEMM's accumulators, against torch autograd of layer_norm on the same operands."""
+    from parity import parity
+    ops, L = _ops()
+    torch.manual_seed(4)
+    N = 320
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    x = (torch.randn(M, N, device="cuda") * 1.5 + 0.3).half()
+    add = torch.randn(M, N, device="cuda").half() if res else None
+    gamma, beta = torch.randn(N, device="cuda") * 0.5 + 1, torch.zeros(N, device="cuda")
+    y, stats = torch.empty_like(x), torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, y, gamma, beta, stats)
+    dx = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    ops.gemm(A, W, dx, R=add, ln_bwd=(gamma, stats, x))
+    xr = x.float().requires_grad_(True)
+    dy = A.float() @ W.float().T
+    F.layer_norm(xr, (N,), gamma, beta, 1e-5).backward(dy)
+    ref = xr.grad + (add.float() if res else 0)
+    parity("fused LN backward vs torch autograd", dx, ref, rel=6e-4, maxabs=1.5e-3, ch_dim=1, ch_rel=1e-3)
+    # and the two-launch path it replaces (dy rounded to fp16 in between)
+    dy16, dx2 = torch.empty(M, N, device="cuda", dtype=torch.float16), torch.empty_like(dx)
+    ops.gemm(A, W, dy16)
+    ops.layernorm_bwd(dy16, x, gamma, stats, dx2, add=add)
+    parity("fused LN backward vs gemm + tb_layernorm_bwd", dx, dx2, rel=1e-3, maxabs=3e-3)
+
+
+def test_layernorm_epilogue_is_refused_where_no_tile_spans_the_row():
+    ops, L = _ops()
+    A, W = torch.randn(4096, 320, device="cuda").half(), torch.randn(320, 320, device="cuda").half()
+    out, y, st = torch.empty(4096, 320, device="cuda", dtype=torch.float16), torch.empty(4096, 320, device="cuda", dtype=torch.float16), torch.empty(4096, 2, device="cuda")
+    g = torch.ones(320, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, W, out, ln_fwd=(g, g, st, y, 1e-5))

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libtextboost_hip" + os.environ.get("TB_LIB_SUFFIX
 
 TB_F16, TB_F32 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD, ACT_GELU, ACT_GELU_GRAD, ACT_GEGLU_GRAD = 0, 1, 2, 3, 4, 5, 6, 7
+ACT_LN_FWD, ACT_LN_BWD = 8, 9
 (ST_LOSS_SCALE, ST_GROWTH_TRACKER, ST_STEP, ST_FOUND_INF, ST_COEF_LORA, ST_COEF_EMB, ST_BC1, ST_BC2, ST_GRAD_NORM,
  ST_SUMSQ_LORA, ST_SUMSQ_EMB, ST_LOSS_MSE, ST_LOSS_KPL, ST_LR_MULT) = range(14)
 ST_COUNT = 16
@@ -37,6 +38,7 @@ class GemmDesc(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int32),
         ("C2", C.c_void_p), ("ldc2", C.c_int64),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -64,6 +66,7 @@ _lib = None
 _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
+    "tb_gemm_ln_epilogue_ok": ([C.c_int64, C.c_int64, C.c_int64], C.c_int),
     "tb_last_hip_error": ([], C.c_char_p),
     "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_gemm_last_config": ([_VP], None),

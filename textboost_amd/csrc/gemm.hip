@@ -975,7 +975,7 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if (d.rowbias && d.ldrb < d.N) d.ldrb = d.N;
   if ((d.act == TB_ACT_QUICK_GELU_GRAD || d.act == TB_ACT_GELU_GRAD || d.act == TB_ACT_GEGLU_GRAD) && !d.C2) return TB_EINVAL;
   if (d.act == TB_ACT_GEGLU_GRAD && (d.N % 32 || d.c_dtype != TB_F16)) return TB_EINVAL;
-  if (d.act < 0 || d.act > TB_ACT_GEGLU_GRAD) return TB_EINVAL;
+  if (d.act < 0 || d.act > TB_ACT_LN_BWD) return TB_EINVAL;
   if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;
     if (d.M != (int64_t)d.B * d.Hout * d.Wout) return TB_EINVAL;
@@ -995,6 +995,7 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     }
     if (r8 != 1) return r8;
   }
+  if (d.act == TB_ACT_LN_FWD || d.act == TB_ACT_LN_BWD) return TB_EINVAL;  // exist in the row-spanning wide tiles only
   if (d.act == TB_ACT_GEGLU) {
     if (d.N % 128 || d.R || d.rowbias || d.c_dtype != TB_F16) return TB_EINVAL;
     if (d.a_mode != TB_A_LINEAR) return TB_EINVAL;

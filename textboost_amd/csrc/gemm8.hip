@@ -158,6 +158,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   float* const bias_s = reinterpret_cast<float*>(smem_raw + (OPB > EPB ? OPB : EPB));
   float bias_v = 0.f;
   if (!CONV && t < BN && p.bias) bias_v = p.bias[n0 + t];
+  // fused-LayerNorm epilogues (TB_ACT_LN_FWD / TB_ACT_LN_BWD; host: the tile spans the row, n0 == 0): gamma / beta take the same route
+  const bool ln_epi = !CONV && (p.act == TB_ACT_LN_FWD || p.act == TB_ACT_LN_BWD);
+  float gam_v = 0.f, bet_v = 0.f;
+  if (ln_epi && t < BN) {
+    gam_v = p.ln_gamma[n0 + t];
+    if (p.act == TB_ACT_LN_FWD) bet_v = p.ln_beta[n0 + t];
+  }
   // epilogue unit geometry (used early by the residual prefetch): a thread keeps ONE 8-column group and walks rows
   using E = G8Epi<BM, BN>;
   constexpr int LDC = E::LDC, PASSES = E::PASSES, PR = E::PR;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
     }
   } else if (PRE_R) {
-    if (p.R && p.ldr % 8 == 0 && ((uintptr_t)p.R) % 16 == 0 && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) && rslot < TPR) {
+    if (p.R && p.ldr % 8 == 0 && ((uintptr_t)p.R) % 16 == 0 && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU || ln_epi) && rslot < TPR) {
 #pragma unroll
       for (int it = 0; it < NU; ++it) {
         const int64_t m = min(m0 + min(rslot + it * TPR, PR - 1), p.M - 1);
@@ -327,7 +334,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   }
   if (NS == 2) cnt_prev = 0;
   wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
-  if (!CONV && t < BN) bias_s[t] = bias_v;
+  if (!CONV && t < BN) {
+    bias_s[t] = bias_v;
+    if (ln_epi) bias_s[BN + t] = gam_v, bias_s[2 * BN + t] = bet_v;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave
   G8_STAMP(1)
 
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     return;
   }
   const EpiFlags ef = epi_flags(p);
-  const bool pre_r = PRE_R && p.R && ef.r_vec && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU);
+  const bool pre_r = PRE_R && p.R && ef.r_vec && p.r_dtype == TB_F16 && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU || ln_epi);
   if (!CONV && p.act != TB_ACT_GEGLU) {
     const f32x4_t u0 = *(const f32x4_t*)(bias_s + cg * 8), u1 = *(const f32x4_t*)(bias_s + cg * 8 + 4);
 #pragma unroll
@@ -608,6 +618,202 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
     return;
   }
+  // LayerNorm fused into the epilogue (Linear tiles that span the output row: BN == N == 320, one 64-row staging pass at a time).
+  // Row statistics need all 40 column groups of a row, which sit in 40 different threads: partial sums go through `red` (one float2 per
+  // (row, column group)), 8 threads per row add them (five each, then three shuffles), results come back through `rowst`.
+  //   LN_FWD: the row written to C is normalised as well: two-pass statistics (mean, then centred squares) over the fp16-ROUNDED outputs,
+  //           exactly the values tb_layernorm_fwd would read back; C2 = LN(row), ln_stats[m] = (mean, rstd).
+  //   LN_BWD: tb_layernorm_bwd on the accumulators: g = acc * gamma, xhat from C2 (the LayerNorm's input) and ln_stats.
+  if constexpr (!CONV && (PR == 64 || PR == 32) && BN == 320) {
+    if (ln_epi) {
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      const bool fwd = p.act == TB_ACT_LN_FWD;
+      const float alpha = p.alpha, inv_n = 1.f / (float)BN, eps = p.ln_eps;
+      f16* const Cg = (f16*)p.C + n;
+      const f16* const Rg = p.R ? (const f16*)p.R + n : nullptr;
+      f16* const C2g = (f16*)p.C2 + n;
+      const int64_t ldc = p.ldc, ldr = p.ldr, ldc2 = p.ldc2, Mtot = p.M;
+      float* const stats_g = p.ln_stats;
+      f32x2_t* const red = reinterpret_cast<f32x2_t*>(smem_raw + EPB);   // [PR][UPR]
+      f32x2_t* const rowst = red + PR * UPR;                             // [PR]
+      float gm[8], bt[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gm[e] = bias_s[BN + cg * 8 + e], bt[e] = bias_s[2 * BN + cg * 8 + e];
+      const int rrow = t >> 3, rj = t & 7;  // reducer role: row (threads with rrow >= PR sit out: whole waves), five-partial slice
+      auto reduce_rows = [&](bool second) {  // sums the UPR partials of every row; leaves (x, y) totals in all 8 lanes of the row's group
+        f32x2_t a = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < UPR / 8; ++k) {
+          const f32x2_t v = red[rrow * UPR + rj * (UPR / 8) + k];
+          a[0] += v[0], a[1] += v[1];
+        }
+#pragma unroll
+        for (int sft = 1; sft < 8; sft <<= 1) {
+          a[0] += __shfl_xor(a[0], sft, 64);
+          a[1] += __shfl_xor(a[1], sft, 64);
+        }
+        (void)second;
+        return a;
+      };
+      f16x8 rv1[NU];
+      if (PASSES == 2 && Rg && rslot < TPR) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const int64_t m = min(m0 + PR + min(rslot + it * TPR, PR - 1), Mtot - 1);
+          rv1[it] = *(const f16x8*)(Rg + m * ldr);
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int rp = pass * PR;
+        if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              *(f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15 - rp) * LDC + (wn * NT + j) * 16 + 4 * lq) = acc[i][j];
+        }
+        f16x8 rv[NU], xv[NU];
+        f32x2_t st[NU];
+        if (rslot < TPR) {
+#pragma unroll
+          for (int it = 0; it < NU; ++it) {
+            const int64_t m = min(m0 + rp + min(rslot + it * TPR, PR - 1), Mtot - 1);
+            if (pass == 1 || pre_r) rv[it] = pass ? rv1[it] : rv0[PRE_R ? it : 0];
+            else if (Rg) rv[it] = *(const f16x8*)(Rg + m * ldr);
+            if (!fwd) {
+              xv[it] = *(const f16x8*)(C2g + m * ldc2);
+              st[it] = *(const f32x2_t*)(stats_g + 2 * m);
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (fwd) {
+          f16x8 o[NU];
+          // ---- phase 1: the output row (stored), partial row sums of the rounded values
+          if (rslot < TPR) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+              const int row = rslot + it * TPR;
+              const int64_t m = m0 + rp + row;
+              if (row < PR) {
+                const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  float x = (e < 4 ? c0[e] : c1[e - 4]) * alpha + b8[e];
+                  if (Rg) x += (float)rv[it][e];
+                  o[it][e] = (f16)x;
+                  sum += (float)o[it][e];
+                }
+                if (m < Mtot) *(f16x8*)(Cg + m * ldc) = o[it];
+                red[row * UPR + cg] = f32x2_t{sum, 0.f};
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (rrow < PR) {
+            const f32x2_t a = reduce_rows(false);
+            if (rj == 0) rowst[rrow] = f32x2_t{a[0] * inv_n, 0.f};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          // ---- phase 2: centred squares
+          if (rslot < TPR) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+              const int row = rslot + it * TPR;
+              if (row < PR) {
+                const float mean = rowst[row][0];
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float d = (float)o[it][e] - mean;
+                  q += d * d;
+                }
+                red[row * UPR + cg] = f32x2_t{q, 0.f};
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (rrow < PR) {
+            const f32x2_t a = reduce_rows(true);
+            if (rj == 0) {
+              const float mean = rowst[rrow][0], rstd = rsqrtf(a[0] * inv_n + eps);
+              rowst[rrow] = f32x2_t{mean, rstd};
+              const int64_t m = m0 + rp + rrow;
+              if (m < Mtot) *(f32x2_t*)(stats_g + 2 * m) = f32x2_t{mean, rstd};
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          // ---- phase 3: the normalised row
+          if (rslot < TPR) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+              const int row = rslot + it * TPR;
+              const int64_t m = m0 + rp + row;
+              if (row < PR && m < Mtot) {
+                const f32x2_t ms = rowst[row];
+                f16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (f16)(((float)o[it][e] - ms[0]) * ms[1] * gm[e] + bt[e]);
+                *(f16x8*)(C2g + m * ldc2) = y;
+              }
+            }
+          }
+        } else {
+          // ---- phase 1: partial sums of g and g * xhat
+          if (rslot < TPR) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+              const int row = rslot + it * TPR;
+              if (row < PR) {
+                const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float g = (e < 4 ? c0[e] : c1[e - 4]) * alpha * gm[e];
+                  const float xh = ((float)xv[it][e] - st[it][0]) * st[it][1];
+                  s1 += g;
+                  s2 += g * xh;
+                }
+                red[row * UPR + cg] = f32x2_t{s1, s2};
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (rrow < PR) {
+            const f32x2_t a = reduce_rows(false);
+            if (rj == 0) rowst[rrow] = f32x2_t{a[0] * inv_n, a[1] * inv_n};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          // ---- phase 2: dx = rstd (g - mean g - xhat mean(g xhat)) + add
+          if (rslot < TPR) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+              const int row = rslot + it * TPR;
+              const int64_t m = m0 + rp + row;
+              if (row < PR && m < Mtot) {
+                const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
+                const f32x2_t ss = rowst[row];
+                f16x8 dx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float g = (e < 4 ? c0[e] : c1[e - 4]) * alpha * gm[e];
+                  const float xh = ((float)xv[it][e] - st[it][0]) * st[it][1];
+                  float v = st[it][1] * (g - ss[0] - xh * ss[1]);
+                  if (Rg) v += (float)rv[it][e];
+                  dx[e] = (f16)v;
+                }
+                *(f16x8*)(Cg + m * ldc) = dx;
+              }
+            }
+          }
+        }
+        if (pass + 1 < PASSES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      return;
+    }
+  }
   if (fast) {
     const float alpha = p.alpha;
     const bool silu = p.act == TB_ACT_SILU;
@@ -683,6 +889,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
     return;
   }
+  if (ln_epi) __builtin_trap();  // (unreachable: every tile the host routes LN epilogues to has the block above)
   // ---- generic path (fp32 output / residual, GELU variants, unaligned rows): rolled loops around the shared epilogue8
 #pragma unroll 1
   for (int pass = 0; pass < PASSES; ++pass) {
@@ -748,7 +955,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   if (CONV && (a_rows8 >> 3) > 8 * 7) return 1;  // more panel load instructions than the kernel issues
   size_t lds = (size_t)(CONV ? 2 : NS) * a_rows8 * 128 + (size_t)NS * BN * 128;
   if (lds < G8Epi<BM, BN>::BYTES) lds = G8Epi<BM, BN>::BYTES;
-  if (!CONV) lds += BN * 4;  // the tile's bias values
+  if (!CONV) lds += BN * 12;  // the tile's bias values (+ LayerNorm gamma / beta of the fused-LN epilogues)
   if (lds > 160 * 1024) return 1;
   static bool attr_done = false;
   if (!attr_done) {
@@ -799,6 +1006,13 @@ extern "C" int tb_gemm8_last(int* out5 /* 6 ints */) {
   return g8_last[0];
 }
 
+extern "C" int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K) {
+  if (N != 320 || K <= 0 || K % 64 || M <= 0) return 0;
+  if (M % 128 == 0 && M / 128 >= 200) return 1;  // 128 x 320 tiles
+  if (M % 64 == 0 && M / 64 >= 200) return 1;    // 64 x 320 tiles
+  return 0;
+}
+
 // returns TB_OK when the launch was taken, 1 when the shape is not covered (the caller falls back to gemm.hip), < 0 on error
 int tb_gemm8_last_split() { return g8_split; }  // k-slices of the launch tb_gemm8_try just made (> 1: partials are in d.ws, reducer due)
 
@@ -813,6 +1027,13 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     if (d.C2 && (d.ldc2 % 8 || ((uintptr_t)d.C2) % 16)) return 1;
     if (d.act == TB_ACT_GEGLU && (d.N % 640 || ((uintptr_t)d.C) % 16)) return 1;       // whole [h32 | g32] blocks per 320-wide tile
     if (d.act == TB_ACT_GEGLU_GRAD && (!d.C2 || d.N % 32 || d.bias)) return 1;
+  }
+  const bool ln_act = d.act == TB_ACT_LN_FWD || d.act == TB_ACT_LN_BWD;
+  if (ln_act) {  // only the row-spanning Linear tiles implement these: anything else is the caller's error (tb_gemm_ln_epilogue_ok)
+    if (!(g8_enable & 2) || d.a_mode != TB_A_LINEAR || !tb_gemm_ln_epilogue_ok(d.M, d.N, d.K) || d.rowbias || d.c_dtype != TB_F16 || !d.C2 ||
+        !d.ln_gamma || !d.ln_stats || (d.act == TB_ACT_LN_FWD && !d.ln_beta) || d.ldc % 8 || ((uintptr_t)d.C) % 16 || d.ldc2 % 8 ||
+        ((uintptr_t)d.C2) % 16 || ((uintptr_t)d.ln_stats) % 8 || (d.R && (d.r_dtype != TB_F16 || d.ldr % 8 || ((uintptr_t)d.R) % 16)))
+      return TB_EINVAL;
   }
   if (d.K % 64 || d.N % 8) return 1;
   const int64_t lim = (int64_t)1 << 32;
@@ -851,6 +1072,7 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
       (d.M / 128) * (d.N / 160) >= 512)
     return launch8<4, 2, 2, 5, false, 2>(d, s, 30);
   if (d.N % 320) return 1;
+  if (ln_act && (d.M / 128) * (d.N / 320) >= 200 && d.M % 128 == 0) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);
   return 1;

@@ -72,11 +72,30 @@ def _gemm_workspace(dev):
     return ws
 
 
+def gemm_ln_ok(M, N, K, dtype=torch.float16):
+    """can a fp16 Linear of this shape carry a fused LayerNorm epilogue (`gemm(..., ln_fwd=... / ln_bwd=...)`)?"""
+    return dtype == torch.float16 and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
+
+
 def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_per_group=0, R=None, act=L.ACT_NONE,
-         alpha=1.0, C2=None, conv=None):
+         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
-    conv = dict(B,Hin,Win,Cin,Hout,Wout,stride,sign,upsample,transposed) switches A to an NHWC 3x3 gather."""
+    conv = dict(B,Hin,Win,Cin,Hout,Wout,stride,sign,upsample,transposed) switches A to an NHWC 3x3 gather.
+    ln_fwd = (gamma, beta, stats_out, y_out, eps): LayerNorm of the output row fused into the epilogue (only where `gemm_ln_ok`): `out` gets the
+    Linear's result as usual, `y_out` = LN(out), `stats_out` [M,2] = (mean, rstd).
+    ln_bwd = (gamma, stats, x): `out` = tb_layernorm_bwd(dy = A @ W^T, x, gamma, stats) + R -- the LayerNorm backward applied to the dgrad
+    GEMM's accumulators (x = the LayerNorm's fp16 input)."""
     d = L.GemmDesc()
+    if ln_fwd is not None:
+        assert act == L.ACT_NONE and C2 is None and ln_bwd is None
+        g_, b_, st_, y_, eps_ = ln_fwd
+        act, C2 = L.ACT_LN_FWD, y_
+        d.ln_gamma, d.ln_beta, d.ln_stats, d.ln_eps = L.ptr(g_), L.ptr(b_), L.ptr(st_), eps_
+    if ln_bwd is not None:
+        assert act == L.ACT_NONE and C2 is None and bias is None
+        g_, st_, x_ = ln_bwd
+        act, C2 = L.ACT_LN_BWD, x_
+        d.ln_gamma, d.ln_stats = L.ptr(g_), L.ptr(st_)
     M = out.shape[0]
     N = W.shape[0]
     d.M, d.N = M, N

@@ -31,6 +31,9 @@ import os as _os
 # (A/B in one process: 35.23 -> 35.06 ms per step); through the 4-wave kernels' generic epilogue it was slower than the streaming kernel
 FUSE_GEGLU_BWD = _os.environ.get("TB_FUSE_GEGLU_BWD", "1") == "1"
 MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  # A/B switch (see the up-block forward)
+# LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
+# residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
+FUSE_LN = _os.environ.get("TB_FUSE_LN", "1") == "1"
 
 
 @dataclass
@@ -327,11 +330,15 @@ class HipUNet:
         n0 = self.scratch("a", M, C)
         self._gn_fwd(x, prefix + ".norm", n0, st0, HW, False, eps=1e-6)
         t0 = self.buf(prefix + ".t0", M, C)
-        ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
+        fuse_ln = FUSE_LN and ops.gemm_ln_ok(M, C, C, self.dtype)
         # --- self attention
         ls1 = self.buf(prefix + ".ls1", M, 2, torch.float32)
-        l1 = self.scratch("a", M, C)
-        ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
+        l1 = self.scratch("a2" if fuse_ln else "a", M, C)   # (fused: written while n0 -- scratch "a" -- is still being read)
+        if fuse_ln:
+            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"], ln_fwd=(P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1, l1, 1e-5))
+        else:
+            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
+            ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
         qkv = self.buf(prefix + ".qkv", M, 3 * C)
         ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
         o1 = self.buf(prefix + ".o1", M, C)
@@ -343,11 +350,15 @@ class HipUNet:
             fp8_ws = self._fp8_ws
         ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, B, heads, HW, HW, hd, fp8_ws=fp8_ws)
         t1 = self.buf(prefix + ".t1", M, C)
-        ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
         # --- cross attention (K/V hoisted)
         ls2 = self.buf(prefix + ".ls2", M, 2, torch.float32)
         l2 = self.scratch("a", M, C)
-        ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
+        if fuse_ln:
+            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0,
+                     ln_fwd=(P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2, l2, 1e-5))
+        else:
+            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
+            ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
         q2 = self.buf(prefix + ".q2", M, C)
         ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
         self._ensure_kv()
@@ -357,11 +368,15 @@ class HipUNet:
         lse2 = self.buf(prefix + ".lse2", B * heads, HW, torch.float32)
         ops.attention_fwd(q2, k2, v2, o2, lse2, B, heads, HW, T, hd)
         t2 = self.buf(prefix + ".t2", M, C)
-        ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
         # --- GEGLU feed-forward
         ls3 = self.buf(prefix + ".ls3", M, 2, torch.float32)
         l3 = self.scratch("a", M, C)
-        ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
+        if fuse_ln:
+            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1,
+                     ln_fwd=(P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3, l3, 1e-5))
+        else:
+            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
+            ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
         raw = self.buf(prefix + ".raw", M, 8 * C)
         gated = self.scratch("b", M, 4 * C)
         ops.gemm(l3, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.b"], act=L.ACT_GEGLU, C2=raw)
@@ -380,10 +395,13 @@ class HipUNet:
                 dgated = self.scratch("gb", M, 4 * C)
                 ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dgated)
                 ops.geglu_bwd(dgated, raw, dproj)
-            dl3 = self.scratch("g2", M, C)
-            ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
             dt2 = self.scratch("g3", M, C)
-            ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
+            if fuse_ln:
+                ops.gemm(dproj, P[tb + ".ff1.wd"], dt2, R=dt3, ln_bwd=(P[tb + ".norm3.g"], ls3, t2))
+            else:
+                dl3 = self.scratch("g2", M, C)
+                ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
+                ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
             do2 = self.scratch("g1", M, C)
             ops.gemm(dt2, P[tb + ".attn2.to_out.0.wd"], do2)
             dq2 = self.scratch("g2", M, C)
@@ -393,10 +411,13 @@ class HipUNet:
             ops.attention_bwd(q2, k2, v2, o2, lse2, do2, delta, dq2, dk2, dv2, B, heads, HW, T, hd, ws=xws)
             if stop_after_cross:
                 return
-            dl2 = self.scratch("g1", M, C)
-            ops.gemm(dq2, P[tb + ".attn2.to_q.wd"], dl2)
             dt1 = self.scratch("g4", M, C)
-            ops.layernorm_bwd(dl2, t1, P[tb + ".norm2.g"], ls2, dt1, add=dt2)
+            if fuse_ln:
+                ops.gemm(dq2, P[tb + ".attn2.to_q.wd"], dt1, R=dt2, ln_bwd=(P[tb + ".norm2.g"], ls2, t1))
+            else:
+                dl2 = self.scratch("g1", M, C)
+                ops.gemm(dq2, P[tb + ".attn2.to_q.wd"], dl2)
+                ops.layernorm_bwd(dl2, t1, P[tb + ".norm2.g"], ls2, dt1, add=dt2)
             do1 = self.scratch("g1", M, C)
             ops.gemm(dt1, P[tb + ".attn1.to_out.0.wd"], do1)
             dqkv = self.scratch("gq", M, 3 * C)
@@ -405,10 +426,13 @@ class HipUNet:
             sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 64, 80) and HW % 128 == 0 and self.dtype == torch.float16 else None
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, do1, delta, dqkv[:, :C], dqkv[:, C:2 * C],
                               dqkv[:, 2 * C:], B, heads, HW, HW, hd, ws=sws)
-            dl1 = self.scratch("g2", M, C)
-            ops.gemm(dqkv, P[tb + ".attn1.qkv.wd"], dl1)
             dt0 = self.scratch("g3", M, C)
-            ops.layernorm_bwd(dl1, t0, P[tb + ".norm1.g"], ls1, dt0, add=dt1)
+            if fuse_ln:
+                ops.gemm(dqkv, P[tb + ".attn1.qkv.wd"], dt0, R=dt1, ln_bwd=(P[tb + ".norm1.g"], ls1, t0))
+            else:
+                dl1 = self.scratch("g2", M, C)
+                ops.gemm(dqkv, P[tb + ".attn1.qkv.wd"], dl1)
+                ops.layernorm_bwd(dl1, t0, P[tb + ".norm1.g"], ls1, dt0, add=dt1)
             dn0 = self.scratch("g1", M, C)
             ops.gemm(dt0, P[prefix + ".proj_in.wd"], dn0)
             self._gn_bwd(dn0, x, prefix + ".norm", st0, dx, HW, False, add=dout)
