@@ -599,19 +599,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
   if (loraA && row < lora_rows) {  // (rows >= lora_rows: a frozen batch riding along -- their rows of tdown are zeroed below)
     // fused LoRA down projection (lora_A of peft lora.Linear on the normalised row): tdown[row, j] = sum_k y[row,k] * fp16(A[j,k]);
     // the row is still in registers, the R <= 24 adapter rows are L2 resident
-    for (int j = 0; j < R; ++j) {
-      float a = 0.f;
+    // four adapter rows at a time: their loads and their butterfly reductions are independent, so the load latencies and the six dependent
+    // cross-lane steps of a reduction are paid once per FOUR rows (one row at a time, the 12 serial [load -> 6 shuffles] chains of r = 4 on q/k/v
+    // made this launch 17.4 us against 5.4 us for the plain LayerNorm of the same rows).  Per-row arithmetic and summation order are unchanged.
+    for (int j0 = 0; j0 < R; j0 += 4) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < LN_MAXV; ++k) {
-        int vi = lane + 64 * k;
-        if (vi < nv) {
-          const f32x4 a0 = *(const f32x4*)(loraA + (int64_t)j * C + vi * 8), a1 = *(const f32x4*)(loraA + (int64_t)j * C + vi * 8 + 4);
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q < R ? j0 + q : R - 1;  // (clamped duplicate, not stored)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a += v[k][e] * (float)(f16)a0[e] + v[k][4 + e] * (float)(f16)a1[e];
+        for (int k = 0; k < LN_MAXV; ++k) {
+          int vi = lane + 64 * k;
+          if (vi < nv) {
+            const f32x4 a0 = *(const f32x4*)(loraA + (int64_t)j * C + vi * 8), a1 = *(const f32x4*)(loraA + (int64_t)j * C + vi * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[q] += v[k][e] * (float)(f16)a0[e] + v[k][4 + e] * (float)(f16)a1[e];
+          }
         }
       }
-      a = wave_sum(a);
-      if (lane == 0) tdown[row * ldt + j] = (f16)a;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += __shfl_xor(a[q], o, 64);
+      }
+      if (lane < 4 && j0 + lane < R) {
+        const float r = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : a[3];
+        tdown[row * ldt + j0 + lane] = (f16)r;
+      }
     }
   } else if (loraA && lane < R) {
     // a frozen row riding along (KPL teacher): its K-extension operand must be zero whatever an earlier call left in the buffer

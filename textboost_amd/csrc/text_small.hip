@@ -128,190 +128,179 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
 //   (a) dt[m, p*r + j]  = scaling * sum_n dY[m, p*D + n] * fp16(B[(p*D+n)*r + j])
 //   (b) dB[(p*D+n)*r+j] += scaling * sum_m dY[m, p*D + n] * t[m, p*r + j]
 //   (c) dA[j*K + k]     += sum_m dt[m, j] * x[m, k]
-// One kernel per slab of LORA_RS rows does all three: (a) lands in LDS (and in dt for the dgrad GEMM), (b)/(c) are per-slab
-// partial sums written to a workspace; blockIdx.y = 0 takes the (b) units, 1 the (c) units so that M / LORA_RS * 2 blocks fill the
-// chip.  A second kernel adds the partials in slab order (deterministic).
-#ifndef TB_LORA_RS
-#define TB_LORA_RS 8
-#endif
-constexpr int LORA_RS = TB_LORA_RS;
+// Two launches, no partial-sum workspace (round 3; before: 8-row slabs writing 11 MB of per-slab partials + a reducer, 43 us per layer):
+//   launch 1: blocks [0, M/16)       -> (a) for 16 rows each (16 threads per row, B staged once per block in LDS as the fp16 values the forward used)
+//             blocks [M/16, +P*D/32) -> (b) for a 32-column panel of dY over ALL rows: 64 row slots x 4 column groups accumulate in registers,
+//                                       the 64 slots are summed through LDS in slot order (deterministic) and added to dB
+//   launch 2: P * K/32 blocks        -> (c) the same panel product with (x, dt) in place of (dY, t)
 constexpr int LORA_MAXR = 24;  // P * r
-template <int RR>  // RR = r when r is 4 or 8 (16-byte vector loads of the B rows, fully unrolled), 0 = generic r <= 8
-__global__ __launch_bounds__(256) void lora_bwd_fused_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ x, int64_t ldx,
-                                                             const f16* __restrict__ t, int64_t ldt, const float* __restrict__ Bcat,
-                                                             f16* __restrict__ dt, int64_t lddt, float* __restrict__ partB,
-                                                             float* __restrict__ partA, int64_t M, int D, int K, int r, int P,
-                                                             float scaling) {
-  __shared__ float ts[LORA_RS][LORA_MAXR];
-  __shared__ float dts[LORA_RS][LORA_MAXR];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int R = P * r;
-  const int64_t m0 = (int64_t)blockIdx.x * LORA_RS;
-  const int rows = (int)(M - m0 < LORA_RS ? M - m0 : LORA_RS);
-  for (int u = tid; u < LORA_RS * LORA_MAXR; u += 256) {
-    const int i = u / LORA_MAXR, j = u - i * LORA_MAXR;
-    ts[i][j] = (i < rows && j < R) ? (float)t[(m0 + i) * ldt + j] : 0.f;
-    dts[i][j] = 0.f;  // columns >= R stay zero for (c)'s 4-row units
-  }
-  __syncthreads();
-  // ---- (a): each wave owns LORA_RS / 4 rows; a chunk of B (8 columns x r) is loaded once into registers and used for all of them
-  constexpr int RPW = LORA_RS / 4;
-  for (int p = 0; p < P; ++p) {
-    float acc[RPW][8];
+constexpr int LORA_DT_ROWS = 16, LORA_PANEL = 32, LORA_SLOTS = 64, LORA_CG = LORA_PANEL / 8;
+
+// red[slot][c][j] = sum over the rows m = slot (mod LORA_SLOTS) of L[m, c0 + c] * S[m, s0 + j]  (c < LORA_PANEL, j < r <= RR); thread (slot = tid / LORA_CG,
+// g = tid % LORA_CG) owns columns 8 g .. 8 g + 7; the callers add the LORA_SLOTS slot sums in slot order
+template <int RR>
+__device__ __forceinline__ void lora_panel_dot(const f16* __restrict__ Lm, int64_t ldl, int64_t c0, const f16* __restrict__ Sm, int64_t lds_, int s0,
+                                               int r, int64_t M, float* red /* [LORA_SLOTS][LORA_PANEL][RR] */) {
+  const int tid = threadIdx.x, slot = tid / LORA_CG, g = tid % LORA_CG;
+  float acc[8][RR];
 #pragma unroll
-    for (int ii = 0; ii < RPW; ++ii)
+  for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[ii][j] = 0.f;
-    for (int n = lane * 8; n < D; n += 512) {
-      const float* bp = Bcat + ((int64_t)p * D + n) * r;
-      float bw[8][8];  // [e][j], fp16-rounded as the forward used them
-      if (RR) {
+    for (int j = 0; j < RR; ++j) acc[e][j] = 0.f;
+  // rows in batches of U: all loads of a batch are issued before its arithmetic (one row at a time the loop was a chain of L2 latencies:
+  // 39 dependent round trips per thread made the whole backward 40 us)
+  constexpr int U = 10;
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t mb = slot; mb < M; mb += LORA_SLOTS * U) {
+    f16x8 lv[U];
+    float sv[U][RR];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = mb + (int64_t)u * LORA_SLOTS;
+      const bool ok = m < M;
+      lv[u] = ok ? *(const f16x8*)(Lm + m * ldl + c0 + g * 8) : z8;
+      if (r == RR && ((lds_ | s0) % RR) == 0) {  // one aligned vector per row (r = 4: 8 bytes, r = 8: 16 bytes)
+        typedef __attribute__((ext_vector_type(RR))) _Float16 hvec;
+        hvec h;
 #pragma unroll
-          for (int q = 0; q < RR / 4; ++q) {
-            const f32x4 b = *(const f32x4*)(bp + RR * e + 4 * q);
+        for (int j = 0; j < RR; ++j) h[j] = (_Float16)0.f;
+        if (ok) h = *(const hvec*)(Sm + m * lds_ + s0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bw[e][4 * q + j] = (float)(f16)b[j];
-          }
+        for (int j = 0; j < RR; ++j) sv[u][j] = (float)h[j];
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bw[e][j] = j < r ? (float)(f16)bp[e * r + j] : 0.f;
-      }
-#pragma unroll
-      for (int ii = 0; ii < RPW; ++ii) {
-        const int i = wave + 4 * ii;
-        if (i < rows) {
-          const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + (int64_t)p * D + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = (float)dy[e];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (j < (RR ? RR : 8)) acc[ii][j] += d * bw[e][j];
-          }
-        }
+        for (int j = 0; j < RR; ++j) sv[u][j] = (ok && j < r) ? (float)Sm[m * lds_ + s0 + j] : 0.f;
       }
     }
 #pragma unroll
-    for (int ii = 0; ii < RPW; ++ii) {
-      const int i = wave + 4 * ii;
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < r) {
-          const float v = wave_sum(acc[ii][j]) * scaling;
-          if (lane == 0) {
-            const f16 h = (f16)v;
-            dts[i][p * r + j] = (float)h;  // (c) consumes the fp16 value the dgrad GEMM sees
-            if (i < rows && blockIdx.y == 0) dt[(m0 + i) * lddt + p * r + j] = h;
-          }
-        }
-    }
+      for (int e = 0; e < 8; ++e) {
+        const float l = (float)lv[u][e];
+#pragma unroll
+        for (int j = 0; j < RR; ++j) acc[e][j] += l * sv[u][j];
+      }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j < RR; ++j) red[(slot * LORA_PANEL + g * 8 + e) * RR + j] = acc[e][j];
   __syncthreads();
-  if (blockIdx.y == 0) {
-    // ---- (b): unit = 8 consecutive columns n of dY; acc[e][j] over the slab rows
-    const int units = P * D / 8;
-    float* o = partB + (int64_t)blockIdx.x * P * D * r;
-    for (int u = tid; u < units; u += 256) {
-      const int n = u * 8, p = n / D;
-      float acc[8][8];
+}
+
+template <int RR>  // RR = 4 (r <= 4) or 8 (r <= 8)
+__global__ __launch_bounds__(256) void lora_bwd_dt_db_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ t, int64_t ldt,
+                                                             const float* __restrict__ Bcat, f16* __restrict__ dt, int64_t lddt,
+                                                             float* __restrict__ dB, int64_t M, int D, int r, int P, float scaling, int nslab) {
+  extern __shared__ __attribute__((aligned(16))) float lora_smem[];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nslab) {
+    // ---- (a): 16 rows, 16 threads per row; thread c of a row takes the 8-column groups n = 8 c (mod 128)
+    float* Bs = lora_smem;  // [P * D][RR], fp16-rounded
+    if (r == RR) {  // same layout: a 16-byte copy, eight vectors in flight per thread
+      const int nvec = P * D * RR / 4;
+      for (int u0 = tid; u0 < nvec; u0 += 256 * 8) {
+        f32x4 v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
+        for (int q = 0; q < 8; ++q) {
+          const int u = u0 + 256 * q;
+          v[q] = u < nvec ? *(const f32x4*)(Bcat + (int64_t)u * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
-      for (int i = 0; i < rows; ++i) {
-        const f16x8 dy = *(const f16x8*)(dY + (m0 + i) * lddy + n);
+        for (int q = 0; q < 8; ++q) {
+          const int u = u0 + 256 * q;
+          if (u < nvec) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < (RR ? RR : r)) {
-            const float tv = ts[i][p * r + j];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e][j] += (float)dy[e] * tv;
+            for (int e = 0; e < 4; ++e) v[q][e] = (float)(f16)v[q][e];
+            *(f32x4*)(Bs + (int64_t)u * 4) = v[q];
           }
+        }
       }
-      if (RR) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-          for (int q = 0; q < RR / 4; ++q) {
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[e][4 * q + j];
-            *(f32x4*)(o + (int64_t)(n + e) * RR + 4 * q) = v;
-          }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j < r) o[(int64_t)(n + e) * r + j] = acc[e][j];
+    } else {
+      for (int u = tid; u < P * D * RR; u += 256) {
+        const int n = u / RR, j = u - n * RR;
+        Bs[u] = j < r ? (float)(f16)Bcat[(int64_t)n * r + j] : 0.f;
       }
     }
-  } else {
-    // ---- (c): unit = (4 adapter rows j, 8 consecutive k)
-    const int kg = K / 8, jgs = (R + 3) / 4;
-    float* o = partA + (int64_t)blockIdx.x * R * K;
-    for (int u = tid; u < kg * jgs; u += 256) {
-      const int jg = u / kg, k = (u - jg * kg) * 8;
-      float acc[4][8];
+    __syncthreads();
+    const int i = tid >> 4, c = tid & 15;
+    const int64_t m = (int64_t)blockIdx.x * LORA_DT_ROWS + i;
+    const bool live = m < M;
+    for (int p = 0; p < P; ++p) {
+      float acc[RR];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < RR; ++j) acc[j] = 0.f;
+      if (live) {
+        for (int nb = c * 8; nb < D; nb += 128 * 4) {  // four column groups per batch, loads first
+          f16x8 dy[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-      for (int i = 0; i < rows; ++i) {
-        const f16x8 xv = *(const f16x8*)(x + (m0 + i) * ldx + k);
+          for (int u = 0; u < 4; ++u) {
+            const int n = nb + 128 * u;
+            const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            dy[u] = n < D ? *(const f16x8*)(dY + m * lddy + (int64_t)p * D + n) : z8;
+          }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = dts[i][jg * 4 + j];  // columns >= R hold zeros (LORA_MAXR is a multiple of 4)
+          for (int u = 0; u < 4; ++u) {
+            const int n = nb + 128 * u;
+            if (n < D) {
+              const float* bp = Bs + ((int64_t)p * D + n) * RR;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[j][e] += d * (float)xv[e];
+              for (int e = 0; e < 8; ++e) {
+                const float d = (float)dy[u][e];
+#pragma unroll
+                for (int j = 0; j < RR; ++j) acc[j] += d * bp[e * RR + j];
+              }
+            }
+          }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (jg * 4 + j < R) {
-          f32x4 v0, v1;
+      for (int j = 0; j < RR; ++j) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v0[e] = acc[j][e];
-            v1[e] = acc[j][4 + e];
-          }
-          float* dst = o + (int64_t)(jg * 4 + j) * K + k;
-          *(f32x4*)dst = v0;
-          *(f32x4*)(dst + 4) = v1;
-        }
+        for (int o = 1; o < 16; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+      }
+      if (live && c < r) {
+        float v = acc[0];
+#pragma unroll
+        for (int j = 1; j < RR; ++j) v = c == j ? acc[j] : v;
+        dt[m * lddt + p * r + c] = (f16)(v * scaling);
+      }
+    }
+    return;
+  }
+  // ---- (b): one LORA_PANEL-column panel of dY (inside one adapter: D % LORA_PANEL == 0) against that adapter's columns of t
+  const int64_t n0 = (int64_t)((int)blockIdx.x - nslab) * LORA_PANEL;
+  const int p = (int)(n0 / D);
+  lora_panel_dot<RR>(dY, lddy, n0, t, ldt, p * r, r, M, lora_smem);
+  for (int u = tid; u < LORA_PANEL * RR; u += 256) {
+    const int c = u / RR, j = u - c * RR;
+    if (j < r) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int sl = 0; sl < LORA_SLOTS; ++sl) a += lora_smem[(sl * LORA_PANEL + c) * RR + j];
+      dB[(n0 + c) * r + j] += a * scaling;
     }
   }
 }
-// dB[i] += scaleB * sum_s partB[s][i] (i < nB);  dA[i] += sum_s partA[s][i] (i < nA): one launch for both, 4 floats per thread
-__global__ __launch_bounds__(256) void lora_slab_reduce_kernel(const float* __restrict__ partB, const float* __restrict__ partA,
-                                                               float* __restrict__ dB, float* __restrict__ dA, int64_t nB, int64_t nA,
-                                                               int nslab, float scaleB) {
-  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  const float* part;
-  float* out;
-  int64_t n;
-  float scale;
-  if (i < nB) part = partB, out = dB, n = nB, scale = scaleB;
-  else if (i - nB < nA) i -= nB, part = partA, out = dA, n = nA, scale = 1.f;
-  else return;
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  int s = 0;
-  for (; s + 4 <= nslab; s += 4) {  // 4 independent loads in flight, summed in slab order
-    const f32x4 v0 = *(const f32x4*)(part + (int64_t)s * n + i), v1 = *(const f32x4*)(part + (int64_t)(s + 1) * n + i),
-                v2 = *(const f32x4*)(part + (int64_t)(s + 2) * n + i), v3 = *(const f32x4*)(part + (int64_t)(s + 3) * n + i);
-    a += v0;
-    a += v1;
-    a += v2;
-    a += v3;
+
+template <int RR>
+__global__ __launch_bounds__(256) void lora_bwd_da_kernel(const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ dt, int64_t lddt,
+                                                          float* __restrict__ dA, int64_t M, int K, int r, int P) {
+  extern __shared__ __attribute__((aligned(16))) float lora_smem[];
+  const int tid = threadIdx.x;
+  const int panels = K / LORA_PANEL;
+  const int p = (int)blockIdx.x / panels;
+  const int64_t k0 = (int64_t)((int)blockIdx.x - p * panels) * LORA_PANEL;
+  lora_panel_dot<RR>(x, ldx, k0, dt, lddt, p * r, r, M, lora_smem);
+  for (int u = tid; u < LORA_PANEL * RR; u += 256) {
+    const int j = u / LORA_PANEL, c = u - j * LORA_PANEL;   // consecutive threads -> consecutive k of one adapter row
+    if (j < r) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int sl = 0; sl < LORA_SLOTS; ++sl) a += lora_smem[(sl * LORA_PANEL + c) * RR + j];
+      dA[(int64_t)(p * r + j) * K + k0 + c] += a;
+    }
   }
-  for (; s < nslab; ++s) a += *(const f32x4*)(part + (int64_t)s * n + i);
-  f32x4 o = *(f32x4*)(out + i);
-  o += a * scale;
-  *(f32x4*)(out + i) = o;
 }
 
 }  // namespace
@@ -401,32 +390,38 @@ extern "C" int tb_lora_pack_f32(const float* A, const float* Bcat, float* w2_fwd
 }
 
 extern "C" int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P) {
-  const int64_t nslab = (M + LORA_RS - 1) / LORA_RS;
-  return nslab * ((int64_t)P * D * r + (int64_t)P * r * K);
+  (void)M, (void)D, (void)K, (void)r, (void)P;
+  return 4;  // the round-3 kernels need no scratch (kept in the ABI: callers still pass a pointer)
 }
 
 extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
                            void* dt, int64_t lddt, float* dA, float* dB, float* ws, int64_t M, int D, int K, int r, int P,
                            float scaling, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || !ws || r > 8 || P * r > LORA_MAXR) return TB_EINVAL;
-  if (D % 8 || K % 8 || lddy % 8 || ldx % 8 || (P * D * r) % 4 || (P * r * K) % 4) return TB_EINVAL;  // 16-byte vector accesses
-  if (((uintptr_t)dY) % 16 || ((uintptr_t)x) % 16 || ((uintptr_t)dA) % 16 || ((uintptr_t)dB) % 16 || ((uintptr_t)ws) % 16 ||
-      ((r == 4 || r == 8) && ((uintptr_t)Bcat) % 16))
-    return TB_EINVAL;
+  (void)ws;
+  if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || r <= 0 || r > 8 || P <= 0 || P * r > LORA_MAXR || M <= 0) return TB_EINVAL;
+  if (D % LORA_PANEL || K % LORA_PANEL || lddy % 8 || ldx % 8) return TB_EINVAL;  // 16-byte vector accesses, panels inside one adapter
+  if (((uintptr_t)dY) % 16 || ((uintptr_t)x) % 16) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int nslab = (int)((M + LORA_RS - 1) / LORA_RS);
-  const int64_t nB = (int64_t)P * D * r, nA = (int64_t)P * r * K;
-  float* partB = ws;
-  float* partA = ws + (int64_t)nslab * nB;
-#define TB_LORA_BWD(RR)                                                                                                                   \
-  hipLaunchKernelGGL(lora_bwd_fused_kernel<RR>, dim3(nslab, 2), dim3(256), 0, s, (const f16*)dY, lddy, (const f16*)x, ldx, (const f16*)t, \
-                     ldt, Bcat, (f16*)dt, lddt, partB, partA, M, D, K, r, P, scaling)
-  if (r == 4) TB_LORA_BWD(4);
-  else if (r == 8) TB_LORA_BWD(8);
-  else TB_LORA_BWD(0);
+  const int nslab = (int)((M + LORA_DT_ROWS - 1) / LORA_DT_ROWS);
+  const int RR = r <= 4 ? 4 : 8;
+  const size_t red_bytes = (size_t)LORA_SLOTS * LORA_PANEL * RR * sizeof(float);
+  const size_t b_bytes = (size_t)P * D * RR * sizeof(float);
+  const size_t lds1 = red_bytes > b_bytes ? red_bytes : b_bytes;
+  if (lds1 > 160 * 1024) return TB_EINVAL;
+#define TB_LORA_BWD(RRV)                                                                                                                        \
+  {                                                                                                                                             \
+    if (lds1 > 64 * 1024 &&                                                                                                                     \
+        hipFuncSetAttribute((const void*)lora_bwd_dt_db_kernel<RRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
+      return TB_ELAUNCH;                                                                                                                        \
+    hipLaunchKernelGGL(lora_bwd_dt_db_kernel<RRV>, dim3(nslab + P * D / LORA_PANEL), dim3(256), lds1, s, (const f16*)dY, lddy, (const f16*)t,   \
+                       ldt, Bcat, (f16*)dt, lddt, dB, M, D, r, P, scaling, nslab);                                                              \
+    hipLaunchKernelGGL(lora_bwd_da_kernel<RRV>, dim3(P * (K / LORA_PANEL)), dim3(256), red_bytes, s, (const f16*)x, ldx, (const f16*)dt, lddt,  \
+                       dA, M, K, r, P);                                                                                                         \
+  }
+  if (RR == 4) TB_LORA_BWD(4)
+  else TB_LORA_BWD(8)
 #undef TB_LORA_BWD
-  hipLaunchKernelGGL(lora_slab_reduce_kernel, GRID1D((nB + nA) / 4), dim3(256), 0, s, partB, partA, dB, dA, nB, nA, nslab, scaling);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
