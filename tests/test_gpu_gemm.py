@@ -350,3 +350,30 @@ def test_layernorm_epilogue_is_refused_where_no_tile_spans_the_row():
     g = torch.ones(320, device="cuda")
     with pytest.raises(RuntimeError):
         ops.gemm(A, W, out, ln_fwd=(g, g, st, y, 1e-5))
+
+
+@pytest.mark.parametrize("B,Co,Ci,H,W,res", [(2, 64, 64, 16, 16, False), (2, 128, 192, 32, 16, True), (8, 320, 320, 64, 64, False), (8, 1280, 1280, 16, 16, True)])
+def test_transposed_dgrad_phase_ordered_rows(B, Co, Ci, H, W, res):
+    """stride-2 dgrad with the rows walked parity class by parity class (tb_gemm switches to it when M / 4 is a whole number of 128-row tiles):
+    against conv_transpose2d and against the map-order gather it replaces (skipped taps only ever added exact zeros: bit-equal unless the launch
+    is split over K, where the slice boundaries move with the shorter tap lists)."""
+    from parity import parity
+    ops, L = _ops()
+    torch.manual_seed(7)
+    Ho, Wo = H // 2, W // 2
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda") / (3 * Co ** 0.5)).half()
+    dy = torch.randn(B, Co, Ho, Wo, device="cuda").half()
+    R = torch.randn(B * H * W, Ci, device="cuda").half() if res else None
+    geo = dict(B=B, Hin=Ho, Win=Wo, Cin=Co, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=1)
+    outs = []
+    for phase in (1, 0):
+        L.lib().tb_gemm_set_variant(9900 + phase)
+        dx = torch.zeros(B * H * W, Ci, device="cuda", dtype=torch.float16)
+        ops.gemm(nhwc(dy).view(-1, Co), pack_conv_w_dgrad(w), dx, conv=geo, R=R)
+        outs.append(dx)
+    L.lib().tb_gemm_set_variant(9901)
+    ref = nhwc(F.conv_transpose2d(dy.float(), w.float(), stride=2, padding=1, output_padding=1)).reshape(B * H * W, Ci)
+    if res:
+        ref = ref + R.float()
+    parity("phase-ordered transposed dgrad", outs[0], ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+    assert torch.equal(outs[0], outs[1]) or rel_err(outs[0], outs[1]) < 3e-4

@@ -121,7 +121,19 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
     const int rp = pass * PR;  // first tile row of this pass
     auto m_of = [&](int row) -> int64_t {
       const int r = rp + row;
-      return m0 + (int64_t)(r >> mshift) * mstride + (r & ((1 << mshift) - 1));
+      const int64_t m = m0 + (int64_t)(r >> mshift) * mstride + (r & ((1 << mshift) - 1));
+      if (p.a_mode == TB_A_CONV3X3 && p.transposed == 2) {  // phase-ordered tile rows (gemm_kernel) back to map order
+        const int64_t mq = p.M >> 2;
+        if (m >= p.M) return m;
+        const int cls = (int)(m / mq), q = 3 - cls;
+        const int64_t rr = m - (int64_t)cls * mq;
+        const int hc = p.Hout >> 1, wc = p.Wout >> 1;
+        const int b = (int)(rr / (hc * wc));
+        const int rem = (int)(rr - (int64_t)b * hc * wc);
+        const int i2 = rem / wc, j2 = rem - i2 * wc;
+        return ((int64_t)b * p.Hout + 2 * i2 + (q >> 1)) * p.Wout + 2 * j2 + (q & 1);
+      }
+      return m;
     };
     if (p.act == TB_ACT_GEGLU) {
       // packed columns: [h0..31 | g0..31] per 64; unit = (row, 8 gate outputs); out column = packed_h_column / 2 (+ j)
@@ -373,6 +385,19 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
     if (MODE == TB_A_LINEAR) {
       a_ptr[i] = (const f16*)p.A + mm * p.lda + a_sw[i];
       a2_ptr[i] = p.A2 ? (const f16*)p.A2 + mm * p.lda2 + a_sw[i] : nullptr;
+    } else if (p.transposed == 2) {
+      // phase-ordered rows (see phase_q below): row m' = class * (M / 4) + ((b * Hout/2 + i) * Wout/2 + j)  ->  output pixel (2 i + qy, 2 j + qx)
+      const int64_t mq = p.M >> 2;
+      const int cls = (int)(mm / mq);
+      const int q = 3 - cls;
+      const int64_t r = mm - (int64_t)cls * mq;
+      const int hc = p.Hout >> 1, wc = p.Wout >> 1;
+      const int b = (int)(r / (hc * wc));
+      const int rem = (int)(r - (int64_t)b * hc * wc);
+      const int i2 = rem / wc;
+      py[i] = 2 * i2 + (q >> 1);
+      px[i] = 2 * (rem - i2 * wc) + (q & 1);
+      pbase[i] = (int64_t)b * p.Hin * p.Win;
     } else {
       const int hw = p.Hout * p.Wout;
       const int b = (int)(mm / hw);
@@ -382,6 +407,13 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
       pbase[i] = (int64_t)b * p.Hin * p.Win;
     }
   }
+  // Transposed (stride-2 dgrad) gather, phase mode (p.transposed == 2, set by tb_gemm when the map is even and M / 4 is a whole number of tiles):
+  // an output pixel only receives the taps with ky = y + 1 (mod 2), kx = x + 1 (mod 2) -- 1, 2, 2 or 4 of the 9, by the parity class (y & 1, x & 1).
+  // With rows in map order every tile holds all four classes and each tap's k-tiles were multiplied for every row (3 of 4 against the zero
+  // line: 60 of the 80 GFLOP of a 320-channel 64x64 map).  Here the tile grid walks the rows class by class (heaviest class first), so a tile
+  // only issues its class's taps: 2.25 taps per pixel on average instead of 9.  The epilogue maps tile rows back to map order.
+  const int phase_q = (MODE == TB_A_CONV3X3 && p.transposed == 2) ? 3 - (int)(m0 / (p.M >> 2)) : -1;
+  const int ph_nky = phase_q >= 0 && (phase_q >> 1) ? 2 : 1, ph_nkx = phase_q >= 0 && (phase_q & 1) ? 2 : 1;
   const f16* w_ptr[BI];
   const f16* w2_ptr[BI];
   bool w_ok[BI];
@@ -418,11 +450,11 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
   }
 #endif
 
-  const int nk_all = (int)(p.K / BK);
-  const int nk1 = (int)(p.K1 / BK);
+  const int kpt = (MODE == TB_A_CONV3X3) ? p.Cin / BK : 1;  // k-tiles per tap
+  const int nk_all = phase_q >= 0 ? ph_nky * ph_nkx * kpt : (int)(p.K / BK);
+  const int nk1 = phase_q >= 0 ? nk_all : (int)(p.K1 / BK);
   const int kt_begin = (int)((int64_t)nk_all * slice / S), kt_end = (int)((int64_t)nk_all * (slice + 1) / S);
   const int nk = kt_end - kt_begin;  // k-tiles of this block; stage()/loops below index them relative to kt_begin
-  const int kpt = (MODE == TB_A_CONV3X3) ? p.Cin / BK : 1;  // k-tiles per tap
   const f16* zero = g_zero_line;
 
   auto stage = [&](int kt_rel, int buf) {
@@ -450,10 +482,15 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
       }
 #endif
     } else {
-      const int tap = kt / kpt;
+      const int tap = kt / kpt;   // (phase mode: index into the class's tap list)
       const int cc = kt - tap * kpt;
       if (cc == 0 || kt_rel == 0) {  // tap changed (or first tile of this block): recompute the gathered row pointers
-        const int ky = tap / 3, kx = tap - ky * 3;
+        int ky = tap / 3, kx = tap - ky * 3;
+        if (phase_q >= 0) {
+          const int ty_ = tap / ph_nkx, tx_ = tap - ty_ * ph_nkx;
+          ky = ph_nky == 2 ? 2 * ty_ : 1;
+          kx = ph_nkx == 2 ? 2 * tx_ : 1;
+        }
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
           int sy, sx;
@@ -485,7 +522,13 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
     }
     {
       const bool second = kt >= nk1;
-      const int koff = (second ? kt - nk1 : kt) * BK;
+      int koff = (second ? kt - nk1 : kt) * BK;
+      if (MODE == TB_A_CONV3X3 && phase_q >= 0) {  // the k-tile of the class's tap list -> its place in the 9-tap weight row
+        const int tl = kt / kpt, cc = kt - tl * kpt;
+        const int ty_ = tl / ph_nkx, tx_ = tl - ty_ * ph_nkx;
+        const int ky = ph_nky == 2 ? 2 * ty_ : 1, kx = ph_nkx == 2 ? 2 * tx_ : 1;
+        koff = ((ky * 3 + kx) * kpt + cc) * BK;
+      }
 #ifdef TB_GEMM_OLD_ADDR
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
@@ -823,6 +866,7 @@ int launch(const tb_gemm_desc& d, hipStream_t s, int S = 1) {
   }
 }
 
+int g_phase = 1;             // stride-2 dgrad gathers walk the rows parity class by parity class (tb_gemm_set_variant(9900 + {0,1}))
 int g_conv_narrow = 0;       // experiment: bit 0 = conv_halo_kernel<64> always, bit 1 = convs do NOT follow the linear tile rule (9000 + bits)
 int g_force_tile = 0;        // profiling: 1 = 64x64, 2 = 128x64, 3 = 128x128 for every un-split launch (tb_gemm_set_variant(8000 + v))
 int g_split_min_tiles = 8;   // k-tiles per slice lower bound (tb_gemm_set_variant(4000 + n))
@@ -934,7 +978,8 @@ extern "C" void tb_gemm_last_config(int* out5) {
 
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
-  if (v >= 9000) g_conv_narrow = v - 9000;
+  if (v >= 9900) g_phase = v - 9900;
+  else if (v >= 9000) g_conv_narrow = v - 9000;
   else if (v >= 8000) g_force_tile = v - 8000;
   else if (v >= 7000) g_halo = v - 7000;
   else if (v >= 6000) g_split_minnk = v - 6000;
@@ -983,6 +1028,10 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     if (d.stride < 1 || (d.shift && (d.upsample || d.transposed))) return TB_EINVAL;
   } else if (d.a_mode != TB_A_LINEAR) {
     return TB_EINVAL;
+  }
+  if (d.a_mode == TB_A_CONV3X3 && d.transposed) {
+    // phase mode of the transposed gather (gemm_kernel): even maps whose quarter is a whole number of 128-row tiles, no per-row-group bias
+    d.transposed = (g_phase && !(d.Hout & 1) && !(d.Wout & 1) && (d.M % 512) == 0 && !d.rowbias && d.Hin * 2 >= d.Hout && d.Win * 2 >= d.Wout) ? 2 : 1;
   }
   {
     const int r8 = tb_gemm8_try(d, s);
