@@ -371,10 +371,10 @@ class TextBoostStep:
         if self.kpl and self.merge_teacher:
             self._phase_teacher()  # only the KPL loss kernel is left of it
         elif self.kpl:
-            # the teacher is issued on a side stream (a fork/join inside the HIP graph) after the UNet forward.  ROCm 7 serialises a graph's
-            # branches at replay (same steps/s with and without the second stream); the teacher as its OWN graph on the side stream, which
-            # does run concurrently with the UNet graph, measured the same steps/s too (26.0 vs 26.0 / 26.1): the UNet's kernels already
-            # occupy every CU, concurrency only re-divides them.
+            # the teacher is issued on a side stream (a fork/join inside the HIP graph) after the UNet forward.  Branches of a graph do run
+            # concurrently on ROCm 7 (scratch/graph_branches.py), but this one never paid (26.0 vs 26.0 / 26.1 steps/s in round 1, also as its
+            # own graph on the side stream): a latency-bound side chain hides only about half of itself under the one-round UNet kernels
+            # ("round 3, second half").
             self.side.wait_event(fork)
             with torch.cuda.stream(self.side), ops.workspace_slot(1):
                 self._phase_teacher()
