@@ -382,3 +382,67 @@ def test_sd15_full_step_at_the_metric_batch_vs_oracle():
     parity("B=8 step: grad lora_A", hip.grad_A, gA, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
     parity("B=8 step: grad lora_B", hip.grad_B, gB, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
     parity("B=8 step: grad added rows", hip.grad_added, gE, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+
+
+def test_sd21_full_step_chain_at_96x96_vs_oracle():
+    """BASELINE.json configs[3] as ONE chain (the pieces above test its halves): trainable OpenCLIP-H (23 layers, LoRA r=8, added rows) -> fp16
+    hidden states -> SD2.x UNet at 768^2 images = 96x96 latents -> dgrad backward -> d(ehs) -> encoder backward -> LoRA A / B and added-row
+    gradients (train_textboost.py:1054-1067, :1108), B=2 with the oracle one sample at a time; v-prediction only changes the target of the MSE
+    (tested on the small config), not this chain.  Tolerances as for the SD1.5 chain at the metric batch."""
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    from oracle import train_step as ts
+    from oracle.unet_sd import UNetConfig
+    from textboost_amd import models, ops
+    from textboost_amd.text_encoder import HipTextEncoder
+    torch.manual_seed(0)
+    B, T, D, hw = 2, 77, 1024, 96
+    ref_unet, hip_unet = _full_unet_pair(models.SD21_UNET, UNetConfig.sd21(), 85, B, hw)
+    for p in ref_unet.parameters():
+        p.requires_grad_(False)
+    csd = models.random_state_dict(models.clip_shapes(models.SD21_CLIP), 86, device="cpu")
+    ref = TextBoostEncoder(CLIPTextCfg.sd21(), r=8)
+    ref.load_hf_state_dict(csd)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.02)
+        null = ref.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    ref.set_null_embedding(null)
+    added = add_tokens(ref, [11, 22, 33])
+    hip = HipTextEncoder(models.SD21_CLIP, csd, B, mode="autocast", lora_rank=8, device=dev, seed=0)
+    hip.set_null_embedding(null)
+    hip.add_tokens([11, 22, 33])
+    for i, layer in enumerate(ref.layers):
+        hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
+        hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
+    g = torch.Generator().manual_seed(7)
+    ids = ts.synthetic_ids(B, added, g)
+    x = torch.randn(B, 4, hw, hw, generator=g).half().float()
+    t = torch.tensor([731, 48])
+    dpred = torch.randn(B, 4, hw, hw, generator=g)
+    preds, dehs = [], []
+    for b in range(B):
+        h = ref(ids[b:b + 1])
+        h.retain_grad()
+        p = ref_unet(x[b:b + 1], t[b:b + 1], h)
+        (p * dpred[b:b + 1]).sum().backward()
+        preds.append(p.detach())
+        dehs.append(h.grad.detach())
+    pred_ref, dehs_ref = torch.cat(preds), torch.cat(dehs)
+    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
+    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
+    gE = ref.token_embedding.weight.grad[added]
+    hip.pack_lora()
+    h_hip = hip.forward(ids.to(dev))
+    ehs16 = torch.empty(B * T, D, device=dev, dtype=torch.float16)
+    ops.convert(h_hip, ehs16)
+    pred = hip_unet.forward(x.half().to(dev), t.to(dev), ehs16)
+    parity("SD2.1 chain: UNet pred @96x96", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
+    d_ehs = hip_unet.backward(dpred.to(dev))
+    # (worst of 1024 hidden channels over only 2 x 77 tokens: 3.1e-2 measured on a channel whose gradient is ~30x below the median one)
+    parity("SD2.1 chain: d_ehs", d_ehs.view(B, T, D), dehs_ref, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=4e-2)
+    hip.zero_grad()
+    hip.backward(d_ehs.float().contiguous())
+    parity("SD2.1 chain: grad lora_A", hip.grad_A, gA, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+    parity("SD2.1 chain: grad lora_B", hip.grad_B, gB, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+    parity("SD2.1 chain: grad added rows", hip.grad_added, gE, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
