@@ -993,8 +993,8 @@ extern "C" int tb_gemm_set_variant(int v) {
   return old;
 }
 
-int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s);  // gemm8.hip: 8-wave wide tiles for the large-M levels; 1 = shape not covered
-int tb_gemm8_last_split();                                // ... k-slices of that launch (> 1: fp32 partials in d.ws)
+int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s, int* split_out);  // gemm8.hip: 8-wave wide tiles for the large-M levels; 1 = shape not covered;
+                                                                         // *split_out = k-slices of the launch (> 1: fp32 partials in d.ws)
 
 extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
@@ -1034,11 +1034,12 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     d.transposed = (g_phase && !(d.Hout & 1) && !(d.Wout & 1) && (d.M % 512) == 0 && !d.rowbias && d.Hin * 2 >= d.Hout && d.Win * 2 >= d.Wout) ? 2 : 1;
   }
   {
-    const int r8 = tb_gemm8_try(d, s);
-    if (r8 == TB_OK && tb_gemm8_last_split() > 1) {
+    int split8 = 1;
+    const int r8 = tb_gemm8_try(d, s, &split8);
+    if (r8 == TB_OK && split8 > 1) {
       const int64_t npad = (d.N + 7) & ~(int64_t)7;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws,
-                         tb_gemm8_last_split(), npad);
+                         split8, npad);
       TB_CHECK_LAUNCH();
       return TB_OK;
     }

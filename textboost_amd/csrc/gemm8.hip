@@ -935,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 
 unsigned long long* g8_dbg = nullptr;  // profiling aid (tb_gemm8_debug): s_memtime stamps of the first and the last block
 int g8_enable = 39;  // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers, 4 = GEGLU / GEGLU-backward epilogues take the wide-tile path
-int g8_split = 1;    // k-slices of the most recent launch: > 1 -> the caller (tb_gemm) runs splitk_reduce_kernel next
+thread_local int g8_split = 1;  // k-slices of the launch tb_gemm8_try is making on this thread (returned through its out-parameter)
 int g8_last[7] = {0, 0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
 template <int WM, int WN, int MT, int NT, bool CONV, int NS>
@@ -1014,9 +1014,15 @@ extern "C" int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K) {
 }
 
 // returns TB_OK when the launch was taken, 1 when the shape is not covered (the caller falls back to gemm.hip), < 0 on error
-int tb_gemm8_last_split() { return g8_split; }  // k-slices of the launch tb_gemm8_try just made (> 1: partials are in d.ws, reducer due)
 
-int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
+static int gemm8_try(const tb_gemm_desc& d, hipStream_t s);
+// *split_out = k-slices of the launch (> 1: fp32 partials are in d.ws and the caller runs the reducer)
+int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s, int* split_out) {
+  const int rc = gemm8_try(d, s);
+  if (split_out) *split_out = g8_split;
+  return rc;
+}
+static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   g8_last[0] = 0;
   g8_split = 1;
   if (!g8_enable) return 1;
@@ -1068,8 +1074,8 @@ int tb_gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     return launch8<2, 4, 4, 2, false, 2>(d, s, 30);
   // short-K layers wider than one 320-column tile (qkv N = 3 C, K = C): several tiles per CU, each a handful of k-steps between a prologue and
   // an epilogue -- 128x160 tiles at 72 KB keep two workgroups on the CU so those phases overlap (as for the GEGLU layers above)
-  if (!(g8_enable & 128) && d.act != TB_ACT_GEGLU && d.act != TB_ACT_GEGLU_GRAD && d.K <= 640 && (d.N > 320 || (g8_enable & 256)) && d.N % 160 == 0 && d.M % 128 == 0 &&
-      (d.M / 128) * (d.N / 160) >= 512)
+  if (!(g8_enable & 128) && !ln_act && d.act != TB_ACT_GEGLU && d.act != TB_ACT_GEGLU_GRAD && d.K <= 640 && (d.N > 320 || (g8_enable & 256)) && d.N % 160 == 0 && d.M % 128 == 0 &&
+      (d.M / 128) * (d.N / 160) >= ((g8_enable & 512) ? 256 : 512))
     return launch8<4, 2, 2, 5, false, 2>(d, s, 30);
   if (d.N % 320) return 1;
   if (ln_act && (d.M / 128) * (d.N / 320) >= 200 && d.M % 128 == 0) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
