@@ -95,6 +95,10 @@ int tb_gemm8_last(int* out5);
 /* profiling aid: device buffer of 16 x uint64 (NULL = off) that receives s_memtime stamps of the first / last workgroup of gemm8 launches */
 int tb_gemm8_debug(void* stamps16);
 
+/* measurement aid (bench.py `roofline.sustained_peak`): `blocks` workgroups of 4 waves issue iters * 16 independent v_mfma_f32_32x32x16_f16 each on
+ * random register operands; FLOP = blocks * 4 * iters * 16 * 32768.  out: blocks * 256 floats (sink). */
+int tb_mfma_peak_probe(float* out, int blocks, int iters, tb_stream_t stream);
+
 /* text of the HIP error behind the most recent -5 (launch failure) return; diagnostics only */
 const char* tb_last_hip_error(void);
 

@@ -68,6 +68,7 @@ _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
     "tb_gemm_ln_epilogue_ok": ([C.c_int64, C.c_int64, C.c_int64], C.c_int),
     "tb_last_hip_error": ([], C.c_char_p),
+    "tb_mfma_peak_probe": ([_VP, _I, _I, _VP], C.c_int),
     "tb_gemm_set_variant": ([_I], C.c_int),
     "tb_gemm_last_config": ([_VP], None),
     "tb_attention_set_variant": ([_I], C.c_int),
