@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll
       for (int e = 0; e < 8; ++e) gm[e] = bias_s[BN + cg * 8 + e], bt[e] = bias_s[2 * BN + cg * 8 + e];
       const int rrow = t >> 3, rj = t & 7;  // reducer role: row (threads with rrow >= PR sit out: whole waves), five-partial slice
-      auto reduce_rows = [&](bool second) {  // sums the UPR partials of every row; leaves (x, y) totals in all 8 lanes of the row's group
+      auto reduce_rows = [&]() {  // sums the UPR partials of this thread's row; leaves the (x, y) totals in all 8 lanes of the row's group
         f32x2_t a = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < UPR / 8; ++k) {
@@ -652,7 +652,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           a[0] += __shfl_xor(a[0], sft, 64);
           a[1] += __shfl_xor(a[1], sft, 64);
         }
-        (void)second;
         return a;
       };
       f16x8 rv1[NU];
@@ -713,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           if (rrow < PR) {
-            const f32x2_t a = reduce_rows(false);
+            const f32x2_t a = reduce_rows();
             if (rj == 0) rowst[rrow] = f32x2_t{a[0] * inv_n, 0.f};
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -736,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           if (rrow < PR) {
-            const f32x2_t a = reduce_rows(true);
+            const f32x2_t a = reduce_rows();
             if (rj == 0) {
               const float mean = rowst[rrow][0], rstd = rsqrtf(a[0] * inv_n + eps);
               rowst[rrow] = f32x2_t{mean, rstd};
@@ -782,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           if (rrow < PR) {
-            const f32x2_t a = reduce_rows(false);
+            const f32x2_t a = reduce_rows();
             if (rj == 0) rowst[rrow] = f32x2_t{a[0] * inv_n, a[1] * inv_n};
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

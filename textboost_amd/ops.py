@@ -250,9 +250,10 @@ def _attn_f32_workspace(dev, B, H, Sq, Skv):
     dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
     if dev.index is None:
         dev = torch.device(dev.type, torch.cuda.current_device())
-    ws = _attn_f32_ws.get(dev)
+    key = (dev, _ws_slot)  # one per concurrently running stream (workspace_slot): the KPL teacher on the trainer's side stream must not
+    ws = _attn_f32_ws.get(key)  # share score matrices with the UNet running beside it
     if ws is None or ws.numel() < need:
-        ws = _attn_f32_ws[dev] = torch.empty(need, device=dev, dtype=torch.float32)
+        ws = _attn_f32_ws[key] = torch.empty(need, device=dev, dtype=torch.float32)
     return ws
 
 

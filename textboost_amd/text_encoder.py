@@ -85,7 +85,9 @@ class HipTextEncoder:
             self.Wl.append(W)
         self.lnf_g, self.lnf_b = lnp(sd[pre + "final_layer_norm.weight"]), lnp(sd[pre + "final_layer_norm.bias"])
         if mode == "fp32":
-            ops.reserve_attention_f32(device, 3 * batch, geo.num_heads, self.T, self.T)   # student + prior + teacher rows in one pass
+            for slot in (0, 1, 2):  # (an encoder may run on the trainer's side streams: one score workspace per stream slot, sized before any capture)
+                with ops.workspace_slot(slot):
+                    ops.reserve_attention_f32(device, 3 * batch, geo.num_heads, self.T, self.T)   # student + prior + teacher rows in one pass
         self.null_embedding = torch.zeros(self.T, D, device=device, dtype=torch.float32)
         self.use_fixed_special_embedding = False
         self.first_added = self.token_table.shape[0]
