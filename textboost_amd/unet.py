@@ -634,11 +634,14 @@ class HipUNet:
                 skip_grad[k] = dcat[(i, j)][:, hc:]
         # down path in reverse: gradient of each skip tensor = grad from its down-path consumer + skip slice
         # g currently = gradient w.r.t. the last skip tensor coming from the mid block
-        for kind, fn, xin, xout, s_idx in reversed(S["down"]):
-            if s_idx is not None:
+        recs = list(reversed(S["down"]))
+        premerged = False  # the previous record's dgrad convolution already added this record's skip gradient (its epilogue residual)
+        for ri, (kind, fn, xin, xout, s_idx) in enumerate(recs):
+            if s_idx is not None and not premerged:
                 merged = self.buf(f"grad.skipmerge.{s_idx}", xout.shape[0], xout.shape[1])
                 ops.add_f16(g, skip_grad[s_idx], merged)
                 g = merged
+            premerged = False
             if kind == "attn":
                 tbwd, stop = fn
                 if stop:
@@ -654,7 +657,10 @@ class HipUNet:
             else:
                 name, lvl = fn
                 gx = self.buf(f"grad.down.{lvl}", xin.shape[0], xin.shape[1])
-                self._conv(g, name, gx, B, hw[lvl + 1][0], hw[lvl + 1][1], hw[lvl][0], hw[lvl][1], dgrad=True, transposed=1)
+                nxt = recs[ri + 1][4] if ri + 1 < len(recs) else None   # the layer in front of the downsampler wrote a skip tensor: its
+                R = skip_grad[nxt] if nxt is not None else None         # gradient rides in as the dgrad GEMM's residual (no add launch)
+                self._conv(g, name, gx, B, hw[lvl + 1][0], hw[lvl + 1][1], hw[lvl][0], hw[lvl][1], dgrad=True, transposed=1, R=R)
+                premerged = R is not None
                 g = gx
         # hoisted K/V dgrad -> d encoder_hidden_states (fp32)
         if d_ehs_out is None:
