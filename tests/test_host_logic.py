@@ -264,3 +264,16 @@ def test_bench_spawn_starts_n_ranks_with_the_rank_environment(tmp_path, monkeypa
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "r0").read_text() == "2 0 127.0.0.1 --gpus=2"
     assert (tmp_path / "r1").read_text() == "2 1 127.0.0.1 --gpus=2"
+
+
+def test_layernorm_epilogue_query_follows_the_row_spanning_tiles():
+    """tb_gemm_ln_epilogue_ok (host side of the library, no GPU needed): the fused LayerNorm epilogues exist exactly where a wide tile spans the
+    whole output row -- N = 320 with at least one chip round of 128- or 64-row tiles (the 64x64 maps at B >= 4 / 2); everything else keeps the
+    separate tb_layernorm_* launches."""
+    from textboost_amd import _lib as L
+    ok = lambda M, N, K: bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))  # noqa: E731
+    assert ok(8 * 4096, 320, 320) and ok(8 * 4096, 320, 2560) and ok(16 * 4096, 320, 960)       # metric batch, B = 16
+    assert ok(4 * 4096, 320, 320) and ok(200 * 64, 320, 64)                                      # 64-row tiles from 200 tiles on
+    assert not ok(4096, 320, 320) and not ok(199 * 64, 320, 320)                                 # less than one round: B = 1
+    assert not ok(8 * 1024, 640, 640) and not ok(8 * 4096, 160, 320)                             # no tile spans N = 640; N must be 320
+    assert not ok(8 * 4096, 320, 100) and not ok(8 * 4096 + 8, 320, 320)                         # K % 64, ragged M
