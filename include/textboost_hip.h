@@ -75,6 +75,11 @@ typedef struct tb_gemm_desc {
   const float* ln_gamma; const float* ln_beta; /* fp32 [N]; ln_beta unused by LN_BWD */
   float* ln_stats;               /* fp32 [M, 2] (mean, rstd): written by LN_FWD, read by LN_BWD */
   float ln_eps;
+  /* optional: sync_count uint32 counters, ZERO before the first call and left zero by every call (one buffer per stream that runs tb_gemm
+   * concurrently): a split-K launch (see `ws`) with at most sync_count output tiles then adds its k-slices inside the kernel -- the slice that
+   * arrives last at its tile's counter reduces, same arithmetic and order as the separate reducer -- instead of launching a second kernel.
+   * Opt-in (tb_gemm_set_variant(9801)): measured SLOWER than the reducer launch (the partials must be written and read coherently) */
+  uint32_t* sync; int64_t sync_count;
 } tb_gemm_desc;
 
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);

@@ -377,3 +377,37 @@ def test_transposed_dgrad_phase_ordered_rows(B, Co, Ci, H, W, res):
         ref = ref + R.float()
     parity("phase-ordered transposed dgrad", outs[0], ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
     assert torch.equal(outs[0], outs[1]) or rel_err(outs[0], outs[1]) < 3e-4
+
+
+@pytest.mark.parametrize("M,N,K,conv", [(616, 768, 24960, None), (1848, 768, 3072, None), (512, 1280, 1280, "8x8"), (2048, 640, 5120, None)])
+def test_split_k_reduced_inside_the_kernel_is_bit_equal_to_the_reducer_launch(M, N, K, conv):
+    """tb_gemm_desc.sync (round 3): the k-slice that arrives last at its tile's counter adds the partials in slice order and applies the epilogue --
+    the same arithmetic as splitk_reduce_kernel, so the results are bit-equal; the counters are left zeroed; repeated launches reuse them."""
+    ops, L = _ops()
+    torch.manual_seed(8)
+    bias = torch.randn(N, device="cuda")
+    R = torch.randn(M, N, device="cuda")
+    if conv:
+        B, H, C = 8, 8, 1280
+        x = torch.randn(B * H * H, C, device="cuda").half()
+        w = (torch.randn(N, 9 * C, device="cuda") / 100).half()
+        geo = dict(B=B, Hin=H, Win=H, Cin=C, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+        run = lambda out: ops.gemm(x, w, out, conv=geo, bias=bias, R=R)  # noqa: E731
+    else:
+        A = torch.randn(M, K, device="cuda").half()
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+        run = lambda out: ops.gemm(A, W, out, bias=bias, R=R, act=L.ACT_SILU)  # noqa: E731
+    outs = []
+    import ctypes
+    for knob in (9800, 9801, 9801):
+        L.lib().tb_gemm_set_variant(knob)
+        out = torch.zeros(M, N, device="cuda")
+        run(out)
+        cfg = (ctypes.c_int * 5)()
+        L.lib().tb_gemm_last_config(cfg)
+        outs.append(out)
+    L.lib().tb_gemm_set_variant(9800)   # (the default: measured slower in the step, DESIGN.md section 4)
+    torch.cuda.synchronize()
+    assert cfg[4] > 1 or L.lib().tb_gemm8_last(None), f"this shape was not split over K (config {list(cfg)})"
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert int(ops._gemm_sync_counters(out.device).abs().sum()) == 0

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("C2", C.c_void_p), ("ldc2", C.c_int64),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
+        ("sync", C.c_void_p), ("sync_count", C.c_int64),
     ]
 
 

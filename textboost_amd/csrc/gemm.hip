@@ -24,13 +24,25 @@
 namespace {
 
 // split-K second pass: C = epilogue(sum_s ws[s][m][n]); ws is fp32 [S][M][Npad] with Npad = N rounded up to 8
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p, const float* __restrict__ ws, int S, int64_t npad) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t groups = npad >> 3;
-  if (idx >= p.M * groups) return;
-  const int64_t m = idx / groups;
-  const int64_t n = (idx - m * groups) << 3;
-  const EpiFlags f = epi_flags(p);
+// 16 bytes of a partial written by ANOTHER workgroup of the same launch (in-kernel reduction): agent-scope loads, coherent at the memory side
+__device__ __forceinline__ f32x4 load_partial_coherent(const float* src) {
+  typedef unsigned long long u64;
+  const u64 a = __hip_atomic_load((const u64*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load((const u64*)src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f32x4 v;
+  v[0] = __uint_as_float((unsigned)a), v[1] = __uint_as_float((unsigned)(a >> 32));
+  v[2] = __uint_as_float((unsigned)b), v[3] = __uint_as_float((unsigned)(b >> 32));
+  return v;
+}
+__device__ __forceinline__ void store_partial_coherent(float* dst, const f32x4& v) {
+  typedef unsigned long long u64;
+  __hip_atomic_store((u64*)dst, (u64)__float_as_uint(v[0]) | ((u64)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((u64*)dst + 1, (u64)__float_as_uint(v[2]) | ((u64)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one (row, 8-column) unit of the split-K second pass: C = epilogue(sum_s ws[s][m][n]) in slice order (deterministic)
+template <bool COHERENT>
+__device__ __forceinline__ void splitk_reduce_unit(const tb_gemm_desc& p, const EpiFlags& f, const float* __restrict__ ws, int S, int64_t npad,
+                                                   int64_t m, int64_t n) {
   float r8[8], b8[8];
   epi_load_r8(p, f, m, n, r8);
   const f16x8 aux = epi_load_aux8(p, f, m, n);
@@ -43,8 +55,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
     f32x4 x[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      x[2 * k] = *(const f32x4*)(src + (s + k) * plane);
-      x[2 * k + 1] = *(const f32x4*)(src + (s + k) * plane + 4);
+      x[2 * k] = COHERENT ? load_partial_coherent(src + (s + k) * plane) : *(const f32x4*)(src + (s + k) * plane);
+      x[2 * k + 1] = COHERENT ? load_partial_coherent(src + (s + k) * plane + 4) : *(const f32x4*)(src + (s + k) * plane + 4);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -55,7 +67,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
       }
   }
   for (; s < S; ++s) {
-    const f32x4 x0 = *(const f32x4*)(src + s * plane), x1 = *(const f32x4*)(src + s * plane + 4);
+    const f32x4 x0 = COHERENT ? load_partial_coherent(src + s * plane) : *(const f32x4*)(src + s * plane);
+    const f32x4 x1 = COHERENT ? load_partial_coherent(src + s * plane + 4) : *(const f32x4*)(src + s * plane + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[e] += x0[e];
@@ -65,13 +78,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
   epilogue8(p, f, m, n, v, b8, r8, aux);
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p, const float* __restrict__ ws, int S, int64_t npad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t groups = npad >> 3;
+  if (idx >= p.M * groups) return;
+  const int64_t m = idx / groups;
+  const int64_t n = (idx - m * groups) << 3;
+  const EpiFlags f = epi_flags(p);
+  splitk_reduce_unit<false>(p, f, ws, S, npad, m, n);
+}
+
 // Shared epilogue of the MFMA kernels (gemm_kernel, conv_halo_kernel): accumulators -> LDS -> coalesced global writes.
 // PASSES = 2 stages the tile in two halves of BM/2 rows (the rows of the waves with wm == pass), which halves the LDS the epilogue
 // needs: with 32-wide k-tiles the operand stages then bound the block's LDS and a third / fourth block fits on the CU.
 template <int BM, int BN, int TM, int TN, int PASSES>
 __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, int64_t m0, int64_t n0,
                                               int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad, int mshift = 30,
-                                              int mstride = 0, bool lean_ok = true) {
+                                              int mstride = 0, bool lean_ok = true, int tile_id = 0) {
   // tile row r (0..BM-1) is output row  m0 + (r >> mshift) * mstride + (r & (2^mshift - 1)):  contiguous rows for the GEMMs (defaults),
   // a 2^mshift-pixel-wide block of image rows (mstride = image width) for the LDS-halo conv
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -198,8 +221,11 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
             if (m >= p.M) continue;
             float* dst = ws + ((int64_t)slice * p.M + m) * npad + n;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-              *(f32x4*)(dst + 4 * q) = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 v = *(const f32x4*)(Cs + row * BN + (((cg * 2 + q) ^ (row & 7)) << 2));
+              if (p.sync) store_partial_coherent(dst + 4 * q, v);  // read back by the last slice of this launch (below)
+              else *(f32x4*)(dst + 4 * q) = v;
+            }
           }
         } else if (fast) {
           // Lean path (every UNet launch and the CLIP out / fc2 projections): the descriptor fields are in locals -- read through `p` in
@@ -310,6 +336,39 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
       }
     }
     if (pass + 1 < PASSES) __syncthreads();  // the next half overwrites the staging tile
+  }
+  // In-kernel split-K reduction (p.sync: one zeroed counter per tile, left zeroed): the slice that arrives LAST at the tile's counter adds the S
+  // partials in slice order -- the arithmetic of splitk_reduce_kernel, bit for bit -- and applies the epilogue; no second launch (a graph node
+  // costs ~4.8 us before it does anything).  No cache-wide fences: partials are written and read with agent-scope accesses
+  // (coherent at the memory side whichever XCD a slice ran on); the arrival counter is an agent-scope atomic issued after the stores completed.
+  if (S > 1 && p.sync) {
+    __shared__ int last_slice;
+    __syncthreads();  // (s_waitcnt vmcnt(0): every thread's partial stores have been acknowledged)
+    if (t == 0) {
+      const unsigned old = __hip_atomic_fetch_add(p.sync + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_slice = old == (unsigned)(S - 1);
+      if (last_slice) __hip_atomic_store(p.sync + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_slice) return;
+    constexpr int UPRT = BN / 8;
+    for (int u = t; u < BM * UPRT; u += 256) {
+      const int r = u / UPRT, cgu = u - r * UPRT;
+      int64_t m = m0 + (int64_t)(r >> mshift) * mstride + (r & ((1 << mshift) - 1));
+      const int64_t n = n0 + cgu * 8;
+      if (m >= p.M || n >= p.N) continue;
+      if (p.a_mode == TB_A_CONV3X3 && p.transposed == 2) {  // phase-ordered tile rows back to map order (as m_of above)
+        const int64_t mq = p.M >> 2;
+        const int cls = (int)(m / mq), q = 3 - cls;
+        const int64_t rr = m - (int64_t)cls * mq;
+        const int hc = p.Hout >> 1, wc = p.Wout >> 1;
+        const int b = (int)(rr / (hc * wc));
+        const int rem = (int)(rr - (int64_t)b * hc * wc);
+        const int i2 = rem / wc, j2 = rem - i2 * wc;
+        m = ((int64_t)b * p.Hout + 2 * i2 + (q >> 1)) * p.Wout + 2 * j2 + (q & 1);
+      }
+      splitk_reduce_unit<true>(p, ef, ws, S, npad, m, n);
+    }
   }
 }
 
@@ -652,7 +711,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
 #undef SWZ
 
   if (abl & 4) return;  // profiling: no epilogue
-  tile_epilogue<BM, BN, TM, TN, (BKT == 32 ? 2 : 1)>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, 30, 0, !(abl & 8));
+  tile_epilogue<BM, BN, TM, TN, (BKT == 32 ? 2 : 1)>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, 30, 0, !(abl & 8), tm * tiles_n + tn);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -802,10 +861,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
     }
   }
 #undef SWZ
-  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, wshift, W);
+  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, wshift, W, true, tm * tiles_n + tn);
 }
 
 
+int g_inkernel_reduce = 0;  // split-K launches with tb_gemm_desc.sync reduce in the kernel (tb_gemm_set_variant(9800 + {0,1})).  OFF: bit-equal to the
+                            // reducer launch, but the agent-scope partial stores / loads it needs make the step 35.1 ms against 31.3 (scratch/ab_step.py)
 int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
 int g_order = 0;    // tile order: 0 = 8-row groups (default), 1 = n-fastest, 2 = m-fastest (tb_gemm_set_variant(3000 + v))
 int g_halo = 1;     // 3x3 stride-1 convs on whole image rows use conv_halo_kernel (tb_gemm_set_variant(7000 + {0,1}))
@@ -830,9 +891,12 @@ int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   // tile order inside each XCD's contiguous range (A/B in situ on one MI355X: n-fastest 22.39, m-fastest 21.62, a bytes-to-fabric
   // cost model 22.11, 8-row groups 22.55 steps/s): what matters is that the ~64 blocks co-resident on an XCD share few k-slices
   const int m_fastest = g_order == 0 ? 3 : (g_order == 2 ? 1 : 0);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, BKT, NST>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, d, tiles_m,
+  tb_gemm_desc dk = d;  // the kernel reduces the k-slices itself when the caller gave it one zeroed counter per tile (tb_gemm_desc.sync)
+  const bool inkernel = S > 1 && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
+  if (!inkernel) dk.sync = nullptr;
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, BKT, NST>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m,
                      tiles_n, S, (float*)d.ws, npad, g_ablate, m_fastest);
-  if (S > 1)
+  if (S > 1 && !inkernel)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
                        npad);
   TB_CHECK_LAUNCH();
@@ -889,9 +953,12 @@ int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
       return TB_ELAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<BN>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, d, tiles_m, tiles_n, wshift, S,
+  tb_gemm_desc dk = d;
+  const bool inkernel = S > 1 && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
+  if (!inkernel) dk.sync = nullptr;
+  hipLaunchKernelGGL((conv_halo_kernel<BN>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m, tiles_n, wshift, S,
                      (float*)d.ws, npad);
-  if (S > 1)
+  if (S > 1 && !inkernel)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
                        npad);
   TB_CHECK_LAUNCH();
@@ -979,6 +1046,7 @@ extern "C" void tb_gemm_last_config(int* out5) {
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
   if (v >= 9900) g_phase = v - 9900;
+  else if (v >= 9800) g_inkernel_reduce = v - 9800;
   else if (v >= 9000) g_conv_narrow = v - 9000;
   else if (v >= 8000) g_force_tile = v - 8000;
   else if (v >= 7000) g_halo = v - 7000;

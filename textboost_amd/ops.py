@@ -72,6 +72,18 @@ def _gemm_workspace(dev):
     return ws
 
 
+_gemm_sync = {}
+GEMM_SYNC_COUNTERS = 16384  # tb_gemm_desc.sync: one zeroed counter per output tile of a split-K launch (left zeroed by the kernels)
+
+
+def _gemm_sync_counters(dev):
+    key = (dev, _ws_slot)
+    t = _gemm_sync.get(key)
+    if t is None:
+        t = _gemm_sync[key] = torch.zeros(GEMM_SYNC_COUNTERS, device=dev, dtype=torch.int32)
+    return t
+
+
 def gemm_ln_ok(M, N, K, dtype=torch.float16):
     """can a fp16 Linear of this shape carry a fused LayerNorm epilogue (`gemm(..., ln_fwd=... / ln_bwd=...)`)?"""
     return dtype == torch.float16 and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
@@ -138,6 +150,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
         return out
     ws = _gemm_workspace(out.device)
     d.ws, d.ws_bytes = L.ptr(ws), ws.numel() * 4
+    sync = _gemm_sync_counters(out.device)
+    d.sync, d.sync_count = L.ptr(sync), sync.numel()
     # algorithmic bytes: every operand read once, the output written once (conv: the input image once, not once per tap)
     a_elems = M * conv["Cin"] if conv is not None else M * d.K
     # GEGLU writes [M, N/2] gated values plus the [M, N] pre-gate projections (C2); GEGLU_GRAD reads those and writes [M, 2N]
