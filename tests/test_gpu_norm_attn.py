@@ -330,3 +330,38 @@ def test_attention_backward_software_pipelined_kernels(B, H, S):
         parity("pipelined dQ", res[0][:, :C].reshape(B, S, C), qr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
         parity("pipelined dK", res[0][:, C:2 * C].reshape(B, S, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
         parity("pipelined dV", res[0][:, 2 * C:].reshape(B, S, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+
+
+@pytest.mark.parametrize("B,H,S,causal", [(3, 12, 77, True), (16, 12, 77, True), (2, 16, 77, True), (1, 3, 77, False), (2, 4, 96, True), (2, 4, 33, True)])
+def test_attention_backward_short_sequence_in_one_launch(B, H, S, causal):
+    """csrc/attention_small.hip (round 3): dQ, dK, dV of a short hd = 64 sequence -- the CLIP text encoder's causal 77 x 77 self-attention -- from one
+    workgroup per (batch, head), against fp32 autograd and against the generic dQ + dK/dV launches (bit 8192 of tb_attention_set_variant)."""
+    ops = _ops()
+    from textboost_amd import _lib as L
+    torch.manual_seed(9)
+    hd = 64
+    C = H * hd
+    qkv = torch.randn(B * S, 3 * C, device="cuda").half()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o = torch.empty(B * S, C, device="cuda", dtype=torch.float16)
+    lse = torch.empty(B, H, S, device="cuda")
+    ops.attention_fwd(q, k, v, o, lse, B, H, S, S, hd, causal=causal)
+    do = torch.randn(B * S, C, device="cuda").half()
+    qr, kr, vr = [t.float().reshape(B, S, C).requires_grad_(True) for t in (q, k, v)]
+    oref, _ = ref_attention(qr, kr, vr, H, causal)
+    oref.backward(do.float().view(B, S, C))
+    res = []
+    old = L.lib().tb_attention_set_variant(1)
+    for bits in (1, 1 | 8192):
+        L.lib().tb_attention_set_variant(bits)
+        delta = torch.empty(B, H, S, device="cuda")
+        dqkv = torch.zeros(B * S, 3 * C, device="cuda", dtype=torch.float16)
+        ops.attention_bwd(q, k, v, o, lse, do, delta, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, H, S, S, hd, causal=causal)
+        res.append(dqkv)
+    L.lib().tb_attention_set_variant(old)
+    for name, dqkv in (("one launch", res[0]), ("generic", res[1])):
+        parity(f"short-sequence dQ ({name})", dqkv[:, :C].reshape(B, S, C), qr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+        parity(f"short-sequence dK ({name})", dqkv[:, C:2 * C].reshape(B, S, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+        parity(f"short-sequence dV ({name})", dqkv[:, 2 * C:].reshape(B, S, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+    assert not torch.equal(res[0], res[1]), "the one-launch kernel did not run"
+    assert rel_err(res[0], res[1]) < 2e-3

@@ -1724,5 +1724,7 @@ extern "C" int tb_attention_bwd(const tb_attn_desc* dp, tb_stream_t stream) {
   const tb_attn_desc d = *dp;
   int rc = check_desc(d, true);
   if (rc) return rc;
+  // short sequences with hd = 64 (the CLIP text encoder's 77 x 77 self-attention): dQ, dK and dV in ONE launch (attention_small.hip)
+  if (!(g_attn_dma & 8192) && tb_attn_small_bwd_ok(d)) return tb_attn_small_bwd(d, (hipStream_t)stream);
   DISPATCH_HD(launch_bwd, d, (hipStream_t)stream);
 }
