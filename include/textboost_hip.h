@@ -80,6 +80,12 @@ typedef struct tb_gemm_desc {
    * arrives last at its tile's counter reduces, same arithmetic and order as the separate reducer -- instead of launching a second kernel.
    * Opt-in (tb_gemm_set_variant(9801)): measured SLOWER than the reducer launch (the partials must be written and read coherently) */
   uint32_t* sync; int64_t sync_count;
+  /* optional HOST pointer (round 4): when non-NULL, a launch that splits K leaves its fp32 partials in `ws` -- layout [S][M][Npad], Npad = N
+   * rounded up to 8, the epilogue NOT applied and C not written -- and writes S to *split_out instead of running the reducer; the caller then
+   * hands (ws, S, Npad, bias, rowbias, R) to a consumer that adds the slices itself (tb_groupnorm_fwd_splitk / tb_groupnorm_bwd_splitk: the
+   * reduction, the conv epilogue and the GroupNorm in one launch).  *split_out = 1 means the launch was not split and C holds the result as
+   * usual.  Honoured for act NONE, fp16 C, alpha == 1 and no C2; never for the phase-ordered stride-2 dgrad. */
+  int32_t* split_out;
 } tb_gemm_desc;
 
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
@@ -120,6 +126,20 @@ int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const flo
 int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,
                      const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx, float* ws,
                      int B, int HW, int C, int G, int silu, tb_stream_t stream);
+/* GroupNorm straight off the fp32 split-K partials of the convolution that produces its input (tb_gemm_desc.split_out): one workgroup per
+ * (image, group) adds the S slices in slice order, applies the convolution's epilogue -- x = fp16(((sum + bias[n]) + R[m,n]) + rowbias[b,n]), the
+ * arithmetic of tb_gemm's reducer bit for bit -- writes x (the tensor the backward and the skip connections read), and normalises from registers.
+ * Replaces the reducer launch + tb_groupnorm_fwd of ResnetBlock2D's conv1 -> norm2 and conv2 -> next norm1 on the 16x16 / 8x8 maps.
+ * Available when tb_groupnorm_splitk_ok (the one-pass per-(image, group) kernels: C / G a multiple of 8, the slice fits a workgroup's registers).
+ * part: fp32 [S][B*HW][npad]; bias fp32 [C] or NULL; rowbias fp32 [B, ldrb] or NULL; R fp16 [B*HW, ldr] or NULL. */
+int tb_groupnorm_splitk_ok(int B, int HW, int C, int G);
+int tb_groupnorm_fwd_splitk(const float* part, int S, int64_t npad, const float* bias, const float* rowbias, int64_t ldrb, const void* R,
+                            int64_t ldr, void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta, float* stats,
+                            int B, int HW, int C, int G, float eps, int silu, tb_stream_t stream);
+/* backward twin: dy = fp16(sum of the dgrad convolution's slices) never goes to memory; dx = GN'(dy) (+ add) */
+int tb_groupnorm_bwd_splitk(const float* part, int S, int64_t npad, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                            const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx, int B, int HW, int C, int G,
+                            int silu, tb_stream_t stream);
 
 /* ---- LayerNorm over rows [M, C]; x fp16 (UNet) or fp32 (CLIP residual stream), y fp16|fp32 ----
  * Replaces torch.nn.LayerNorm in diffusers BasicTransformerBlock and transformers CLIPEncoderLayer /

@@ -411,3 +411,99 @@ def test_split_k_reduced_inside_the_kernel_is_bit_equal_to_the_reducer_launch(M,
     assert cfg[4] > 1 or L.lib().tb_gemm8_last(None), f"this shape was not split over K (config {list(cfg)})"
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     assert int(ops._gemm_sync_counters(out.device).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,res,silu", [(8, 1280, 1280, 16, False, True), (8, 2560, 1280, 16, True, True), (8, 1280, 1280, 8, True, False),
+                                                   (8, 2560, 1280, 8, False, True), (8, 640, 1280, 16, True, True)])
+def test_split_k_slices_added_by_the_groupnorm_behind_the_convolution(B, Cin, Cout, H, res, silu):
+    """round 4 (tb_gemm_desc.split_out + tb_groupnorm_fwd_splitk / tb_groupnorm_bwd_splitk): on the 16x16 / 8x8 maps the split-K convolution
+    leaves its fp32 slices to the GroupNorm launch behind it, which adds them in slice order, applies the convolution's epilogue (bias, time-
+    embedding row bias, residual), writes the convolution's output and normalises -- reducer + GroupNorm arithmetic, so everything is BIT-equal
+    to the three-launch sequence; the backward twin never materialises dy."""
+    ops, L = _ops()
+    torch.manual_seed(21)
+    M, HW = B * H * H, H * H
+    x = torch.randn(M, Cin, device="cuda").half()
+    w = (torch.randn(Cout, 9 * Cin, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    rowbias = torch.randn(B, Cout + 64, device="cuda")[:, 32:32 + Cout]
+    R = torch.randn(M, Cout + 8, device="cuda").half()[:, :Cout] if res else None
+    gamma, beta = torch.randn(Cout, device="cuda") * 0.5 + 1, torch.randn(Cout, device="cuda") * 0.3
+    ws = torch.empty(ops.groupnorm_ws(B, HW, Cout), device="cuda")
+    geo = dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+    assert ops.groupnorm_splitk_ok(B, HW, Cout)
+    # three launches: convolution, reducer (inside ops.gemm), GroupNorm
+    h_ref = torch.empty(M, Cout, device="cuda", dtype=torch.float16)
+    ops.gemm(x, w, h_ref, conv=geo, bias=bias, rowbias=rowbias, rows_per_group=HW, R=R)
+    y_ref, st_ref = torch.empty_like(h_ref), torch.empty(B, 32, 2, device="cuda")
+    ops.groupnorm_fwd(h_ref, y_ref, gamma, beta, st_ref, ws, B, HW, Cout, silu=silu)
+    # two launches
+    hbuf = torch.zeros(M, Cout + 16, device="cuda", dtype=torch.float16)
+    h = hbuf[:, 8:8 + Cout]
+    pk = ops.gemm(x, w, h, conv=geo, bias=bias, rowbias=rowbias, rows_per_group=HW, R=R, defer=True)
+    assert isinstance(pk, ops.SplitKPartials) and pk.S > 1, "this shape was not split over K"
+    assert float(hbuf.abs().max()) == 0.0   # the convolution's output has NOT been written yet
+    y, st = torch.empty_like(h_ref), torch.empty_like(st_ref)
+    ops.groupnorm_fwd(h, y, gamma, beta, st, ws, B, HW, Cout, silu=silu, partials=pk)
+    assert torch.equal(h, h_ref) and torch.equal(y, y_ref) and torch.equal(st, st_ref)
+    assert float(hbuf[:, :8].abs().max()) == 0.0 and float(hbuf[:, 8 + Cout:].abs().max()) == 0.0
+    # backward: dgrad convolution (no epilogue) -> GroupNorm backward (+ add)
+    dy = torch.randn(M, Cout, device="cuda").half()
+    wd = (torch.randn(Cin, 9 * Cout, device="cuda") / (3 * Cout ** 0.5)).half()
+    gin, bin_ = torch.randn(Cin, device="cuda") * 0.5 + 1, torch.randn(Cin, device="cuda") * 0.3
+    geo_d = dict(B=B, Hin=H, Win=H, Cin=Cout, Hout=H, Wout=H, stride=1, sign=-1, upsample=0, transposed=0)
+    if ops.groupnorm_splitk_ok(B, HW, Cin):
+        stx, a1 = torch.empty(B, 32, 2, device="cuda"), torch.empty(M, Cin, device="cuda", dtype=torch.float16)
+        ops.groupnorm_fwd(x, a1, gin, bin_, stx, ws, B, HW, Cin, silu=silu)
+        add = torch.randn(M, Cin, device="cuda").half()
+        da_ref = torch.empty(M, Cin, device="cuda", dtype=torch.float16)
+        ops.gemm(dy, wd, da_ref, conv=geo_d)
+        dx_ref = torch.empty_like(da_ref)
+        ops.groupnorm_bwd(da_ref, x, gin, bin_, stx, dx_ref, ws, B, HW, Cin, silu=silu, add=add)
+        da = torch.zeros_like(da_ref)
+        pk = ops.gemm(dy, wd, da, conv=geo_d, defer=True)
+        if isinstance(pk, ops.SplitKPartials):   # (1280 -> 2560 at 16x16 has enough tiles and is not split)
+            dx = torch.empty_like(dx_ref)
+            ops.groupnorm_bwd(da, x, gin, bin_, stx, dx, ws, B, HW, Cin, silu=silu, add=add, partials=pk)
+            assert torch.equal(dx, dx_ref) and float(da.abs().max()) == 0.0
+        else:
+            assert pk is da and torch.equal(da, da_ref) and Cin == 2560 and H == 16
+    # a launch that is NOT split writes its output as usual and returns it
+    xs = torch.randn(8 * 64 * 64, 320, device="cuda").half()
+    ws_ = (torch.randn(320, 9 * 320, device="cuda") / 50).half()
+    o = torch.empty(8 * 64 * 64, 320, device="cuda", dtype=torch.float16)
+    r = ops.gemm(xs, ws_, o, conv=dict(B=8, Hin=64, Win=64, Cin=320, Hout=64, Wout=64, stride=1, sign=1, upsample=0, transposed=0), defer=True)
+    assert r is o
+
+
+def test_unet_with_and_without_deferred_split_k_reduction_is_bit_equal():
+    """the whole executor (SD-shaped tiny UNet at B = 8, where the 8x8 / 4x4 maps split K): forward and dgrad backward with the reducer launches
+    (TB_DEFER_SPLITK=0 behaviour) and with the GroupNorm launches adding the slices must give identical bits"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_model import make_unet
+    ops, L = _ops()
+    B, hw, D = 8, 32, 64
+    ref, hip, cfg = make_unet(B, hw, D, channels=(64, 128, 256, 256))   # 8-channel groups on the 8x8 / 4x4 maps: the one-pass GroupNorm kernels
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, hw, hw, generator=g).half().cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    ehs = torch.randn(B * 77, D, generator=g).half().cuda()
+    dpred = torch.randn(B, 4, hw, hw, generator=g).cuda()
+    outs = []
+    prev = ops.DEFER_SPLITK
+    try:
+        for flag in (False, True):
+            ops.DEFER_SPLITK = flag
+            ops.start_recording()
+            pred = hip.forward(x, t, ehs).clone()
+            d_ehs = hip.backward(dpred).clone()
+            names = [r[0] for r in ops.stop_recording()]
+            outs.append((pred, d_ehs, names))
+    finally:
+        ops.DEFER_SPLITK = prev
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not any("splitk" in n for n in outs[0][2])
+    nf, nb = sum(n == "groupnorm_fwd(splitk)" for n in outs[1][2]), sum(n == "groupnorm_bwd(splitk)" for n in outs[1][2])
+    print(f"[deferred split-K] {nf} forward and {nb} backward GroupNorm launches add their producer's slices")
+    assert nf >= 4 and nb >= 4

@@ -29,11 +29,13 @@ def round_fp16_(module):
     return module
 
 
-def make_unet(B=2, hw=16, cross_dim=64, seed=0, sd2=False):
+def make_unet(B=2, hw=16, cross_dim=64, seed=0, sd2=False, channels=None):
     from oracle.unet_sd import UNet2DCondition, UNetConfig
     from textboost_amd.unet import HipUNet, UNetGeometry
     torch.manual_seed(seed)
     cfg = UNetConfig.tiny(cross_dim)
+    if channels is not None:
+        cfg.block_out_channels = tuple(channels)
     if sd2:  # SD2.x structure: Linear proj_in/out, per-level head counts with a uniform head dim of 64
         cfg.use_linear_projection = True
         cfg.num_heads = (1, 2, 2, 2)
@@ -539,3 +541,43 @@ def test_encoder_forward_as_a_branch_beside_the_unet_head_is_bit_equal():
     for other in res[1:]:
         for a, b in zip(res[0], other):
             torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["autocast", "fp32"])
+def test_hip_text_encoder_on_the_reference_generated_fixture(mode):
+    """tests/golden/clip_textboost_tiny.pt was produced by the REFERENCE's own TextBoostModel (/root/reference/textboost/text_encoder.py:34-87,
+    generator tests/golden/make_golden.py): forward incl. both pins, and the gradients of sum(out * R).  The HIP encoder is run on the same
+    weights / ids directly (until round 4 the fixture only pinned the CPU oracle, so the HIP <-> reference link was transitive): hidden states,
+    the gradient of every token-embedding row the prompts use (from the returned input gradient) and the added-token rows' accumulated
+    gradient (what the optimizer consumes).  autocast = the fp16 mixed-precision arithmetic of the metric; fp32 = the no-AMP mode."""
+    import os
+    from textboost_amd.text_encoder import CLIPGeometry, HipTextEncoder
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_textboost_tiny.pt"))
+    c = g["cfg"]
+    V0 = 49408                                  # the fixture's table already carries 3 added rows (49408..49410)
+    n_added = c["V"] - V0
+    emb = torch.zeros(c["V"], c["D"])
+    emb[g["emb_rows_idx"]] = g["emb_rows"]
+    sd = {"text_model." + k: v for k, v in g["state_dict"].items()}
+    sd["text_model.embeddings.token_embedding.weight"] = emb[:V0]
+    geo = CLIPGeometry(vocab_size=V0, hidden_size=c["D"], intermediate_size=c["I"], num_layers=c["L"], num_heads=c["H"])
+    ids = g["ids"]
+    B, T, D = ids.shape[0], ids.shape[1], c["D"]
+    hip = HipTextEncoder(geo, sd, B, mode=mode, lora_rank=0, device=dev)
+    new_ids = hip.add_tokens([0] * n_added)
+    assert new_ids == list(range(V0, c["V"]))
+    hip.token_table[V0:] = emb[V0:].to(hip.token_table)
+    hip.set_null_embedding(g["null"])
+    out = hip.forward(ids.to(dev), slot=0)
+    tol = dict(rel=5e-4, maxabs=1e-3, ch_rel=2e-3) if mode == "autocast" else dict(rel=2e-6, maxabs=5e-6, ch_rel=5e-6)
+    parity(f"reference fixture, hidden states ({mode})", out.view(B, T, D), g["out"], ch_dim=2, **tol)
+    assert torch.equal(out.view(B, T, D)[:, 0].cpu(), g["null"][0].expand(B, -1))   # text_encoder.py:81-86
+    assert torch.equal(out.view(B, T, D)[2].cpu(), g["null"])                        # :71-79 (row 2 is the null prompt)
+    hip.zero_grad()
+    d_in = hip.backward(g["R"].reshape(B * T, D).to(dev).contiguous(), slot=0)       # gradient w.r.t. the embedded inputs, per position
+    flat = ids.reshape(-1).to(dev)
+    g_rows = torch.zeros(c["V"], D, device=dev).index_add_(0, flat, d_in.float())[g["emb_rows_idx"].to(dev)]
+    gtol = dict(rel=1.5e-3, maxabs=2e-3) if mode == "autocast" else dict(rel=5e-6, maxabs=1e-5)
+    parity(f"reference fixture, token-row gradients ({mode})", g_rows, g["g_emb_rows"], **gtol)
+    added_pos = [int((g["emb_rows_idx"] == t).nonzero()) for t in new_ids]
+    parity(f"reference fixture, added-row gradients ({mode})", hip.grad_added, g["g_emb_rows"][added_pos], **gtol)

@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
         ("sync", C.c_void_p), ("sync_count", C.c_int64),
+        ("split_out", C.POINTER(C.c_int32)),
     ]
 
 
@@ -81,6 +82,9 @@ _SIGS = {
     "tb_groupnorm_ws_floats": ([_I, _I, _I, _I], _I64),
     "tb_groupnorm_fwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
     "tb_groupnorm_bwd": ([_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _I, _I, _I, _I, _I, _VP], C.c_int),
+    "tb_groupnorm_splitk_ok": ([_I, _I, _I, _I], C.c_int),
+    "tb_groupnorm_fwd_splitk": ([_VP, _I, _I64, _VP, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP], C.c_int),
+    "tb_groupnorm_bwd_splitk": ([_VP, _I, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _I, _I, _I, _I, _I, _VP], C.c_int),
     "tb_layernorm_fwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _I, _F, _VP], C.c_int),
     "tb_layernorm_lora_fwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _I, _F, _VP, _I, _VP, _I64, _VP], C.c_int),
     "tb_layernorm_lora_rows_fwd": ([_VP, _I64, _I, _VP, _I64, _I, _VP, _VP, _VP, _I64, _I, _F, _VP, _I, _VP, _I64, _I64, _VP], C.c_int),

@@ -776,7 +776,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
 // Same construction for dQ (hd = 40, Sq % 128 == 0, Skv % 64 == 0, non-causal): K and V tiles by LDS-DMA, row-major, NST-slot ring; the
 // fragments of S^T = K Q^T and dP^T = V dO^T are ds_read_b128 of those rows, the K^T fragments of dQ^T += K^T dS^T come from the same K rows
 // through the transposing read.  Also computes delta = rowsum(dO * O) and publishes -lse log2(e) / -delta for attn_bwd_dkv_dma_kernel.
-template <int DT, int KS, int PC, int NST>
+// PAD = false (round 4, hd = 40): rows of hd / 8 chunks WITHOUT the pad chunk, i.e. an 80-byte pitch.  Nothing in this kernel needs the pad to hold
+// a value -- the statistics enter as accumulator inputs, and the k-step that runs past a row's end (columns hd .. 16 KS - 1) meets the zeros of the
+// lane-owned Q / dO fragments -- it only has to be FINITE: the next row's first chunk, or for the last row of the V tile the zeroed 64-byte slack
+// behind the stage.  80-byte rows put the 16 rows of a ds_read_b128 lane group on 16 distinct 16-byte bank slots (the 96-byte rows were a
+// 2-way conflict on every such read: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, profiles/r03_pmc_sq.txt) and the DMA moves 1/6 fewer bytes.
+template <int DT, int KS, int PC, int NST, bool PAD = true>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_desc p, int remap, int publish) {
   constexpr int PCB = PC * 16, TILE_B = KVT * PCB;
   constexpr int STAGE_B = 2 * TILE_B + 64;
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
     const int tensor = t >= PC ? 1 : 0;
     const int f = (t - tensor * PC) * 64 + lane;
     const int row = f / PC, c = f - row * PC;
-    g_on[i] = t < NI && c < PC - 1;
+    g_on[i] = t < NI && (!PAD || c < PC - 1);
     g_off[i] = (uint32_t)((int64_t)row * (tensor ? ldv : ldk) * 2 + c * 16);
   }
   int n_issued = 0;
@@ -851,10 +856,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
       }
     }
   };
-  for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {  // pad chunks: zeros (finite)
-    const int st = u / (2 * KVT), r = u - st * 2 * KVT;
+  if (PAD) {
+    for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {  // pad chunks: zeros (finite)
+      const int st = u / (2 * KVT), r = u - st * 2 * KVT;
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = z;
+    }
+  } else if (threadIdx.x < NST * 4) {  // the 64-byte slack behind every stage: what the last V row's over-long k-step reads
     const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = z;
+    *(f16x8*)(smem_raw + (threadIdx.x >> 2) * STAGE_B + 2 * TILE_B + (threadIdx.x & 3) * 16) = z;
   }
   const int ntiles = Skv / KVT;
 #pragma unroll
@@ -1609,6 +1619,10 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
         // (bit-equal results; PMC: 714 k cycles vs the LDS-DMA kernel's 697 k per launch at S = 4096, B = 8 -- no gain for this product mix)
         const int rc = tb_attn_il_dq(d, s, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
         if (rc) return rc;
+      } else if (dq_dma && DT == 2 && KS == 3 && !(g_attn_dma & 8192)) {   // hd = 40: 80-byte rows without the pad chunk (bit-equal results)
+        constexpr int PCN = 5;
+        const size_t ldsq = NST * (2 * KVT * PCN * 16 + 64);
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DT, KS, PCN, NST, false>), grid, dim3(256), ldsq, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
       } else if (dq_dma) {
         const size_t ldsq = NST * (2 * KVT * PC * 16 + 64);
         static bool attr_q = false;

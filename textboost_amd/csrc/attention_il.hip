@@ -435,7 +435,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_il_kernel(const tb_attn_desc 
 //                vector ALU   = p = exp2(s), ds = p * dp, fp16 packing of half k (48 instructions, 3.4 per MFMA)
 // so every MFMA is followed by a slice of the softmax work of the half in between; score registers and packed fragments are double-buffered
 // by the half's parity.  One barrier per 64-query tile, placed where the pipeline first touches the next tile.
-constexpr int D_PCB = 96, D_TILE_B = KVT * D_PCB, D_STAGE_B = 2 * D_TILE_B + 2 * KVT * 4 + 64, D_NST = 4;
+// Rows of hd / 8 = 5 chunks WITHOUT a pad chunk (round 4; 80-byte pitch: the b128 row reads of a 16-lane group land on 16 distinct bank slots, the
+// 96-byte rows were a 2-way conflict).  The k-step that runs past a row's end multiplies the zeros of the lane-owned K / V fragments, so what it
+// reads only has to be finite: the next row, the dO tile behind the Q tile, and behind the dO tile a zeroed 64-byte gap in front of the statistics
+// rows (raw fp32 bit patterns: NOT safe to read as fp16).  TB_IL_DKV_PAD=1 builds the padded layout of round 3.
+#ifndef TB_IL_DKV_PAD
+#define TB_IL_DKV_PAD 0
+#endif
+constexpr int D_PC = TB_IL_DKV_PAD ? 6 : 5, D_PCB = D_PC * 16, D_TILE_B = KVT * D_PCB, D_GAP = 64, D_STAGE_B = 2 * D_TILE_B + D_GAP + 2 * KVT * 4 + 64,
+              D_NST = 4;
 
 struct DkvState {
   f32x16 dk[2], dv[2];
@@ -539,7 +547,7 @@ __device__ __forceinline__ void dkv_phase(DkvState& st, uint32_t prev_tr, uint32
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_desc p, int remap) {
-  constexpr int PC = 6, NI = 2 * PC + 2, WI = (NI + 3) / 4;
+  constexpr int PC = D_PC, NI = 2 * PC + 2, WI = (NI + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_d
     const int tensor = t >= PC ? 1 : 0;
     const int f = (t - tensor * PC) * 64 + lane;
     const int row = f / PC, cc = f - row * PC;
-    g_on[i] = t < 2 * PC && cc < PC - 1;
+    g_on[i] = t < 2 * PC && (!TB_IL_DKV_PAD || cc < PC - 1);
     g_off[i] = (uint32_t)((int64_t)row * (tensor ? lddo : ldq) * 2 + cc * 16);
   }
   int n_issued = 0;
@@ -598,14 +606,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_d
         if (g_on[i]) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + t * 1024), 16, 0, 0);
       } else if (t < NI) {  // 64 floats = one dword per lane
         const char* src = (t == 2 * PC ? NLg : NDg) + ((int64_t)tile * KVT + lane) * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + 2 * D_TILE_B + (t - 2 * PC) * 256), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + 2 * D_TILE_B + D_GAP + (t - 2 * PC) * 256), 4, 0, 0);
       }
     }
   };
-  for (int u = threadIdx.x; u < 2 * KVT * D_NST; u += 256) {  // pad chunks of every row of every stage: zeros (finite)
-    const int s_ = u / (2 * KVT), r = u - s_ * 2 * KVT;
+  if (TB_IL_DKV_PAD) {
+    for (int u = threadIdx.x; u < 2 * KVT * D_NST; u += 256) {  // pad chunks of every row of every stage: zeros (finite)
+      const int s_ = u / (2 * KVT), r = u - s_ * 2 * KVT;
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *(f16x8*)(smem_raw + s_ * D_STAGE_B + (r >= KVT ? D_TILE_B : 0) + (r & (KVT - 1)) * D_PCB + (PC - 1) * 16) = z;
+    }
+  }
+  if (threadIdx.x < D_NST * 4) {  // the gap between the dO tile and the statistics rows of every stage
     const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    *(f16x8*)(smem_raw + s_ * D_STAGE_B + (r >= KVT ? D_TILE_B : 0) + (r & (KVT - 1)) * D_PCB + (PC - 1) * 16) = z;
+    *(f16x8*)(smem_raw + (threadIdx.x >> 2) * D_STAGE_B + 2 * D_TILE_B + (threadIdx.x & 3) * 16) = z;
   }
   const int n = p.Sq / KVT;  // >= 2 (launcher)
 #pragma unroll
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_d
   const uint32_t rm_lane = lds0 + l31 * D_PCB + hi * 16;
   const int g4 = lane >> 4, j16 = lane & 15;
   const uint32_t tr_lane = lds0 + (4 * (g4 >> 1) + (j16 >> 2)) * D_PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
-  const uint32_t stat0 = lds0 + 2 * D_TILE_B;
+  const uint32_t stat0 = lds0 + 2 * D_TILE_B + D_GAP;
   // tile t in slot t & 3.  `sync(t)`: tile t has landed for every wave, every wave is done with tile t - 2 (-> the loads of tile t + 2 go there)
   auto sync = [&](int t) {
     int later = n - 1 - t;
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_il_kernel(const tb_attn_d
 // reads with -lse log2(e) / -delta as accumulator inputs; dQ^T += K^T dS^T through the transposing read; also delta = rowsum(dO * O) and the
 // statistics the dK/dV kernel reads) as the same three-stage pipeline over 32-key halves:
 //     phase k:   matrix pipe = dQ of half k-1 (4 MFMAs) + S^T, dP^T of half k+1 (6 MFMAs);   vector ALU = dS = exp2(s) * dp, packing of half k
-constexpr int Q_STAGE_B = 2 * D_TILE_B + 64;
+constexpr int Q_PCB = 96, Q_TILE_B = KVT * Q_PCB, Q_STAGE_B = 2 * Q_TILE_B + 64;  // (the opt-in dQ kernel keeps the padded 96-byte rows)
 struct DqState {
   f32x16 dq[2];
   f32x16 s[2], dp[2];   // [parity of the half]
@@ -716,11 +730,11 @@ template <int N, int KT>
 __device__ __forceinline__ f16x8 dq_fetch(uint32_t prev_tr, uint32_t next_rm) {
   if constexpr (N < 4) {
     constexpr int jj = N >> 1, d = N & 1;
-    constexpr int off = (KT * 32 + 16 * jj) * D_PCB + d * 64;
-    return join8(tr_read<off>(prev_tr), tr_read<off + 8 * D_PCB>(prev_tr));
+    constexpr int off = (KT * 32 + 16 * jj) * Q_PCB + d * 64;
+    return join8(tr_read<off>(prev_tr), tr_read<off + 8 * Q_PCB>(prev_tr));
   } else {
     constexpr int j = (N - 4) >> 1, which = (N - 4) & 1;
-    return rm_read(next_rm + (which ? D_TILE_B : 0) + KT * 32 * D_PCB + j * 32);
+    return rm_read(next_rm + (which ? Q_TILE_B : 0) + KT * 32 * Q_PCB + j * 32);
   }
 }
 template <int N, int PAR>
@@ -845,16 +859,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_il_kernel(const tb_attn_de
   for (int u = threadIdx.x; u < 2 * KVT * D_NST; u += 256) {  // pad chunks: zeros (finite)
     const int s_ = u / (2 * KVT), r = u - s_ * 2 * KVT;
     const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    *(f16x8*)(smem_raw + s_ * Q_STAGE_B + (r >= KVT ? D_TILE_B : 0) + (r & (KVT - 1)) * D_PCB + (PC - 1) * 16) = z;
+    *(f16x8*)(smem_raw + s_ * Q_STAGE_B + (r >= KVT ? Q_TILE_B : 0) + (r & (KVT - 1)) * Q_PCB + (PC - 1) * 16) = z;
   }
   const int n = Skv / KVT;  // >= 2 (launcher)
 #pragma unroll
   for (int t = 0; t < D_NST - 1; ++t)
     if (t < n) stage_loads(t, t);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem_raw;
-  const uint32_t rm_lane = lds0 + l31 * D_PCB + hi * 16;
+  const uint32_t rm_lane = lds0 + l31 * Q_PCB + hi * 16;
   const int g4 = lane >> 4, j16 = lane & 15;
-  const uint32_t tr_lane = lds0 + (4 * (g4 >> 1) + (j16 >> 2)) * D_PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
+  const uint32_t tr_lane = lds0 + (4 * (g4 >> 1) + (j16 >> 2)) * Q_PCB + ((g4 & 1) * 16 + 4 * (j16 & 3)) * 2;
   auto sync = [&](int t) {
     int later = n - 1 - t;
     later = later > 1 ? 1 : later;

@@ -865,6 +865,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
 }
 
 
+// tb_gemm_desc.split_out: the caller adds the k-slices itself (a consumer kernel that reads the fp32 partials: tb_groupnorm_*_splitk) -- no reducer launch
+inline bool defer_reduce(const tb_gemm_desc& d, int S) {
+  return S > 1 && d.split_out && d.act == TB_ACT_NONE && d.c_dtype == TB_F16 && d.alpha == 1.f && !d.C2 && (!d.R || d.r_dtype == TB_F16) &&
+         !(d.a_mode == TB_A_CONV3X3 && d.transposed == 2);
+}
+
 int g_inkernel_reduce = 0;  // split-K launches with tb_gemm_desc.sync reduce in the kernel (tb_gemm_set_variant(9800 + {0,1})).  OFF: bit-equal to the
                             // reducer launch, but the agent-scope partial stores / loads it needs make the step 35.1 ms against 31.3 (scratch/ab_step.py)
 int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
@@ -892,11 +898,13 @@ int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   // cost model 22.11, 8-row groups 22.55 steps/s): what matters is that the ~64 blocks co-resident on an XCD share few k-slices
   const int m_fastest = g_order == 0 ? 3 : (g_order == 2 ? 1 : 0);
   tb_gemm_desc dk = d;  // the kernel reduces the k-slices itself when the caller gave it one zeroed counter per tile (tb_gemm_desc.sync)
-  const bool inkernel = S > 1 && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
+  const bool defer = defer_reduce(d, S);
+  const bool inkernel = S > 1 && !defer && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
   if (!inkernel) dk.sync = nullptr;
   hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, BKT, NST>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m,
                      tiles_n, S, (float*)d.ws, npad, g_ablate, m_fastest);
-  if (S > 1 && !inkernel)
+  if (defer) *d.split_out = S;
+  else if (S > 1 && !inkernel)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
                        npad);
   TB_CHECK_LAUNCH();
@@ -954,11 +962,13 @@ int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
     attr_done = true;
   }
   tb_gemm_desc dk = d;
-  const bool inkernel = S > 1 && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
+  const bool defer = defer_reduce(d, S);
+  const bool inkernel = S > 1 && !defer && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
   if (!inkernel) dk.sync = nullptr;
   hipLaunchKernelGGL((conv_halo_kernel<BN>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m, tiles_n, wshift, S,
                      (float*)d.ws, npad);
-  if (S > 1 && !inkernel)
+  if (defer) *d.split_out = S;
+  else if (S > 1 && !inkernel)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
                        npad);
   TB_CHECK_LAUNCH();
@@ -1071,6 +1081,7 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.K % BK) return TB_EINVAL;
   if (!d.A || !d.W || !d.C) return TB_EINVAL;
+  if (d.split_out) *d.split_out = 1;
   if (!d.A2 && !d.W2) d.K1 = d.K;
   if (d.K1 % BK || d.K1 > d.K || d.K1 <= 0) return TB_EINVAL;
   if ((d.A2 == nullptr) != (d.W2 == nullptr)) return TB_EINVAL;
@@ -1104,6 +1115,10 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   {
     int split8 = 1;
     const int r8 = tb_gemm8_try(d, s, &split8);
+    if (r8 == TB_OK && defer_reduce(d, split8)) {
+      *d.split_out = split8;
+      return TB_OK;
+    }
     if (r8 == TB_OK && split8 > 1) {
       const int64_t npad = (d.N + 7) & ~(int64_t)7;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws,

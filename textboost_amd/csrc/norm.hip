@@ -385,9 +385,99 @@ __device__ __forceinline__ void gnf_block_sum2(float& a, float& b, float* red /*
   b = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
+// Split-K source of a fused GroupNorm (tb_groupnorm_*_splitk): the fp32 k-slices of the producing convolution and its epilogue operands.
+// gnf_splitk_load8 is splitk_reduce_unit + epilogue8 of gemm.hip for act NONE / fp16 C / alpha 1, operation for operation (slice order, then
+// + bias, + residual, + row bias, one rounding to fp16), so the fused launch is bit-identical to reducer + GroupNorm.
+struct GnSplitK {
+  const float* part;      // [S][M][npad]
+  int S;
+  int64_t npad, plane;    // plane = M * npad
+  const float* bias;      // [C] or null
+  const float* rowbias;   // [B, ldrb] or null (time-embedding projection of the image)
+  int64_t ldrb;
+  const f16* R;           // residual [M, ldr] or null
+  int64_t ldr;
+};
+// All of a thread's items at once: the loads of every item of a slice (or of two slices, when few items are active) are issued before the first
+// add, so a workgroup has 10-20 16-byte loads per thread in flight instead of one dependent round trip per item (the first version of this
+// kernel ran exactly as long as the reducer launch it replaced).  Inactive items read item 0's address (valid memory, result ignored): no
+// branches around the loads.
+template <int VPT>
+__device__ __forceinline__ void gnf_splitk_load_all(const GnSplitK& k, int b, int HW, int g, int gs, int cv, int items, f16x8 (&out)[GNF_VPT]) {
+  float acc[VPT][8];
+  int64_t off[VPT], roff[VPT];
+  int col[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int it = threadIdx.x + i * 256;
+    const int itc = it < items ? it : 0;
+    const int r = itc / cv, c = itc - r * cv;
+    col[i] = g * gs + c * 8;
+    off[i] = ((int64_t)b * HW + r) * k.npad + col[i];
+    roff[i] = ((int64_t)b * HW + r) * k.ldr + col[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+  }
+  f16x8 rv[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    if (k.R) rv[i] = *(const f16x8*)(k.R + roff[i]);
+    else rv[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  constexpr int CH = VPT <= 2 ? 8 : (VPT <= 3 ? 6 : (VPT <= 5 ? 4 : 1));  // slices per round: <= 160 registers of loads in flight
+  int s = 0;
+  for (; s + CH <= k.S; s += CH) {
+    f32x4 x[VPT][CH][2];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        const float* src = k.part + off[i] + (s + j) * k.plane;
+        x[i][j][0] = *(const f32x4*)src;
+        x[i][j][1] = *(const f32x4*)(src + 4);
+      }
+#pragma unroll
+    for (int j = 0; j < CH; ++j)  // slice order
+#pragma unroll
+      for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[i][e] += x[i][j][0][e];
+          acc[i][4 + e] += x[i][j][1][e];
+        }
+  }
+  for (; s < k.S; ++s) {
+    f32x4 x[VPT][2];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const float* src = k.part + off[i] + s * k.plane;
+      x[i][0] = *(const f32x4*)src;
+      x[i][1] = *(const f32x4*)(src + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[i][e] += x[i][0][e];
+        acc[i][4 + e] += x[i][1][e];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = acc[i][e] * 1.f + (k.bias ? k.bias[col[i] + e] : 0.f) + (float)rv[i][e];
+      if (k.rowbias) t += k.rowbias[(int64_t)b * k.ldrb + col[i] + e];
+      out[i][e] = (f16)t;
+    }
+  }
+}
+
+template <bool SPLITK>
 __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ stats, int HW, int C, int G, float eps, int silu) {
+                                                           float* __restrict__ stats, int HW, int C, int G, float eps, int silu,
+                                                           const GnSplitK sk) {
   __shared__ float red[8];
   const int g = blockIdx.x, b = blockIdx.y, gs = C / G, cv = gs >> 3;
   const int items = HW * cv;
@@ -395,12 +485,26 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const f16* __restrict
   f16* yb = Y + (int64_t)b * HW * ldy + g * gs;
   f16x8 v[GNF_VPT];
   float s = 0.f, q = 0.f;
+  if (SPLITK) {  // x = the convolution's output, formed here from its k-slices and written for the backward / the skip connections
+    if (items <= 2 * 256) gnf_splitk_load_all<2>(sk, b, HW, g, gs, cv, items, v);
+    else if (items <= 3 * 256) gnf_splitk_load_all<3>(sk, b, HW, g, gs, cv, items, v);
+    else if (items <= 5 * 256) gnf_splitk_load_all<5>(sk, b, HW, g, gs, cv, items, v);
+    else gnf_splitk_load_all<GNF_VPT>(sk, b, HW, g, gs, cv, items, v);
+#pragma unroll
+    for (int i = 0; i < GNF_VPT; ++i) {
+      const int it = threadIdx.x + i * 256;
+      if (it < items) {
+        const int r = it / cv, c = it - r * cv;
+        *(f16x8*)(const_cast<f16*>(xb) + (int64_t)r * ldx + c * 8) = v[i];
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < GNF_VPT; ++i) {
     const int it = threadIdx.x + i * 256;
     if (it < items) {
       const int r = it / cv, c = it - r * cv;
-      v[i] = *(const f16x8*)(xb + (int64_t)r * ldx + c * 8);
+      if (!SPLITK) v[i] = *(const f16x8*)(xb + (int64_t)r * ldx + c * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float f = (float)v[i][e];
@@ -435,27 +539,35 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const f16* __restrict
   }
 }
 
+template <bool SPLITK>
 __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ X, int64_t ldx,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ stats, const f16* __restrict__ add, int64_t ldadd,
-                                                           f16* __restrict__ dX, int64_t lddx, int HW, int C, int G, int silu) {
+                                                           f16* __restrict__ dX, int64_t lddx, int HW, int C, int G, int silu,
+                                                           const GnSplitK sk) {
   __shared__ float red[8];
   const int g = blockIdx.x, b = blockIdx.y, gs = C / G, cv = gs >> 3;
   const int items = HW * cv;
   const f16* xb = X + (int64_t)b * HW * ldx + g * gs;
-  const f16* dyb = dY + (int64_t)b * HW * lddy + g * gs;
+  const f16* dyb = SPLITK ? nullptr : dY + (int64_t)b * HW * lddy + g * gs;
   const f16* ab = add ? add + (int64_t)b * HW * ldadd + g * gs : nullptr;
   f16* dxb = dX + (int64_t)b * HW * lddx + g * gs;
   const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
   f16x8 xh[GNF_VPT], dh[GNF_VPT];  // the slice's x and dy rows (both passes below work from these registers)
   float s1 = 0.f, s2 = 0.f;
+  if (SPLITK) {  // dy = the dgrad convolution's k-slices: never stored
+    if (items <= 2 * 256) gnf_splitk_load_all<2>(sk, b, HW, g, gs, cv, items, dh);
+    else if (items <= 3 * 256) gnf_splitk_load_all<3>(sk, b, HW, g, gs, cv, items, dh);
+    else if (items <= 5 * 256) gnf_splitk_load_all<5>(sk, b, HW, g, gs, cv, items, dh);
+    else gnf_splitk_load_all<GNF_VPT>(sk, b, HW, g, gs, cv, items, dh);
+  }
 #pragma unroll
   for (int i = 0; i < GNF_VPT; ++i) {
     const int it = threadIdx.x + i * 256;
     if (it < items) {
       const int r = it / cv, c = it - r * cv;
       xh[i] = *(const f16x8*)(xb + (int64_t)r * ldx + c * 8);
-      dh[i] = *(const f16x8*)(dyb + (int64_t)r * lddy + c * 8);
+      if (!SPLITK) dh[i] = *(const f16x8*)(dyb + (int64_t)r * lddy + c * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int ch = g * gs + c * 8 + e;
@@ -496,10 +608,212 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const f16* __restrict
     }
   }
 }
-int g_gn_fused = 1;  // tb_groupnorm_set_variant: 0 = always the two-pass kernels
+// ------------------------------------------------------------------------------------------- GroupNorm, one pass, any even group width (round 4)
+// The large maps (64x64 / 32x32, groups of 10 .. 60 channels) ran the two-pass kernels above: a statistics launch that reads x (and dy), then an
+// apply launch that reads them AGAIN -- at 10-35 us per launch these passes were 2.2 ms of the step at 2.4-2.9 TB/s.  Here one 1024-thread
+// workgroup owns an (image, group) slice at DWORD granularity (two channels per item; a pixel's slice is gs / 2 consecutive dwords, 4-byte
+// aligned for any even gs), holds it in registers (<= NV dwords per thread), reduces in the block and normalises from the registers: x (and dy)
+// are read once and there is one launch.  A wave's 64 consecutive items cover 64 / (gs / 2) pixels, i.e. a handful of 128-byte lines per load
+// instruction instead of two -- paid in the CU's L1, which has nothing else to do here.  The lines of a pixel row are shared by the 32 groups of
+// the image: the block -> slice map gives every XCD a contiguous run of slices (a whole image at B = 8), so they meet in one L2 and HBM sees the
+// tensor once.
+constexpr int GNS_T = 1024, GNS_W = GNS_T / 64, GNS_MAXGS = 128;
+__device__ __forceinline__ void gns_block_sum2(float& a, float& b, float* red /* [2 * GNS_W] */) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = a, red[GNS_W + wave] = b;
+  __syncthreads();
+  float x = 0.f, y = 0.f;
+#pragma unroll
+  for (int w = 0; w < GNS_W; ++w) x += red[w], y += red[GNS_W + w];
+  a = x, b = y;
+}
+__device__ __forceinline__ void gns_slice_of_block(int B, int G, int& b, int& g) {  // XCD-aware: workgroup w runs on XCD w & 7
+  const int n = B * G, bid = blockIdx.x;
+  int sl = bid;
+  if ((n & 7) == 0) sl = (bid & 7) * (n >> 3) + (bid >> 3);
+  b = sl / G;
+  g = sl - b * G;
+}
+// Thread -> items: with dpp = gs / 2 dwords per pixel only the first T' = (1024 / dpp) * dpp threads work; thread t owns dword column j = t % dpp
+// (so its two channels -- gamma, beta -- are loop constants) of the pixels p0 + k * PS, p0 = t / dpp, PS = T' / dpp: consecutive threads read
+// consecutive dwords of a pixel's slice, then the next pixel's; the k-th access is a constant stride behind the (k-1)-th.  No per-item index
+// state survives between the passes (the first version, a flat item walk, kept 2 NV index registers alive and spilled kilobytes per lane).
+struct GnsMap {
+  int j, p0, ps;
+  bool active;
+  __device__ GnsMap(int dpp) {
+    const int per = GNS_T / dpp;  // pixels per sweep
+    ps = per;
+    p0 = threadIdx.x / dpp;
+    j = threadIdx.x - p0 * dpp;
+    active = p0 < per;
+  }
+};
+__host__ __device__ inline int gns_items_per_thread(int HW, int gs) {
+  const int per = GNS_T / (gs >> 1);
+  return (HW + per - 1) / per;
+}
+__device__ __forceinline__ float2 gns_unpack(uint32_t v) {
+  const f16x2 h = __builtin_bit_cast(f16x2, v);
+  return make_float2((float)h[0], (float)h[1]);
+}
+__device__ __forceinline__ uint32_t gns_pack(float a, float b) {
+  f16x2 h;
+  h[0] = (f16)a, h[1] = (f16)b;
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+template <int NV>
+__global__ __launch_bounds__(GNS_T) void gn_slice_fwd_kernel(const f16* __restrict__ X, int64_t ldx, f16* __restrict__ Y, int64_t ldy,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ stats, int B, int HW, int C, int G, float eps, int silu) {
+  __shared__ float red[2 * GNS_W];
+  int b, g;
+  gns_slice_of_block(B, G, b, g);
+  const int gs = C / G;
+  const GnsMap mp(gs >> 1);
+  const uint32_t* xb = reinterpret_cast<const uint32_t*>(X + (int64_t)b * HW * ldx + g * gs) + mp.j;
+  uint32_t* yb = reinterpret_cast<uint32_t*>(Y + (int64_t)b * HW * ldy + g * gs) + mp.j;
+  const uint32_t ldxw = (uint32_t)(ldx >> 1), ldyw = (uint32_t)(ldy >> 1);
+  uint32_t v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int p = mp.p0 + k * mp.ps;
+    v[k] = xb[(mp.active && p < HW) ? (uint32_t)p * ldxw : 0u];  // (clamped: no branch around the load; ignored below)
+  }
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (mp.active && mp.p0 + k * mp.ps < HW) {
+      const float2 f = gns_unpack(v[k]);
+      s += f.x + f.y;
+      q += f.x * f.x + f.y * f.y;
+    }
+  }
+  gns_block_sum2(s, q, red);
+  const float n = (float)gs * (float)HW;
+  const float mean = s / n;
+  const float rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+  if (threadIdx.x == 0) {
+    stats[((int64_t)b * G + g) * 2 + 0] = mean;
+    stats[((int64_t)b * G + g) * 2 + 1] = rstd;
+  }
+  if (!mp.active) return;
+  const int ch = g * gs + 2 * mp.j;
+  const float sc0 = rstd * gamma[ch], sc1 = rstd * gamma[ch + 1];
+  const float of0 = beta[ch] - mean * sc0, of1 = beta[ch + 1] - mean * sc1;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int p = mp.p0 + k * mp.ps;
+    if (p < HW) {
+      const float2 f = gns_unpack(v[k]);
+      float z0 = f.x * sc0 + of0, z1 = f.y * sc1 + of1;
+      if (silu) z0 = silu_f(z0), z1 = silu_f(z1);
+      yb[(uint32_t)p * ldyw] = gns_pack(z0, z1);
+    }
+  }
+}
+
+// KEEP = true would hold d = dy silu'(z) gamma in registers between the two passes; hipcc then spills kilobytes per lane (it hoists the second
+// pass's arithmetic above the block reduction), so the launches use KEEP = false: d is recomputed from the raw x / dy dwords, as the two-pass
+// kernels did
+template <int NV, bool KEEP>
+__global__ __launch_bounds__(GNS_T) void gn_slice_bwd_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ stats, const f16* __restrict__ add, int64_t ldadd,
+                                                               f16* __restrict__ dX, int64_t lddx, int B, int HW, int C, int G, int silu) {
+  __shared__ float red[2 * GNS_W];
+  int b, g;
+  gns_slice_of_block(B, G, b, g);
+  const int gs = C / G;
+  const GnsMap mp(gs >> 1);
+  const uint32_t* xb = reinterpret_cast<const uint32_t*>(X + (int64_t)b * HW * ldx + g * gs) + mp.j;
+  const uint32_t* dyb = reinterpret_cast<const uint32_t*>(dY + (int64_t)b * HW * lddy + g * gs) + mp.j;
+  const uint32_t* ab = add ? reinterpret_cast<const uint32_t*>(add + (int64_t)b * HW * ldadd + g * gs) + mp.j : nullptr;
+  uint32_t* dxb = reinterpret_cast<uint32_t*>(dX + (int64_t)b * HW * lddx + g * gs) + mp.j;
+  const uint32_t ldxw = (uint32_t)(ldx >> 1), lddyw = (uint32_t)(lddy >> 1), ldaw = (uint32_t)(ldadd >> 1), lddxw = (uint32_t)(lddx >> 1);
+  const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
+  uint32_t xv[NV], dv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int p = mp.p0 + k * mp.ps;
+    const bool ok = mp.active && p < HW;
+    xv[k] = xb[ok ? (uint32_t)p * ldxw : 0u];
+    dv[k] = dyb[ok ? (uint32_t)p * lddyw : 0u];
+  }
+  const int ch = g * gs + 2 * (mp.active ? mp.j : 0);
+  const float g0 = gamma[ch], g1 = gamma[ch + 1], b0 = beta[ch], b1 = beta[ch + 1];
+  float d0[KEEP ? NV : 1], d1[KEEP ? NV : 1];
+  float s1 = 0.f, s2 = 0.f;
+  auto grad_of = [&](int k, float& h0, float& h1, float& a0, float& a1) {
+    const float2 x = gns_unpack(xv[k]), dy = gns_unpack(dv[k]);
+    h0 = (x.x - mu) * rs, h1 = (x.y - mu) * rs;
+    a0 = dy.x, a1 = dy.y;
+    if (silu) a0 *= silu_grad_f(h0 * g0 + b0), a1 *= silu_grad_f(h1 * g1 + b1);
+    a0 *= g0, a1 *= g1;
+  };
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (KEEP) d0[k] = d1[k] = 0.f;
+    if (mp.active && mp.p0 + k * mp.ps < HW) {
+      float h0, h1, a0, a1;
+      grad_of(k, h0, h1, a0, a1);
+      if (KEEP) d0[k] = a0, d1[k] = a1;
+      s1 += a0 + a1;
+      s2 += a0 * h0 + a1 * h1;
+    }
+  }
+  gns_block_sum2(s1, s2, red);
+  if (!mp.active) return;
+  const float n = (float)gs * (float)HW;
+  const float m1 = s1 / n, m2 = s2 / n;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int p = mp.p0 + k * mp.ps;
+    if (p < HW) {
+      float h0, h1, a0, a1;
+      if (KEEP) {
+        const float2 x = gns_unpack(xv[k]);
+        h0 = (x.x - mu) * rs, h1 = (x.y - mu) * rs;
+        a0 = d0[k], a1 = d1[k];
+      } else {
+        grad_of(k, h0, h1, a0, a1);
+      }
+      float o0 = rs * (a0 - m1 - h0 * m2), o1 = rs * (a1 - m1 - h1 * m2);
+      if (ab) {
+        const float2 a = gns_unpack(ab[(uint32_t)p * ldaw]);
+        o0 += a.x, o1 += a.y;
+      }
+      dxb[(uint32_t)p * lddxw] = gns_pack(o0, o1);
+    }
+  }
+}
+// NV (dwords per thread) the slice kernels would need, 0 when they do not apply: even groups of <= 128 channels, strides even, enough slices
+// to occupy the chip, and the slice must fit the registers of 1024 threads (forward <= 44, backward <= 33 dwords per thread: x and dy live)
+int g_gn_fused = 3;  // tb_groupnorm_set_variant bits: 1 = one-pass 256-thread kernels for the small maps with 8-aligned groups, 2 = one-pass slice
+                     // kernels for the large maps (round 4); 0 = always the two-pass kernels
+inline int gn_slice_nv(int B, int HW, int C, int G, bool bwd) {
+  if (!(g_gn_fused & 2) || G <= 0 || C % G) return 0;
+  const int gs = C / G;
+  if ((gs & 1) || gs > GNS_MAXGS || (int64_t)B * G < 128) return 0;
+  // measured on one MI355X (scratch/gn_slice_time.py, B = 8; two-pass -> one-pass us): forward 4096x320 24.8 -> 20.9, 4096x640 34.7 -> 26.6,
+  // 1024x640 18.3 -> 10.1, 1024x1280 24.8 -> 15.7, 1024x1920 28.8 -> 21.0, 256x1920 15.4 -> 7.9; backward 4096x320 39.3 -> 35.3, 1024x640 25.1 -> 17.2,
+  // 1024x960 29.8 -> 23.7, 256x640 16.0 -> 8.3 -- but 44 dwords of x AND dy per thread (4096x640 backward) spill and ran 66 -> 101 us, and 64
+  // (4096x960 forward) 48 -> 60: those shapes keep the two-pass kernels
+  const int nv = gns_items_per_thread(HW, gs);
+  if (nv <= 11) return 11;
+  if (nv <= 22) return 22;
+  if (nv <= 33) return 33;
+  if (nv <= 44 && !bwd) return 44;
+  return 0;
+}
+
 inline bool gn_fused_ok(int B, int HW, int C, int G) {
   const int gs = C / G;
-  return g_gn_fused && gs % 8 == 0 && (int64_t)HW * (gs / 8) <= 256 * GNF_VPT && (int64_t)B * G >= 128;
+  return (g_gn_fused & 1) && gs % 8 == 0 && (int64_t)HW * (gs / 8) <= 256 * GNF_VPT && (int64_t)B * G >= 128;
 }
 
 // ------------------------------------------------------------------------------------------- LayerNorm
@@ -696,8 +1010,20 @@ extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
   if (gn_fused_ok(B, HW, C, G)) {
-    hipLaunchKernelGGL(gn_fused_fwd_kernel, dim3(G, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, HW, C, G, eps,
-                       silu);
+    hipLaunchKernelGGL(gn_fused_fwd_kernel<false>, dim3(G, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, HW, C, G,
+                       eps, silu, GnSplitK{});
+    TB_CHECK_LAUNCH();
+    return TB_OK;
+  }
+  if (const int nv = gn_slice_nv(B, HW, C, G, false)) {
+#define TB_GNS_FWD(NV_)                                                                                                                       \
+  hipLaunchKernelGGL(gn_slice_fwd_kernel<NV_>, dim3(B * G), dim3(GNS_T), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, B, HW, C, G, \
+                     eps, silu)
+    if (nv == 11) TB_GNS_FWD(11);
+    else if (nv == 22) TB_GNS_FWD(22);
+    else if (nv == 33) TB_GNS_FWD(33);
+    else TB_GNS_FWD(44);
+#undef TB_GNS_FWD
     TB_CHECK_LAUNCH();
     return TB_OK;
   }
@@ -720,8 +1046,19 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
   if (gn_fused_ok(B, HW, C, G)) {
-    hipLaunchKernelGGL(gn_fused_bwd_kernel, dim3(G, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
-                       (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, silu);
+    hipLaunchKernelGGL(gn_fused_bwd_kernel<false>, dim3(G, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
+                       (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, silu, GnSplitK{});
+    TB_CHECK_LAUNCH();
+    return TB_OK;
+  }
+  if (const int nv = gn_slice_nv(B, HW, C, G, true)) {
+#define TB_GNS_BWD(NV_)                                                                                                                        \
+  hipLaunchKernelGGL((gn_slice_bwd_kernel<NV_, false>), dim3(B * G), dim3(GNS_T), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,      \
+                     (const f16*)add, ldadd, (f16*)dx, lddx, B, HW, C, G, silu)
+    if (nv == 11) TB_GNS_BWD(11);
+    else if (nv == 22) TB_GNS_BWD(22);
+    else TB_GNS_BWD(33);
+#undef TB_GNS_BWD
     TB_CHECK_LAUNCH();
     return TB_OK;
   }
@@ -735,6 +1072,40 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
 #endif
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nch, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
                      fin, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, nch, silu);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_groupnorm_splitk_ok(int B, int HW, int C, int G) {
+  return (G > 0 && C % 8 == 0 && C % G == 0 && gn_fused_ok(B, HW, C, G)) ? 1 : 0;
+}
+
+extern "C" int tb_groupnorm_fwd_splitk(const float* part, int S, int64_t npad, const float* bias, const float* rowbias, int64_t ldrb,
+                                       const void* R, int64_t ldr, void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
+                                       const float* beta, float* stats, int B, int HW, int C, int G, float eps, int silu, tb_stream_t stream) {
+  (void)hipGetLastError();
+  if (!part || S < 1 || !x || !y || !gamma || !beta || !stats) return TB_EINVAL;
+  if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || ldy % 8 || B <= 0 || HW <= 0 || npad < C || npad % 8) return TB_EINVAL;
+  if (((uintptr_t)part) % 16 || (R && (ldr % 8 || ((uintptr_t)R) % 16)) || ((uintptr_t)x) % 16 || ((uintptr_t)y) % 16) return TB_EINVAL;
+  if (!gn_fused_ok(B, HW, C, G)) return TB_EINVAL;
+  GnSplitK sk{part, S, npad, (int64_t)B * HW * npad, bias, rowbias, ldrb, (const f16*)R, ldr};
+  hipLaunchKernelGGL(gn_fused_fwd_kernel<true>, dim3(G, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta,
+                     stats, HW, C, G, eps, silu, sk);
+  TB_CHECK_LAUNCH();
+  return TB_OK;
+}
+
+extern "C" int tb_groupnorm_bwd_splitk(const float* part, int S, int64_t npad, const void* x, int64_t ldx, const float* gamma,
+                                       const float* beta, const float* stats, const void* add, int64_t ldadd, void* dx, int64_t lddx, int B,
+                                       int HW, int C, int G, int silu, tb_stream_t stream) {
+  (void)hipGetLastError();
+  if (!part || S < 1 || !x || !gamma || !beta || !stats || !dx) return TB_EINVAL;
+  if (C % 8 || C > GN_MAXC || G <= 0 || G > 64 || C % G || ldx % 8 || lddx % 8 || (add && ldadd % 8) || npad < C || npad % 8) return TB_EINVAL;
+  if (((uintptr_t)part) % 16) return TB_EINVAL;
+  if (!gn_fused_ok(B, HW, C, G)) return TB_EINVAL;
+  GnSplitK sk{part, S, npad, (int64_t)B * HW * npad, nullptr, nullptr, 0, nullptr, 0};
+  hipLaunchKernelGGL(gn_fused_bwd_kernel<true>, dim3(G, B), dim3(256), 0, (hipStream_t)stream, (const f16*)nullptr, (int64_t)0, (const f16*)x,
+                     ldx, gamma, beta, stats, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, silu, sk);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }

@@ -2,6 +2,8 @@
 Tensors are PyTorch-ROCm tensors used for memory + streams only; all arithmetic happens in the HIP kernels."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -89,8 +91,20 @@ def gemm_ln_ok(M, N, K, dtype=torch.float16):
     return dtype == torch.float16 and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
 
 
+class SplitKPartials:
+    """fp32 k-slices left in the GEMM workspace by `gemm(..., defer=True)` (tb_gemm_desc.split_out) together with the epilogue operands the
+    consumer has to apply: handed to `groupnorm_fwd(..., partials=)` / `groupnorm_bwd(..., partials=)`.  Valid until the next gemm on the stream."""
+    __slots__ = ("ws", "S", "npad", "bias", "rowbias", "R", "out")
+
+    def __init__(self, ws, S, npad, bias, rowbias, R, out):
+        self.ws, self.S, self.npad, self.bias, self.rowbias, self.R, self.out = ws, S, npad, bias, rowbias, R, out
+
+
+DEFER_SPLITK = os.environ.get("TB_DEFER_SPLITK", "1") == "1"   # A/B switch: 0 = every split-K launch runs its reducer
+
+
 def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_per_group=0, R=None, act=L.ACT_NONE,
-         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None):
+         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None, defer=False):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
     conv = dict(B,Hin,Win,Cin,Hout,Wout,stride,sign,upsample,transposed) switches A to an NHWC 3x3 gather.
     ln_fwd = (gamma, beta, stats_out, y_out, eps): LayerNorm of the output row fused into the epilogue (only where `gemm_ln_ok`): `out` gets the
@@ -152,6 +166,11 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
     d.ws, d.ws_bytes = L.ptr(ws), ws.numel() * 4
     sync = _gemm_sync_counters(out.device)
     d.sync, d.sync_count = L.ptr(sync), sync.numel()
+    split = None
+    if defer and DEFER_SPLITK:   # a split-K launch leaves its slices in `ws` for the consumer (returns SplitKPartials instead of `out`)
+        import ctypes
+        split = ctypes.c_int32(1)
+        d.split_out = ctypes.pointer(split)
     # algorithmic bytes: every operand read once, the output written once (conv: the input image once, not once per tap)
     a_elems = M * conv["Cin"] if conv is not None else M * d.K
     # GEGLU writes [M, N/2] gated values plus the [M, N] pre-gate projections (C2); GEGLU_GRAD reads those and writes [M, 2N]
@@ -170,6 +189,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
                 r.name = f"conv_halo_kernel<{cfg[1]}>"
             else:
                 r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
+    if split is not None and split.value > 1:
+        return SplitKPartials(ws, split.value, (N + 7) // 8 * 8, bias, rowbias, R, out)
     return out
 
 
@@ -192,8 +213,24 @@ def groupnorm_ws(B, HW, C, G=32):
     return int(L.lib().tb_groupnorm_ws_floats(B, HW, C, G))
 
 
-def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, G=32, eps=1e-5, silu=False):
-    """x,y: [B*HW, C] fp16 (may be strided slices). stats [B,G,2] fp32 out."""
+def groupnorm_splitk_ok(B, HW, C, G=32, dtype=torch.float16):
+    """can GroupNorm over [B*HW, C] take its input straight from split-K partials (`groupnorm_fwd/bwd(..., partials=)`)?"""
+    return DEFER_SPLITK and dtype == torch.float16 and bool(L.lib().tb_groupnorm_splitk_ok(B, HW, C, G))
+
+
+def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, G=32, eps=1e-5, silu=False, partials=None):
+    """x,y: [B*HW, C] fp16 (may be strided slices). stats [B,G,2] fp32 out.
+    partials (SplitKPartials of the convolution that produces x): x is WRITTEN here -- reduction + conv epilogue + GroupNorm in one launch."""
+    if partials is not None:
+        pk = partials
+        assert pk.out.data_ptr() == x.data_ptr() and pk.npad >= C
+        with _rec("groupnorm_fwd(splitk)", 0.0, (4.0 * pk.S + 4.0) * B * HW * C):
+            L.check(L.lib().tb_groupnorm_fwd_splitk(L.ptr(pk.ws), pk.S, pk.npad, L.ptr(pk.bias), L.ptr(pk.rowbias),
+                                                    pk.rowbias.stride(0) if pk.rowbias is not None else 0, L.ptr(pk.R),
+                                                    pk.R.stride(0) if pk.R is not None else 0, L.ptr(x), x.stride(0), L.ptr(y), y.stride(0),
+                                                    L.ptr(gamma), L.ptr(beta), L.ptr(stats), B, HW, C, G, eps, int(silu), L.stream()),
+                    "tb_groupnorm_fwd_splitk")
+        return y
     if x.dtype == torch.float32:
         L.check(L.lib().tb_groupnorm_f32_fwd(L.ptr(x), x.stride(0), L.ptr(y), y.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats), B, HW, C, G,
                                              eps, int(silu), L.stream()), "tb_groupnorm_f32_fwd")
@@ -204,7 +241,15 @@ def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, G=32, eps=1e-5, silu=F
     return y
 
 
-def groupnorm_bwd(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G=32, silu=False, add=None):
+def groupnorm_bwd(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G=32, silu=False, add=None, partials=None):
+    if partials is not None:   # dy = the k-slices of the dgrad convolution (never materialised)
+        pk = partials
+        assert pk.bias is None and pk.rowbias is None and pk.R is None and pk.npad >= C
+        with _rec("groupnorm_bwd(splitk)", 0.0, (4.0 * pk.S + (6.0 if add is not None else 4.0)) * B * HW * C):
+            L.check(L.lib().tb_groupnorm_bwd_splitk(L.ptr(pk.ws), pk.S, pk.npad, L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
+                                                    L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), B, HW, C, G,
+                                                    int(silu), L.stream()), "tb_groupnorm_bwd_splitk")
+        return dx
     if x.dtype == torch.float32:
         L.check(L.lib().tb_groupnorm_f32_bwd(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(add),
                                              add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), B, HW, C, G, int(silu),

@@ -264,25 +264,38 @@ class HipUNet:
 
     # ------------------------------------------------------------------ primitive wrappers
     def _conv(self, x, name, out, B, Hin, Win, Hout, Wout, dgrad=False, stride=1, upsample=0, transposed=0, **epi):
+        """returns `out`, or (with defer=True, when the launch split K) the ops.SplitKPartials the following GroupNorm consumes"""
         w = self.P[name + (".wd" if dgrad else ".w")]
         cin = x.shape[1]
         geo = dict(B=B, Hin=Hin, Win=Win, Cin=cin, Hout=Hout, Wout=Wout, stride=stride, sign=-1 if (dgrad and not transposed) else 1,
                    upsample=upsample, transposed=transposed)
         return ops.gemm(x, w, out, conv=geo, **epi)
 
-    def _gn_fwd(self, x, name, y, stats, HW, silu, eps=None):
+    def _gn_fwd(self, x, name, y, stats, HW, silu, eps=None, partials=None):
         C = x.shape[1]
         ops.groupnorm_fwd(x, y, self.P[name + ".g"], self.P[name + ".b"], stats, self.gn_ws, self.B, HW, C, self.geo.norm_num_groups,
-                          self.geo.norm_eps if eps is None else eps, silu)
+                          self.geo.norm_eps if eps is None else eps, silu, partials=partials)
 
-    def _gn_bwd(self, dy, x, name, stats, dx, HW, silu, add=None):
+    def _gn_bwd(self, dy, x, name, stats, dx, HW, silu, add=None, partials=None):
         C = x.shape[1]
         ops.groupnorm_bwd(dy, x, self.P[name + ".g"], self.P[name + ".b"], stats, dx, self.gn_ws, self.B, HW, C,
-                          self.geo.norm_num_groups, silu, add)
+                          self.geo.norm_num_groups, silu, add, partials=partials)
+
+    def _gn_splitk(self, HW, C):
+        """may the producer of a GroupNorm input over [B*HW, C] leave its split-K slices to the GroupNorm launch (round 4: on the 16x16 / 8x8 maps
+        the reducer launch between a convolution and the GroupNorm behind it was ~9 us of a ~45 us pair)?"""
+        return ops.groupnorm_splitk_ok(self.B, HW, C, self.geo.norm_num_groups, self.dtype)
+
+    @staticmethod
+    def _pk(r):
+        return r if isinstance(r, ops.SplitKPartials) else None
 
     # ------------------------------------------------------------------ blocks
-    def _resnet(self, prefix, x, out, lvl_hw):
-        """x [M,Cin] view -> out [M,Cout] view; pushes its backward on the tape."""
+    def _resnet(self, prefix, x, out, lvl_hw, x_partials=None, defer_out=False):
+        """x [M,Cin] view -> out [M,Cout] view; returns its backward.
+        x_partials: x has not been written yet -- its producer left split-K slices for norm1 to add (and to write x).
+        defer_out: the caller guarantees that the NEXT launch on the stream is a GroupNorm over `out` alone; conv2 may then leave its
+        split-K slices to it.  Returns (bwd, partials-or-None)."""
         H, W = lvl_hw
         HW, M, B = H * W, x.shape[0], self.B
         cin, cout = x.shape[1], out.shape[1]
@@ -290,35 +303,40 @@ class HipUNet:
         st1 = self.buf(prefix + ".st1", B * self.geo.norm_num_groups, 2, torch.float32)
         st2 = self.buf(prefix + ".st2", B * self.geo.norm_num_groups, 2, torch.float32)
         a1 = self.scratch("a", M, cin)
-        self._gn_fwd(x, prefix + ".norm1", a1, st1, HW, True)
+        self._gn_fwd(x, prefix + ".norm1", a1, st1, HW, True, partials=x_partials)
         h1 = self.buf(prefix + ".h1", M, cout)
         rb = self.rowbias[:, self.temb_off[prefix]: self.temb_off[prefix] + cout]
-        self._conv(a1, prefix + ".conv1", h1, B, H, W, H, W, bias=P[prefix + ".conv1.b"], rowbias=rb, rows_per_group=HW)
+        sk_out = self._gn_splitk(HW, cout)
+        pk1 = self._pk(self._conv(a1, prefix + ".conv1", h1, B, H, W, H, W, bias=P[prefix + ".conv1.b"], rowbias=rb, rows_per_group=HW,
+                                  defer=sk_out))
         a2 = self.scratch("a", M, cout)
-        self._gn_fwd(h1, prefix + ".norm2", a2, st2, HW, True)
+        self._gn_fwd(h1, prefix + ".norm2", a2, st2, HW, True, partials=pk1)
         has_sc = cin != cout
+        defer_out = defer_out and sk_out
         if has_sc:
             ops.gemm(x, P[prefix + ".conv_shortcut.w"], out, bias=P[prefix + ".conv_shortcut.b"])
-            self._conv(a2, prefix + ".conv2", out, B, H, W, H, W, bias=P[prefix + ".conv2.b"], R=out)
+            pk_out = self._pk(self._conv(a2, prefix + ".conv2", out, B, H, W, H, W, bias=P[prefix + ".conv2.b"], R=out, defer=defer_out))
         else:
-            self._conv(a2, prefix + ".conv2", out, B, H, W, H, W, bias=P[prefix + ".conv2.b"], R=x)
+            pk_out = self._pk(self._conv(a2, prefix + ".conv2", out, B, H, W, H, W, bias=P[prefix + ".conv2.b"], R=x, defer=defer_out))
+        sk_in = self._gn_splitk(HW, cin)
 
         def bwd(dout, dx):
             da2 = self.scratch("g1", M, cout)
-            self._conv(dout, prefix + ".conv2", da2, B, H, W, H, W, dgrad=True)
+            pk = self._pk(self._conv(dout, prefix + ".conv2", da2, B, H, W, H, W, dgrad=True, defer=sk_out))
             dh1 = self.scratch("g2", M, cout)
-            self._gn_bwd(da2, h1, prefix + ".norm2", st2, dh1, HW, True)
+            self._gn_bwd(da2, h1, prefix + ".norm2", st2, dh1, HW, True, partials=pk)
             da1 = self.scratch("g1", M, cin)
-            self._conv(dh1, prefix + ".conv1", da1, B, H, W, H, W, dgrad=True)
-            if has_sc:
+            if has_sc:   # (the shortcut's dgrad first: the GroupNorm backward must directly follow the convolution whose slices it adds)
                 dsc = self.scratch("g3", M, cin)
                 ops.gemm(dout, P[prefix + ".conv_shortcut.wd"], dsc)
-                self._gn_bwd(da1, x, prefix + ".norm1", st1, dx, HW, True, add=dsc)
+                pk = self._pk(self._conv(dh1, prefix + ".conv1", da1, B, H, W, H, W, dgrad=True, defer=sk_in))
+                self._gn_bwd(da1, x, prefix + ".norm1", st1, dx, HW, True, add=dsc, partials=pk)
             else:
-                self._gn_bwd(da1, x, prefix + ".norm1", st1, dx, HW, True, add=dout)
-        return bwd
+                pk = self._pk(self._conv(dh1, prefix + ".conv1", da1, B, H, W, H, W, dgrad=True, defer=sk_in))
+                self._gn_bwd(da1, x, prefix + ".norm1", st1, dx, HW, True, add=dout, partials=pk)
+        return bwd, pk_out
 
-    def _transformer(self, prefix, x, out, lvl_hw, level):
+    def _transformer(self, prefix, x, out, lvl_hw, level, x_partials=None):
         H, W = lvl_hw
         HW, M, B, C = H * W, x.shape[0], self.B, x.shape[1]
         heads = self.geo.heads(level)
@@ -328,7 +346,7 @@ class HipUNet:
         G = self.geo.norm_num_groups
         st0 = self.buf(prefix + ".st0", B * G, 2, torch.float32)
         n0 = self.scratch("a", M, C)
-        self._gn_fwd(x, prefix + ".norm", n0, st0, HW, False, eps=1e-6)
+        self._gn_fwd(x, prefix + ".norm", n0, st0, HW, False, eps=1e-6, partials=x_partials)  # (x_partials: see _resnet)
         t0 = self.buf(prefix + ".t0", M, C)
         fuse_ln = FUSE_LN and ops.gemm_ln_ok(M, C, C, self.dtype)
         # --- self attention
@@ -503,37 +521,44 @@ class HipUNet:
         ops.conv4_to_nhwc(sample, P["conv_in.wp"], P["conv_in.b"], x, B, self.H, self.W, ch[0], sign=1)
         k = 1
         down_records = []   # (kind, bwd_fn / info, input_view, output_view, skip index of the output or None)
+        # xpk: split-K slices of the convolution that produces x, when x itself is still unwritten -- the GroupNorm that opens the next block adds
+        # them, applies the convolution's epilogue and writes x (`defer_out` / `x_partials`: only where that GroupNorm is the very next launch)
+        xpk = None
         for i, c in enumerate(ch):
             for j in range(L_):
                 has_attn = geo.cross_attn_levels[i]
                 dst = cat_views[k]
                 if has_attn:
                     mid = self.buf(f"down.{i}.{j}.res", Ms[i], c)
-                    rb = self._resnet(f"down_blocks.{i}.resnets.{j}", x, mid, hw[i])
-                    tbwd, stop = self._transformer(f"down_blocks.{i}.attentions.{j}", mid, dst, hw[i], i)
+                    rb, pk = self._resnet(f"down_blocks.{i}.resnets.{j}", x, mid, hw[i], x_partials=xpk, defer_out=True)
+                    tbwd, stop = self._transformer(f"down_blocks.{i}.attentions.{j}", mid, dst, hw[i], i, x_partials=pk)
+                    xpk = None
                     down_records.append(("res", rb, x, mid, None))
                     down_records.append(("attn", (tbwd, stop), mid, dst, k))
                 else:
-                    rb = self._resnet(f"down_blocks.{i}.resnets.{j}", x, dst, hw[i])
+                    # followed by the next resnet of the level, or (last level) by mid_block.resnets.0: both open with a GroupNorm over dst alone
+                    rb, xpk = self._resnet(f"down_blocks.{i}.resnets.{j}", x, dst, hw[i], x_partials=xpk,
+                                           defer_out=(j + 1 < L_ or i == nl - 1))
                     down_records.append(("res", rb, x, dst, k))
                 x = dst
                 k += 1
             if i < nl - 1:
                 dst = cat_views[k]
                 name = f"down_blocks.{i}.downsamplers.0.conv"
-                self._conv(x, name, dst, B, hw[i][0], hw[i][1], hw[i + 1][0], hw[i + 1][1], stride=2, bias=P[name + ".b"])
+                xpk = self._pk(self._conv(x, name, dst, B, hw[i][0], hw[i][1], hw[i + 1][0], hw[i + 1][1], stride=2, bias=P[name + ".b"],
+                                          defer=self._gn_splitk(hw[i + 1][0] * hw[i + 1][1], c)))
                 down_records.append(("down", (name, i), x, dst, k))
                 x = dst
                 k += 1
         # ---- mid
         lvl = nl - 1
         m1 = self.buf("mid.r0", Ms[lvl], ch[-1])
-        mb0 = self._resnet("mid_block.resnets.0", x, m1, hw[lvl])
+        mb0, pk = self._resnet("mid_block.resnets.0", x, m1, hw[lvl], x_partials=xpk, defer_out=True)
         m2 = self.buf("mid.a0", Ms[lvl], ch[-1])
-        mb1, _ = self._transformer("mid_block.attentions.0", m1, m2, hw[lvl], lvl)
+        mb1, _ = self._transformer("mid_block.attentions.0", m1, m2, hw[lvl], lvl, x_partials=pk)
         cb, hc = cats[(0, 0)]
         m3 = cb[:, :hc]
-        mb2 = self._resnet("mid_block.resnets.1", m2, m3, hw[lvl])
+        mb2, _ = self._resnet("mid_block.resnets.1", m2, m3, hw[lvl])
         mid_records = [(mb0, x, m1), (mb1, m1, m2), (mb2, m2, m3)]
         # ---- up path
         up_records = []
@@ -552,12 +577,12 @@ class HipUNet:
                     dst = self.buf("up.final", Ms[lvl], c)
                 if has_attn:
                     mid = self.buf(f"up.{i}.{j}.res", Ms[lvl], c)
-                    rb = self._resnet(f"up_blocks.{i}.resnets.{j}", cb, mid, hw[lvl])
-                    tbwd, _ = self._transformer(f"up_blocks.{i}.attentions.{j}", mid, dst, hw[lvl], lvl)
+                    rb, pk = self._resnet(f"up_blocks.{i}.resnets.{j}", cb, mid, hw[lvl], defer_out=True)
+                    tbwd, _ = self._transformer(f"up_blocks.{i}.attentions.{j}", mid, dst, hw[lvl], lvl, x_partials=pk)
                     up_records.append(("res", rb, cb, mid, (i, j)))
                     up_records.append(("attn", tbwd, mid, dst, None))
                 else:
-                    rb = self._resnet(f"up_blocks.{i}.resnets.{j}", cb, dst, hw[lvl])
+                    rb, _ = self._resnet(f"up_blocks.{i}.resnets.{j}", cb, dst, hw[lvl])
                     up_records.append(("res", rb, cb, dst, (i, j)))
                 x = dst
             if i < nl - 1:
