@@ -92,6 +92,15 @@ int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
 /* 1 when a fp16 Linear of this shape takes a tile that spans the whole output row, i.e. TB_ACT_LN_FWD / TB_ACT_LN_BWD are available for it
  * (N == 320, K % 64 == 0, M a multiple of the tile height with at least one chip round of tiles); tb_gemm returns -22 for them otherwise */
 int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K);
+/* 1 when the pair nearest-x2 upsampling + conv3x3 (diffusers Upsample2D, up_blocks.*.upsamplers.0; train_textboost.py:1063-1067 forward, :1108
+ * backward) over a coarse [B, Hc, Wc, Cin] map can run as four 2 x 2-tap SUB-PIXEL convolutions with pre-summed weights (2.25x fewer FLOP, the 4x
+ * map is never written): tb_gemm with a_mode = CONV3X3 and
+ *   upsample = 2 (forward): A = coarse [B, Hin, Win, Cin], C = fine fp16 [B, 2 Hin, 2 Win, N], K = 4 Cin, W = fp16 [4 classes][N][4 taps][Cin]
+ *                           (class 2 py + px = parity of the output pixel, tap 2 a + c = window row / column; ldw = 4 Cin), bias optional;
+ *   upsample = 3 (dgrad):   A = fine gradient [B, Hin, Win, Cin], C = coarse fp16 [B, Hin / 2, Win / 2, N], K = 16 Cin,
+ *                           W = fp16 [N][4 views][4 taps][Cin].
+ * The fp16 rounding of the summed filter rows is the one stated divergence from the 9-tap arithmetic (tests bound it). */
+int tb_gemm_subpixel_ok(int B, int Hc, int Wc, int Cin, int N);
 /* tuning knob for the k-tile / pipeline-depth variant of tb_gemm (returns the previous value); 0 is the default */
 int tb_gemm_set_variant(int v);
 /* {BM, BN, a_mode, k_tile*10 + stages, split_k} of the most recent tb_gemm launch (profiling aid) */

@@ -3,6 +3,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from parity import parity
+
 pytestmark = pytest.mark.gpu
 
 
@@ -507,3 +509,49 @@ def test_unet_with_and_without_deferred_split_k_reduction_is_bit_equal():
     nf, nb = sum(n == "groupnorm_fwd(splitk)" for n in outs[1][2]), sum(n == "groupnorm_bwd(splitk)" for n in outs[1][2])
     print(f"[deferred split-K] {nf} forward and {nb} backward GroupNorm launches add their producer's slices")
     assert nf >= 4 and nb >= 4
+
+
+@pytest.mark.parametrize("B,C,Hc", [(8, 640, 32), (8, 1280, 16), (2, 640, 32), (4, 320, 64), (8, 1280, 32)])
+def test_upsampler_convolution_as_sub_pixel_convolutions(B, C, Hc):
+    """round 4 (csrc/gemm8.hip SUB modes; diffusers Upsample2D = nearest x2 + conv3x3): the forward as four 2x2-tap convolutions on the coarse map
+    (tb_gemm_desc.upsample = 2) and its input gradient from the fine gradient's four strided views (upsample = 3), against torch on the upsampled
+    map and against the 9-tap kernels on the materialised 4x map.  Stated divergence: the pre-summed filter rows are rounded to fp16 once
+    (relative 2^-11 per weight) -- bounded here by the same 2e-3 / 4e-3 / 3e-3 triple as every other convolution."""
+    ops, L = _ops()
+    torch.manual_seed(31)
+    Hf = 2 * Hc
+    if not ops.subpixel_ok(B, Hc, Hc, C, C):
+        pytest.skip("shape not covered by the sub-pixel tiles")
+    x = torch.randn(B, C, Hc, Hc, device="cuda").half()
+    w = (torch.randn(C, C, 3, 3, device="cuda") / (3 * C ** 0.5)).half()
+    bias = torch.randn(C, device="cuda")
+    wf, wd = ops.pack_subpixel_weights(w)
+    xn = nhwc(x).reshape(B * Hc * Hc, C)
+    out = torch.empty(B * Hf * Hf, C, device="cuda", dtype=torch.float16)
+    ops.gemm(xn, wf, out, bias=bias, conv=dict(B=B, Hin=Hc, Win=Hc, Cin=C, Hout=Hf, Wout=Hf, stride=1, sign=1, upsample=2, transposed=0))
+    xr = x.float().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), w.float(), bias, padding=1)
+    parity(f"sub-pixel upsampler forward {B}x{C}x{Hc}", out.view(B, Hf, Hf, C), nhwc(ref), rel=2e-3, maxabs=4e-3, ch_dim=3, ch_rel=3e-3)
+    # the 9-tap path on the materialised map
+    xu = torch.empty(B * Hf * Hf, C, device="cuda", dtype=torch.float16)
+    ops.upsample2x(xn, xu, B, Hc, Hc, C)
+    out9 = torch.empty_like(out)
+    ops.gemm(xu, pack_conv_w(w), out9, bias=bias, conv=dict(B=B, Hin=Hf, Win=Hf, Cin=C, Hout=Hf, Wout=Hf, stride=1, sign=1, upsample=0, transposed=0))
+    assert rel_err(out, out9) < 1.5e-3
+    # input gradient
+    dy = torch.randn(B, C, Hf, Hf, device="cuda").half()
+    dyn = nhwc(dy).reshape(B * Hf * Hf, C)
+    dx = torch.empty(B * Hc * Hc, C, device="cuda", dtype=torch.float16)
+    ops.gemm(dyn, wd, dx, conv=dict(B=B, Hin=Hf, Win=Hf, Cin=C, Hout=Hc, Wout=Hc, stride=1, sign=1, upsample=3, transposed=0))
+    ref.backward(dy.float())
+    parity(f"sub-pixel upsampler dgrad {B}x{C}x{Hc}", dx.view(B, Hc, Hc, C), nhwc(xr.grad), rel=2e-3, maxabs=4e-3, ch_dim=3, ch_rel=3e-3)
+    du = torch.empty(B * Hf * Hf, C, device="cuda", dtype=torch.float16)
+    ops.gemm(dyn, pack_conv_w_dgrad(w), du, conv=dict(B=B, Hin=Hf, Win=Hf, Cin=C, Hout=Hf, Wout=Hf, stride=1, sign=-1, upsample=0, transposed=0))
+    dx9 = torch.empty_like(dx)
+    ops.pool2x2_sum(du, dx9, B, Hc, Hc, C)
+    assert rel_err(dx, dx9) < 2e-3   # (the 9-tap path rounds the fine-map gradient to fp16 before pooling)
+    # shapes the tiles do not cover are refused, not silently mis-computed
+    bad = torch.empty(2 * 16 * 16, 64, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(2 * 8 * 8, 64, device="cuda", dtype=torch.float16), torch.zeros(256, 256, device="cuda", dtype=torch.float16), bad,
+                 conv=dict(B=2, Hin=8, Win=8, Cin=64, Hout=16, Wout=16, stride=1, sign=1, upsample=2, transposed=0))

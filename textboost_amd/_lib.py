@@ -69,6 +69,7 @@ _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
     "tb_gemm_ln_epilogue_ok": ([C.c_int64, C.c_int64, C.c_int64], C.c_int),
+    "tb_gemm_subpixel_ok": ([_I, _I, _I, _I, _I], C.c_int),
     "tb_last_hip_error": ([], C.c_char_p),
     "tb_mfma_peak_probe": ([_VP, _I, _I, _VP], C.c_int),
     "tb_gemm_set_variant": ([_I], C.c_int),

@@ -1100,7 +1100,15 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if ((d.act == TB_ACT_QUICK_GELU_GRAD || d.act == TB_ACT_GELU_GRAD || d.act == TB_ACT_GEGLU_GRAD) && !d.C2) return TB_EINVAL;
   if (d.act == TB_ACT_GEGLU_GRAD && (d.N % 32 || d.c_dtype != TB_F16)) return TB_EINVAL;
   if (d.act < 0 || d.act > TB_ACT_LN_BWD) return TB_EINVAL;
-  if (d.a_mode == TB_A_CONV3X3) {
+  if (d.a_mode == TB_A_CONV3X3 && (d.upsample == 2 || d.upsample == 3)) {
+    // sub-pixel form of nearest-x2 + conv3x3 (gemm8.hip): upsample == 2 forward (A coarse [B, Hin, Win, Cin], C fine [B, 2 Hin, 2 Win, N],
+    // W [4 classes][N][4 taps][Cin], K = 4 Cin), upsample == 3 dgrad (A fine [B, Hin, Win, Cin], C coarse [B, Hin / 2, Win / 2, N], W [N][16 Cin])
+    if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != (d.upsample == 2 ? 4 : 16) * (int64_t)d.Cin) return TB_EINVAL;
+    if (d.M != (int64_t)d.B * d.Hout * d.Wout || d.stride != 1 || d.transposed || d.shift || d.R || d.rowbias || d.C2 || d.act != TB_ACT_NONE ||
+        d.c_dtype != TB_F16)
+      return TB_EINVAL;
+    if (d.upsample == 2 ? (d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) : (d.Hin != 2 * d.Hout || d.Win != 2 * d.Wout)) return TB_EINVAL;
+  } else if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;
     if (d.M != (int64_t)d.B * d.Hout * d.Wout) return TB_EINVAL;
     if (d.sign != 1 && d.sign != -1) return TB_EINVAL;

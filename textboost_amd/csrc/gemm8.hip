@@ -98,7 +98,18 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 }
 
 // WM x WN waves (WM * WN == 8), each wave (16 MT) x (16 NT) outputs; CONV: 3x3 stride-1 halo convolution, else A rows linear
-template <int WM, int WN, int MT, int NT, bool CONV, int NS>
+//
+// SUB (round 4): the nearest-x2 upsampler convolutions (diffusers Upsample2D = F.interpolate(x, 2, "nearest") + conv3x3: up_blocks.*.upsamplers.0) as
+// SUB-PIXEL convolutions.  An output pixel (2Y + py, 2X + px) of the fine map only ever sees a 2 x 2 window of the COARSE map -- rows Y - 1 + py,
+// Y + py, with the 3 x 3 filter's rows summed pairwise ({0}, {1, 2} for py = 0; {0, 1}, {2} for py = 1), the same in x -- so the convolution is four
+// 2 x 2-tap convolutions with pre-summed (frozen) weights: 16 instead of 36 tap products per coarse pixel, 2.25x fewer FLOP, and the 4x map is
+// never written.  The kernel stays the halo kernel: tiles of 256 COARSE pixels, the usual (R + 2) x (TW + 2) halo, four taps whose halo shifts
+// depend on the class.
+//   SUB = 1 (forward, tb_gemm_desc.upsample == 2): A = the coarse map; the output class (py, px) is the `slice` of the workgroup (S = 4); row r of
+//           the tile is stored to the fine pixel (2 y + py, 2 x + px);  W = [4 classes][N][4 taps][Cin].
+//   SUB = 2 (dgrad, upsample == 3): A = the fine gradient read as four strided VIEWS (py, px), the k-loop walks (view, channel chunk) pairs with
+//           four taps each, the output is the coarse map; W = [N][4 views][4 taps][Cin]; split-K over the (view, chunk) list as usual.
+template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int a_rows8,
                                                           unsigned long long* dbg, int S, float* __restrict__ ws, int64_t npad, int xn) {
   static_assert(WM * WN == 8, "8 waves");
@@ -108,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   G8_STAMP(0)
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BK = 64;
-  constexpr int TAPS = CONV ? 9 : 1;
+  static_assert(!SUB || CONV, "SUB is a convolution mode");
+  constexpr int TAPS = CONV ? (SUB ? 4 : 9) : 1;
   constexpr int NI_W = BN / 8;               // weight-tile load instructions (8 rows x 128 B each) per step
   constexpr int WI = (NI_W + 7) / 8;         // ... per wave
   constexpr int MAXHI = CONV ? 7 : (BM / 64 > 0 ? BM / 64 : 1);  // A-panel load instructions per wave per chunk
@@ -149,6 +161,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
     tm = tile / tiles_n, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
   }
+  const int cls = SUB == 1 ? slice : 0;   // SUB == 1: the `slice` index is the output class 2 py + px, not a k-range
+  if constexpr (SUB == 1) slice = 0;
+  const int Ssplit = SUB == 1 ? 1 : S;
   const int64_t n0 = (int64_t)tn * BN;
   // Linear tiles: the BN bias values go through a small LDS array filled under the prologue loads.  Loaded at the point of use (after the main
   // loop) they queued behind the CU's in-flight stores and operand loads: 8300 cycles of a 35000-cycle 128x128x320 GEGLU tile were this wait.
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   const int64_t n = n0 + cg * 8;
 
   // ---- tile geometry
-  const int TW = 1 << wshift, W = p.Wout, H = p.Hout;
+  const int TW = 1 << wshift, W = SUB == 1 ? p.Win : p.Wout, H = SUB == 1 ? p.Hin : p.Hout;  // the map the tile grid walks (SUB: the coarse one)
   const int R = BM >> wshift, HC = TW + 2, NH = CONV ? (R + 2) * HC : BM;
   const int NI_H = a_rows8 >> 3;
   int64_t m0;
@@ -191,6 +206,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   } else {
     m0 = (int64_t)tm * BM;
   }
+  // output row of tile row r: the tile's pixels in map order; SUB == 1: the class's pixels (2 y + py, 2 x + px) of the fine (2H x 2W) map
+  const int64_t mo0 = SUB == 1 ? ((int64_t)bimg * 2 * H + 2 * y0 + (cls >> 1)) * (2 * W) + 2 * x0 + (cls & 1) : m0;
+  const int oys = SUB == 1 ? 4 * W : W, oxs = SUB == 1 ? 2 : 1;
+  auto out_row = [&](int r) -> int64_t {
+    if constexpr (SUB == 1) return mo0 + (int64_t)(r >> wshift) * oys + (int64_t)(r & (TW - 1)) * oxs;
+    else return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r;
+  };
   // Early epilogue operands (a global load issued after the main loop queues behind the CU's own stores and operand traffic for microseconds).
   // conv: bias, plus the time-embedding row bias when it is constant over the tile, stay in 8 registers across the main loop;
   // Linear: bias goes through bias_s (above) and the residual rows of the first staging pass are fetched now into NU x 4 registers.
@@ -235,7 +257,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       const int hy = hr / HC, hx = hr - hy * HC;
       const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
       ok = j < NI_H && hr < NH && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      grow = (int64_t)bimg * hw + (int64_t)yy * W + xx;
+      grow = SUB == 2 ? ((int64_t)bimg * 2 * H + 2 * yy) * (2 * W) + 2 * xx   // view (0, 0) of the fine gradient; other views: + a uniform offset
+                      : (int64_t)bimg * hw + (int64_t)yy * W + xx;
     } else {
       ok = j < NI_H && m0 + hr < p.M;
       grow = m0 + hr;
@@ -251,13 +274,31 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     w_off[i] = (uint32_t)((n * p.ldw + ((cp ^ (row & 7)) << 3)) * 2);
   }
   const int kpt = CONV ? p.Cin / BK : 1;                 // k-tiles per tap
-  const int nchunk_all = CONV ? kpt : (int)(p.K / BK);
-  const int c_begin = S > 1 ? nchunk_all * slice / S : 0;
-  const int nchunk = S > 1 ? nchunk_all * (slice + 1) / S : nchunk_all;  // end of this workgroup's chunk range [c_begin, nchunk)
+  const int nchunk_all = CONV ? (SUB == 2 ? 4 * kpt : kpt) : (int)(p.K / BK);   // SUB == 2: (view, channel chunk) pairs, view-major
+  const int c_begin = Ssplit > 1 ? nchunk_all * slice / Ssplit : 0;
+  const int nchunk = Ssplit > 1 ? nchunk_all * (slice + 1) / Ssplit : nchunk_all;  // end of this workgroup's chunk range [c_begin, nchunk)
+  // SUB == 2: chunk index -> (view, channel chunk), kept incrementally for the current chunk (_c) and the next one (_n): the halo source of a
+  // view is view (0, 0)'s plus (py * Wsrc + px) pixels, its weights sit 4 * kpt k-tiles behind the previous view's
+  int sv_view_c = 0, sv_lc_c = 0, sv_view_n = 0, sv_lc_n = 0;
+  if (SUB == 2) {
+    sv_view_c = c_begin / kpt, sv_lc_c = c_begin - sv_view_c * kpt;
+    sv_view_n = sv_view_c, sv_lc_n = sv_lc_c + 1;
+    if (sv_lc_n == kpt) sv_lc_n = 0, ++sv_view_n;
+  }
+  auto sub_a_off = [&](int view, int lcv) -> int64_t {  // element offset of (view, channel chunk) from view (0, 0), chunk 0 (in-map lanes only)
+    return (int64_t)lcv * BK + ((int64_t)(view >> 1) * (2 * W) + (view & 1)) * p.lda;
+  };
 
-  auto stage_a_piece = [&](int c, int i) {  // one load instruction of chunk c's panel
+  auto stage_a_piece = [&](int c, int i, bool next) {  // one load instruction of chunk c's panel (SUB == 2: c is the current or the NEXT chunk)
     const int j = wave + 8 * i;
-    if (j < NI_H) glds16(h_ptr[i] + (int64_t)c * h_step[i], As + (c & 1) * a_elems + j * 8 * BK);
+    if constexpr (SUB == 2) {
+      if (j < NI_H) {
+        const int64_t off = next ? sub_a_off(sv_view_n, sv_lc_n) : sub_a_off(sv_view_c, sv_lc_c);
+        glds16(h_ptr[i] + (h_step[i] ? off : 0), As + (c & 1) * a_elems + j * 8 * BK);
+      }
+    } else {
+      if (j < NI_H) glds16(h_ptr[i] + (int64_t)c * h_step[i], As + (c & 1) * a_elems + j * 8 * BK);
+    }
   };
 
   f32x4_t acc[MT][NT];
@@ -291,24 +332,36 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // ---- software pipeline: NS weight stages (and, for Linear, NS activation stages); the loads of step s + NS - 1 are issued in step s,
   // so NS - 2 steps of loads stay in flight across each barrier (counted vmcnt, raw s_barrier: cdna guide T3/T4).  An L2 round trip under
   // load is ~1 us, as long as one step of MFMAs: with NS = 2 every step waited for it.
-  static_assert(!CONV || TAPS % NS == 0, "the weight ring slot of a conv step is tap % NS");
+  static_assert(!CONV || SUB || TAPS % NS == 0, "the weight ring slot of a conv step is tap % NS (SUB: run-time ring counters, like the Linear path)");
   // The stage loaded during step (c, tap) is the one NS - 1 steps ahead: (lc, ltap).  The tap loop is fully unrolled, so tap, ltap, the
   // ring slots and the tap's halo offset are compile-time; only the chunk index is a loop variable.  (With a rolled tap loop the LOAD
   // phase was ~100 instructions, half of them scalar index arithmetic, and took 420 cycles against 340 for the 20 MFMAs of the partner.)
-  constexpr int NSLOT = CONV ? WI + 1 : WI + MAXHI;  // load slots per step: WI weight pieces, then the halo piece (conv) / MAXHI A pieces
+  constexpr int NSLOT = CONV ? WI + (SUB ? 3 : 1) : WI + MAXHI;  // load slots per step: WI weight pieces, then the halo piece(s) (conv: one of the
+                                                                 // next chunk's <= 7 per tap; SUB: up to three, see issue_slot) / MAXHI A pieces
   // dgrad (sign < 0) gathers with flipped offsets: walk the taps in reverse weight order instead, so that the gather offset of unrolled
   // step t is always (t / 3, t % 3)
   const int wtap0 = p.sign > 0 ? 0 : TAPS - 1, wtapd = p.sign > 0 ? 1 : -1;
-  auto issue_slot = [&](int k, int lc, int ltap, int lslot, int c, int tap) {
+  auto issue_slot = [&](int k, int lc, int ltap, int lslot, int c, int tap, int lnext) {  // lnext: the loaded stage belongs to chunk c + 1
     if (G8_ABL & 2) return;
     if (k < WI) {
       const int j = wave + 8 * k;
       if (lc < nchunk && j < NI_W) {
-        const char* base = (const char*)p.W + (int64_t)((wtap0 + wtapd * ltap) * kpt + lc) * BK * 2;
-        glds16((const f16*)(base + w_off[k]), Ws + lslot * (BN * BK) + j * 8 * BK);
+        if constexpr (SUB == 0) {
+          const char* base = (const char*)p.W + (int64_t)((wtap0 + wtapd * ltap) * kpt + lc) * BK * 2;
+          glds16((const f16*)(base + w_off[k]), Ws + lslot * (BN * BK) + j * 8 * BK);
+        } else {
+          int64_t kt;   // k-tile of the stage inside a weight row
+          if (SUB == 2) kt = (int64_t)((lnext ? sv_view_n : sv_view_c) * 4 + ltap) * kpt + (lnext ? sv_lc_n : sv_lc_c);
+          else kt = (int64_t)ltap * kpt + lc;
+          const char* base = (const char*)p.W + (SUB == 1 ? (int64_t)cls * p.N * p.ldw * 2 : 0) + kt * BK * 2;
+          glds16((const f16*)(base + w_off[k]), Ws + lslot * (BN * BK) + j * 8 * BK);
+        }
       }
     } else if (CONV) {
-      if (tap >= 0 && tap < MAXHI && c + 1 < nchunk) stage_a_piece(c + 1, tap);
+      // SUB: the next chunk's halo pieces go out in taps 0 .. 2 only (pieces tap, tap + 3, tap + 6): the counted wait at the end of a step covers
+      // everything EXCEPT that step's own loads, so a piece issued in the last tap (3) would not have landed when the next chunk's first tap reads it
+      const int piece = SUB ? tap + 3 * (k - WI) : tap;
+      if (tap >= 0 && (!SUB || tap < 3) && piece < MAXHI && c + 1 < nchunk) stage_a_piece(c + 1, piece, true);
     } else if (lc < nchunk) {
       const int i = k - WI, j = wave + 8 * i;
       if (j < NI_H) glds16(h_ptr[i] + (int64_t)lc * h_step[i], As + lslot * a_elems + j * 8 * BK);
@@ -316,13 +369,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   };
   auto stage_count = [&](int lc, int c, int tap) -> int {  // loads this wave issues in step (c, tap): for the counted wait of the NEXT step
     int n = lc < nchunk ? n_w + (CONV ? 0 : n_a) : 0;
-    if (CONV && c + 1 < nchunk && tap < MAXHI && wave + 8 * tap < NI_H) ++n;
+    if (!SUB && CONV && c + 1 < nchunk && tap < MAXHI && wave + 8 * tap < NI_H) ++n;
+    if (SUB && c + 1 < nchunk && tap < 3) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (tap + 3 * q < MAXHI && wave + 8 * (tap + 3 * q) < NI_H) ++n;
+    }
     return n;
   };
   int cnt_prev = 0;
   if (CONV) {
 #pragma unroll
-    for (int i = 0; i < MAXHI; ++i) stage_a_piece(c_begin, i);
+    for (int i = 0; i < MAXHI; ++i) stage_a_piece(c_begin, i, false);
   }
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st) {  // stages 0 .. NS-2; the youngest one's loads may stay in flight at step 0 (NS = 3)
@@ -330,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     cnt_prev = lc < nchunk ? n_w + (CONV ? 0 : n_a) : 0;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k)
-      if (!CONV || k < WI) issue_slot(k, lc, ltap, st % NS, -2, -1);
+      if (!CONV || k < WI) issue_slot(k, lc, ltap, st % NS, -2, -1, 0);
   }
   if (NS == 2) cnt_prev = 0;
   wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
@@ -366,14 +424,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   const uint32_t as_addr = lds_addr(As), ws_addr = lds_addr(Ws);
   int lin_slot = 0, lin_lslot = (NS - 1) % NS;  // Linear: ring slots of the current / the loaded stage (conv: tap % NS, compile-time)
   for (int c = c_begin; c < nchunk; ++c) {
+    // SUB: halo position of the 2 x 2 window's first tap -- forward: (py, px) of the output class; dgrad: (1 - py, 1 - px) of the chunk's view
+    int sub_shift0 = 0;
+    if constexpr (SUB != 0) {
+      const int sub_oy = SUB == 1 ? (cls >> 1) : 1 - (sv_view_c >> 1), sub_ox = SUB == 1 ? (cls & 1) : 1 - (sv_view_c & 1);
+      sub_shift0 = sub_oy * HC + sub_ox;
+    }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       constexpr int dummy_ = 0;
       (void)dummy_;
       const int ltap = (tap + NS - 1) % TAPS, lc = c + (tap + NS - 1) / TAPS;
-      const int wslot = CONV ? tap % NS : lin_slot, lslot = CONV ? (tap + NS - 1) % NS : lin_lslot;
+      constexpr bool RT_RING = !CONV || SUB != 0;   // run-time ring counters
+      const int wslot = RT_RING ? lin_slot : tap % NS, lslot = RT_RING ? lin_lslot : (tap + NS - 1) % NS;
       const int cnt_step = NS == 2 ? 0 : stage_count(lc, c, tap);
-      const int shift = CONV ? (tap / 3) * HC + (tap % 3) : 0;
+      int shift = CONV ? (tap / 3) * HC + (tap % 3) : 0;
+      if constexpr (SUB != 0) shift = sub_shift0 + (tap >> 1) * HC + (tap & 1);
       const uint32_t ab_addr = as_addr + (CONV ? (c & 1) : wslot) * (a_elems * 2) + shift * 128;
       const uint32_t wb_addr = ws_addr + wslot * (BN * BK * 2);
       f16x8 af[2][MT], bf[2][NT];
@@ -410,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k)
-          if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap);
+          if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
         __builtin_amdgcn_sched_barrier(0);
         // after the step's last issue: everything except THIS step's loads has landed (this wave's part), i.e. the next step's stage
         if (h == HALVES - 1) wait_vmcnt(cnt_step);
@@ -440,10 +506,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         G8_PF(3)
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!CONV) {
+      if (!CONV || SUB) {
         lin_slot = lin_slot + 1 == NS ? 0 : lin_slot + 1;
         lin_lslot = lin_lslot + 1 == NS ? 0 : lin_lslot + 1;
       }
+    }
+    if (SUB == 2) {  // (view, channel chunk) of the next iteration and of the one after it
+      sv_view_c = sv_view_n, sv_lc_c = sv_lc_n;
+      if (++sv_lc_n == kpt) sv_lc_n = 0, ++sv_view_n;
     }
   }
   if (group == 0) asm volatile("s_barrier" ::: "memory");  // pairs with the second group's last barrier
@@ -458,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // ---- epilogue: accumulators -> padded fp32 tile in LDS -> (row, 8 columns) units with 16-byte global accesses.  A thread keeps ONE
   // column group (bias loaded once) and walks rows; all residual / auxiliary loads of its units are issued before the arithmetic.
   float* Cs = reinterpret_cast<float*>(smem_raw);
-  if (CONV && S > 1) {  // raw fp32 partial of this k-slice
+  if (CONV && Ssplit > 1) {  // raw fp32 partial of this k-slice
     float* const dst0 = ws + (int64_t)slice * p.M * npad + n;
     const int64_t Mtot = p.M;
 #pragma unroll 1
@@ -824,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
     }
-    auto m_row = [&](int r) -> int64_t { return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r; };
+    auto m_row = [&](int r) -> int64_t { return out_row(r); };
     f16x8 rv1[NU];  // second pass: its residual rows are requested before the first pass is staged
     if (PASSES == 2 && Rg && rslot < TPR) {
 #pragma unroll
@@ -846,10 +916,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
             *(f32x4_t*)(Cs + row * LDC + col) = acc[i][j];
           }
       }
-      auto m_of = [&](int row) -> int64_t {
-        const int r = rp + row;
-        return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r;
-      };
+      auto m_of = [&](int row) -> int64_t { return out_row(rp + row); };
       f16x8 rv[NU];
       if (pass == 1 || pre_r) {
 #pragma unroll
@@ -903,10 +970,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           *(f32x4_t*)(Cs + row * LDC + col) = acc[i][j];
         }
     }
-    auto m_of = [&](int row) -> int64_t {
-      const int r = rp + row;
-      return CONV ? m0 + (int64_t)(r >> wshift) * W + (r & (TW - 1)) : m0 + r;
-    };
+    auto m_of = [&](int row) -> int64_t { return out_row(rp + row); };
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (rslot < TPR) {
 #pragma unroll 1
@@ -937,12 +1001,14 @@ int g8_enable = 39;  // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers,
 thread_local int g8_split = 1;  // k-slices of the launch tb_gemm8_try is making on this thread (returned through its out-parameter)
 int g8_last[7] = {0, 0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
-template <int WM, int WN, int MT, int NT, bool CONV, int NS>
+template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0>
 int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-  const int tiles_m = (int)(d.M / BM), tiles_n = (int)(d.N / BN);
+  // SUB == 1: the tile grid walks the COARSE map (a quarter of the output rows) once per output class: S = 4 is the class count, not a k-split
+  const int tiles_m = (int)((SUB == 1 ? d.M / 4 : d.M) / BM), tiles_n = (int)(d.N / BN);
   const int64_t npad = (d.N + 7) & ~(int64_t)7;
-  if (S > 1 && (!CONV || !d.ws || (size_t)S * (size_t)d.M * (size_t)npad * 4 > d.ws_bytes)) return 1;
+  if (SUB == 1 && S != 4) return TB_EINVAL;
+  if (SUB != 1 && S > 1 && (!CONV || !d.ws || (size_t)S * (size_t)d.M * (size_t)npad * 4 > d.ws_bytes)) return 1;
   int a_rows;
   if (CONV) {
     const int TW = 1 << wshift, R = BM >> wshift;
@@ -958,7 +1024,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   if (lds > 160 * 1024) return 1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return TB_ELAUNCH;
     attr_done = true;
@@ -974,10 +1040,10 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
       if (cost < best) xn = c, best = cost;
     }
   }
-  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
+  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
                      wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn);
   TB_CHECK_LAUNCH();
-  g8_split = S;
+  g8_split = SUB == 1 ? 1 : S;
   g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
   return TB_OK;
 }
@@ -1003,6 +1069,20 @@ extern "C" int tb_gemm8_last(int* out5 /* 6 ints */) {
   if (out5)
     for (int i = 0; i < 6; ++i) out5[i] = g8_last[1 + i];
   return g8_last[0];
+}
+
+// can the nearest-x2 + conv3x3 pair over a coarse [B, Hc, Wc, Cin] map run as sub-pixel convolutions (tb_gemm_desc.upsample == 2 / 3)?
+extern "C" int tb_gemm_subpixel_ok(int B, int Hc, int Wc, int Cin, int N) {
+  if (B <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cin % 64 || N <= 0 || N % 80) return 0;
+  int sh = 0;
+  while (sh < 6 && !(Wc & (1 << sh))) ++sh;
+  if (sh < 4) return 0;                              // tile width: the largest power of two (16 .. 64) dividing Wc
+  const int TW = 1 << sh;
+  if (Wc % TW || 256 % TW || Hc % (256 / TW)) return 0;
+  const int64_t Mc = (int64_t)B * Hc * Wc;
+  if (Mc % 256) return 0;
+  if ((Mc / 256) * (N / 80) * 4 < 128) return 0;     // not enough tiles to be worth it
+  return 1;
 }
 
 extern "C" int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K) {
@@ -1042,7 +1122,23 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   }
   if (d.K % 64 || d.N % 8) return 1;
   const int64_t lim = (int64_t)1 << 32;
-  if (((d.N - 1) * d.ldw + d.K) * 2 >= lim) return 1;
+  if (((d.N * (d.upsample == 2 ? 4 : 1) - 1) * d.ldw + d.K) * 2 >= lim) return 1;
+  if (d.a_mode == TB_A_CONV3X3 && (d.upsample == 2 || d.upsample == 3)) {  // sub-pixel upsampler convolution (forward / dgrad), see the kernel
+    if (!tb_gemm_subpixel_ok(d.B, d.upsample == 2 ? d.Hin : d.Hout, d.upsample == 2 ? d.Win : d.Wout, d.Cin, (int)d.N)) return TB_EINVAL;
+    const int Wc = d.upsample == 2 ? d.Win : d.Wout;
+    const int wshift = halo_wshift8(Wc);
+    const int64_t Mc = d.upsample == 2 ? d.M / 4 : d.M;
+    const int64_t t160 = (Mc / 256) * (d.N / 160), t80 = (Mc / 256) * (d.N / 80);
+    if (d.upsample == 2) {
+      if (d.N % 160 == 0 && t160 * 4 >= 200) return launch8<4, 2, 4, 5, true, 3, 1>(d, s, wshift, 4);
+      return launch8<8, 1, 2, 5, true, 3, 1>(d, s, wshift, 4);
+    }
+    if (d.N % 160 == 0 && t160 >= 200) return launch8<4, 2, 4, 5, true, 3, 2>(d, s, wshift);
+    if (t80 >= 200) return launch8<8, 1, 2, 5, true, 3, 2>(d, s, wshift);
+    // too few tiles: one VIEW of the fine gradient per k-slice (fp32 partials + the caller's reducer)
+    if (d.N % 160 == 0 && t160 * 4 >= 128) return launch8<4, 2, 4, 5, true, 3, 2>(d, s, wshift, 4);
+    return launch8<8, 1, 2, 5, true, 3, 2>(d, s, wshift, 4);
+  }
   if (d.a_mode == TB_A_CONV3X3) {
     if (!(g8_enable & 1)) return 1;
     if (d.stride != 1 || d.upsample || d.transposed || d.shift || d.Hin != d.Hout || d.Win != d.Wout) return 1;

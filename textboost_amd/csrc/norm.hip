@@ -792,7 +792,7 @@ __global__ __launch_bounds__(GNS_T) void gn_slice_bwd_kernel(const f16* __restri
   }
 }
 // NV (dwords per thread) the slice kernels would need, 0 when they do not apply: even groups of <= 128 channels, strides even, enough slices
-// to occupy the chip, and the slice must fit the registers of 1024 threads (forward <= 44, backward <= 33 dwords per thread: x and dy live)
+// to occupy the chip, and the slice must fit the registers of 1024 threads (forward <= 44, backward <= 22 dwords per thread: x and dy live)
 int g_gn_fused = 3;  // tb_groupnorm_set_variant bits: 1 = one-pass 256-thread kernels for the small maps with 8-aligned groups, 2 = one-pass slice
                      // kernels for the large maps (round 4); 0 = always the two-pass kernels
 inline int gn_slice_nv(int B, int HW, int C, int G, bool bwd) {
@@ -805,9 +805,12 @@ inline int gn_slice_nv(int B, int HW, int C, int G, bool bwd) {
   // (4096x960 forward) 48 -> 60: those shapes keep the two-pass kernels
   const int nv = gns_items_per_thread(HW, gs);
   if (nv <= 11) return 11;
+  if (bwd && !(g_gn_fused & 4)) return 0;   // backward with 22 dwords of x and dy per thread (4096x320, 1024x1280): 39 -> 35 us on one box, 39 -> 45 on
+                                            // another; opt-in (bit 4) until the step says otherwise
   if (nv <= 22) return 22;
+  if (bwd) return 0;   // (33 dwords of x and of dy per thread: 1024x1920 backward 50.5 -> 60.1 us)
   if (nv <= 33) return 33;
-  if (nv <= 44 && !bwd) return 44;
+  if (nv <= 44) return 44;
   return 0;
 }
 
@@ -1056,8 +1059,7 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   hipLaunchKernelGGL((gn_slice_bwd_kernel<NV_, false>), dim3(B * G), dim3(GNS_T), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,      \
                      (const f16*)add, ldadd, (f16*)dx, lddx, B, HW, C, G, silu)
     if (nv == 11) TB_GNS_BWD(11);
-    else if (nv == 22) TB_GNS_BWD(22);
-    else TB_GNS_BWD(33);
+    else TB_GNS_BWD(22);
 #undef TB_GNS_BWD
     TB_CHECK_LAUNCH();
     return TB_OK;

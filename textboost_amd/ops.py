@@ -86,6 +86,32 @@ def _gemm_sync_counters(dev):
     return t
 
 
+def subpixel_ok(B, Hc, Wc, Cin, N, dtype=torch.float16):
+    """can nearest-x2 + conv3x3 over a coarse [B, Hc, Wc, Cin] map run as four 2x2-tap sub-pixel convolutions (`gemm(..., conv=dict(upsample=2 | 3))`)?"""
+    return dtype == torch.float16 and bool(L.lib().tb_gemm_subpixel_ok(B, Hc, Wc, Cin, N))
+
+
+def pack_subpixel_weights(w):
+    """[Co, Ci, 3, 3] conv weight of `Upsample2D` -> (forward [4*Co, 4*Ci], dgrad [Ci, 16*Co]) fp16 operands of the sub-pixel convolutions.
+    Output pixel (2Y+py, 2X+px) sees coarse rows Y-1+py+a, a in {0, 1}, through the filter rows KY[py][a] = ({0}, {1,2}) for py = 0 and
+    ({0,1}, {2}) for py = 1 (same in x); the rows are summed in fp32 and rounded ONCE to fp16 (the stated divergence from the 9-tap arithmetic).
+    forward: row (2py+px)*Co + co, column (2a+c)*Ci + ci.   dgrad: row ci, column (((2py+px)*4 + 2a'+c')*Co + co) with a' = 1-a, c' = 1-c (the
+    window of view (py, px) of the fine gradient starts at coarse row y - py: its first row meets the filter rows of a = 1)."""
+    Co, Ci = w.shape[0], w.shape[1]
+    w32 = w.detach().float()
+    KY = (((0,), (1, 2)), ((0, 1), (2,)))
+    fwd = torch.empty(4, Co, 4, Ci, dtype=torch.float32, device=w.device)
+    dg = torch.empty(Ci, 4, 4, Co, dtype=torch.float32, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for c in range(2):
+                    ws = sum(w32[:, :, ky, kx] for ky in KY[py][a] for kx in KY[px][c])   # [Co, Ci]
+                    fwd[2 * py + px, :, 2 * a + c, :] = ws
+                    dg[:, 2 * py + px, 2 * (1 - a) + (1 - c), :] = ws.t()
+    return fwd.reshape(4 * Co, 4 * Ci).half().contiguous(), dg.reshape(Ci, 16 * Co).half().contiguous()
+
+
 def gemm_ln_ok(M, N, K, dtype=torch.float16):
     """can a fp16 Linear of this shape carry a fused LayerNorm epilogue (`gemm(..., ln_fwd=... / ln_bwd=...)`)?"""
     return dtype == torch.float16 and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
@@ -124,6 +150,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
         d.ln_gamma, d.ln_stats = L.ptr(g_), L.ptr(st_)
     M = out.shape[0]
     N = W.shape[0]
+    if conv is not None and conv.get("upsample", 0) == 2:   # sub-pixel forward: W holds the four output classes' [N, 4 Cin] blocks
+        N //= 4
     d.M, d.N = M, N
     f32 = A.dtype == torch.float32  # fp32 (no-AMP) numeric mode: every operand fp32, the exact-fp32 MFMA kernel (csrc/f32_path.hip)
     if f32:
@@ -135,7 +163,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
         d.a_mode = L.A_CONV3X3
         for k, v in conv.items():
             setattr(d, k, v)
-        d.K = 9 * conv["Cin"]
+        # upsample = 2 / 3: the sub-pixel forms of nearest-x2 + conv3x3 (4 taps per output class / 16 per coarse pixel), see `subpixel_ok`
+        d.K = {2: 4, 3: 16}.get(conv.get("upsample", 0), 9) * conv["Cin"]
         d.K1 = d.K
         d.lda = A.stride(-2)
     else:

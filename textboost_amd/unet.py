@@ -34,6 +34,10 @@ MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  #
 # LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
 # residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
 FUSE_LN = _os.environ.get("TB_FUSE_LN", "1") == "1"
+# Upsampler convolutions (nearest x2 + conv3x3) as four 2x2-tap sub-pixel convolutions with pre-summed frozen weights (round 4): 2.25x fewer FLOP in
+# the forward and in the dgrad, no materialised 4x map, no 2x2 gradient pooling pass.  The summed filter rows are rounded to fp16 once: a stated
+# divergence from the 9-tap arithmetic, bounded in tests/test_gpu_gemm.py.  TB_SUBPIXEL=0 restores the materialised-upsample path (A/B).
+SUBPIXEL = _os.environ.get("TB_SUBPIXEL", "1") == "1"
 
 
 @dataclass
@@ -243,6 +247,9 @@ class HipUNet:
                     transformer(f"up_blocks.{i}.attentions.{j}", c)
             if i < len(ch) - 1:
                 conv(f"up_blocks.{i}.upsamplers.0.conv")
+                name = f"up_blocks.{i}.upsamplers.0.conv"
+                if wdt == torch.float16 and ops.subpixel_ok(self.B, self.H >> level, self.W >> level, c, c, wdt):
+                    P[name + ".wsub"], P[name + ".wdsub"] = ops.pack_subpixel_weights(sd[name + ".weight"].to(dev).to(wdt))
             prev = c
         # hoisted projections
         tw = torch.cat([sd[p + ".time_emb_proj.weight"] for p in self.resnets], dim=0)
@@ -589,7 +596,12 @@ class HipUNet:
                 nb, nhc = cats[(i + 1, 0)]
                 dst = nb[:, :nhc]
                 name = f"up_blocks.{i}.upsamplers.0.conv"
-                if MATERIALIZE_UPSAMPLE and hw[lvl - 1][1] % 16 == 0:
+                if SUBPIXEL and (name + ".wsub") in P:
+                    # four 2x2-tap convolutions on the COARSE map, each writing one parity class of the fine map (csrc/gemm8.hip, SUB = 1)
+                    ops.gemm(x, P[name + ".wsub"], dst, bias=P[name + ".b"],
+                             conv=dict(B=B, Hin=hw[lvl][0], Win=hw[lvl][1], Cin=x.shape[1], Hout=hw[lvl - 1][0], Wout=hw[lvl - 1][1], stride=1,
+                                       sign=1, upsample=2, transposed=0))
+                elif MATERIALIZE_UPSAMPLE and hw[lvl - 1][1] % 16 == 0:
                     # nearest x2 written out (12 us for the largest map), so that the halo-resident wide-tile kernel takes the convolution
                     # instead of the 4-wave gather with the upsampling folded in (311 -> ~205 us at 64x64 x 640 channels)
                     xu = self.scratch("up2x", Ms[lvl - 1], x.shape[1])
@@ -628,10 +640,16 @@ class HipUNet:
             M, cin = xin.shape
             if kind == "up":
                 name, lvl = fn
-                du = self.scratch("gu", Ms[lvl - 1], xin.shape[1])
-                self._conv(g, name, du, B, hw[lvl - 1][0], hw[lvl - 1][1], hw[lvl - 1][0], hw[lvl - 1][1], dgrad=True)
                 gx = self.buf(f"grad.up.{name}", M, cin)
-                ops.pool2x2_sum(du, gx, B, hw[lvl][0], hw[lvl][1], cin)
+                if SUBPIXEL and (name + ".wdsub") in self.P:
+                    # dgrad of the sub-pixel convolutions: the fine gradient read as four strided views, 16 taps per coarse pixel (SUB = 2)
+                    ops.gemm(g, self.P[name + ".wdsub"], gx,
+                             conv=dict(B=B, Hin=hw[lvl - 1][0], Win=hw[lvl - 1][1], Cin=g.shape[1], Hout=hw[lvl][0], Wout=hw[lvl][1], stride=1,
+                                       sign=1, upsample=3, transposed=0))
+                else:
+                    du = self.scratch("gu", Ms[lvl - 1], xin.shape[1])
+                    self._conv(g, name, du, B, hw[lvl - 1][0], hw[lvl - 1][1], hw[lvl - 1][0], hw[lvl - 1][1], dgrad=True)
+                    ops.pool2x2_sum(du, gx, B, hw[lvl][0], hw[lvl][1], cin)
                 g = gx
             elif kind == "attn":
                 gx = self.buf(f"grad.attn.{M}x{cin}.u", M, cin)
