@@ -115,6 +115,32 @@ int tb_gemm8_last(int* out5);
 /* profiling aid: device buffer of 16 x uint64 (NULL = off) that receives s_memtime stamps of the first / last workgroup of gemm8 launches */
 int tb_gemm8_debug(void* stamps16);
 
+/* ---- fused GEGLU feed-forward of diffusers BasicTransformerBlock (ff.net.0.proj -> h * gelu(g) -> ff.net.2; train_textboost.py:1063-1067 forward,
+ * :1108 backward) for the C = 320 transformer blocks of the 64x64 maps (csrc/ff_fused.hip): one launch per direction, the 128-row input tile stays
+ * in registers, the 4C-wide intermediate never goes to memory (forward: the gated tensor; backward: d(proj)); only the packed pre-gate
+ * projections HG (what tb_gemm's TB_ACT_GEGLU writes to C2, same [h32 | g32] packing) are written by the forward and read by the backward.
+ *   tb_ff_fwd: HG = X W1^T + b1 (fp16);  Y = fp16((h * gelu(g)) W2^T + b2 + R)            X = LayerNorm output [M, C]
+ *              W1 = ff.net.0.proj.weight with rows packed [h32 | g32] ([2 inner, C]), W2 = ff.net.2.weight [C, inner]
+ *   tb_ff_bwd: du = X W1^T;  dh = du gelu(g), dg = du h gelu'(g);  Y = fp16([dh | dg] W2^T + R)   X = d(out) [M, C]
+ *              W1 = ff.net.2.weight transposed [inner, C], W2 = the packed ff.net.0.proj.weight transposed [C, 2 inner]
+ * Same arithmetic as the two tb_gemm launches it replaces (fp16 operands, fp32 accumulation, the gate evaluated on the fp16-rounded projections);
+ * only the fp32 summation order of the second product differs.  tb_ff_fused_ok: M % 128 == 0, C == 320, inner == 1280. */
+typedef struct tb_ff_desc {
+  int64_t M; int32_t C, inner;
+  const void* X; int64_t ldx;      /* fp16 [M, C], 16-byte aligned rows */
+  const void* W1; int64_t ldw1;    /* fp16, see above */
+  const void* W2; int64_t ldw2;
+  const float* b1; const float* b2;/* forward: fp32 [2 inner] (packed like W1's rows) / [C], or NULL; backward: ignored */
+  void* HG; int64_t ldhg;          /* fp16 [M, 2 inner]: written by tb_ff_fwd, read by tb_ff_bwd */
+  const void* R; int64_t ldr;      /* optional fp16 [M, C] added to Y */
+  void* Y; int64_t ldy;            /* fp16 [M, C] */
+} tb_ff_desc;
+int tb_ff_fused_ok(int64_t M, int C, int inner);
+int tb_ff_fwd(const tb_ff_desc* d, tb_stream_t stream);
+int tb_ff_bwd(const tb_ff_desc* d, tb_stream_t stream);
+/* profiling aid (builds with -DFF_PROF=1 only): device buffer of 16 x uint64 (NULL = off) that receives per-phase s_memtime sums of waves 0 and 4 of workgroup 0 */
+int tb_ff_debug(void* buf16);
+
 /* measurement aid (bench.py `roofline.sustained_peak`): `blocks` workgroups of 4 waves issue iters * 16 independent v_mfma_f32_32x32x16_f16 each on
  * random register operands; FLOP = blocks * 4 * iters * 16 * 32768.  out: blocks * 256 floats (sink). */
 int tb_mfma_peak_probe(float* out, int blocks, int iters, tb_stream_t stream);

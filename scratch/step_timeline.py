@@ -12,8 +12,9 @@ for prev, r in zip(rows, rows[1:]):
     if r[1] - prev[2] > 100_000: groups.append(g); g = []
     g.append(r)
 groups.append(g)
-big = [x for x in groups if len(x) > 1000]
-g = big[-1]
+big = [x for x in groups if len(x) > 600]
+tight = [x for x in big if (x[-1][2] - x[0][1]) < 1.08 * sum(r[2] - r[1] for r in x)]   # graph replays (kernels abut), not the eager roofline leg
+g = (tight or big)[-1]
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 t0 = g[0][1]
 def short(n):

@@ -1,0 +1,102 @@
+"""GPU parity: the fused GEGLU feed-forward launches (tb_ff_fwd / tb_ff_bwd, csrc/ff_fused.hip) against torch fp32 and against the
+tb_gemm launches they replace (ff.net.0.proj + GEGLU epilogue, ff.net.2; their dgrads) -- diffusers BasicTransformerBlock.ff,
+train_textboost.py:1063-1067 / :1108."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from parity import parity
+from test_gpu_gemm import pack_geglu, rel_err
+
+pytestmark = pytest.mark.gpu
+
+C, INNER = 320, 1280
+
+
+def _ops():
+    from textboost_amd import ops, _lib
+    return ops, _lib
+
+
+def _weights(seed):
+    g = torch.Generator().manual_seed(seed)
+    w1 = (torch.randn(2 * INNER, C, generator=g) / C ** 0.5).half().cuda()       # ff.net.0.proj.weight (h rows, then g rows)
+    b1 = (torch.randn(2 * INNER, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(C, INNER, generator=g) / INNER ** 0.5).half().cuda()       # ff.net.2.weight
+    b2 = (torch.randn(C, generator=g) * 0.3).cuda()
+    return w1, b1, w2, b2
+
+
+def _ref_fwd(x, w1, b1, w2, b2, R):
+    proj = x.float() @ w1.float().T + b1
+    h, g = proj[:, :INNER].half().float(), proj[:, INNER:].half().float()     # the gate acts on the fp16-rounded projections
+    u = (h * F.gelu(g)).half().float()
+    y = u @ w2.float().T + b2
+    return proj, y + (R.float() if R is not None else 0)
+
+
+@pytest.mark.parametrize("M,with_r", [(128, True), (384, False), (4096, True)])
+def test_ff_forward_vs_torch_and_vs_the_two_launch_path(M, with_r):
+    ops, L = _ops()
+    assert ops.ff_fused_ok(M, C, INNER) and not ops.ff_fused_ok(M + 64, C, INNER) and not ops.ff_fused_ok(M, 640, 2560)
+    torch.manual_seed(M)
+    w1, b1, w2, b2 = _weights(1)
+    x = torch.randn(M, C, device="cuda").half()
+    R = torch.randn(M, C, device="cuda").half() if with_r else None
+    w1p, b1p = pack_geglu(w1).contiguous(), pack_geglu(b1).contiguous()
+    hg = torch.full((M, 2 * INNER + 16), 7.0, device="cuda", dtype=torch.float16)     # strided views: columns beyond the tensor stay untouched
+    ybuf = torch.full((M, C + 8), 7.0, device="cuda", dtype=torch.float16)
+    y = ops.ff_fwd(x, w1p, b1p, w2, b2, hg[:, :2 * INNER], ybuf[:, :C], R=R)
+    proj, yref = _ref_fwd(x, w1, b1, w2, b2, R)
+    parity("ff_fwd pre-gate projections (packed)", hg[:, :2 * INNER], pack_geglu(proj.T).T, 1e-3, 2e-3, ch_dim=1, ch_rel=2e-3)
+    parity("ff_fwd output", y, yref, 2e-3, 3e-3, ch_dim=1, ch_rel=3e-3)
+    assert (hg[:, 2 * INNER:] == 7).all() and (ybuf[:, C:] == 7).all()
+    # the launches it replaces: the same arithmetic up to fp32 summation order (k-step width of the MFMA shape the dispatcher picked for this M)
+    raw = torch.empty(M, 2 * INNER, device="cuda", dtype=torch.float16)
+    gated = torch.empty(M, INNER, device="cuda", dtype=torch.float16)
+    y2 = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.gemm(x, w1p, gated, bias=b1p, act=L.ACT_GEGLU, C2=raw)
+    ops.gemm(gated, w2, y2, bias=b2, R=R)
+    assert rel_err(raw, hg[:, :2 * INNER]) < 3e-4 and (raw.float() - hg[:, :2 * INNER].float()).abs().max().item() < 8e-3   # <= 1 fp16 ulp at |x| < 8
+    assert rel_err(y, y2) < 3e-4
+
+
+@pytest.mark.parametrize("M,with_r", [(128, False), (384, True), (4096, False)])
+def test_ff_backward_vs_autograd_and_vs_the_two_launch_path(M, with_r):
+    ops, L = _ops()
+    torch.manual_seed(M + 1)
+    w1, b1, w2, b2 = _weights(2)
+    x = torch.randn(M, C, device="cuda").half()
+    dy = torch.randn(M, C, device="cuda").half()
+    R = torch.randn(M, C, device="cuda").half() if with_r else None
+    w1p, b1p = pack_geglu(w1).contiguous(), pack_geglu(b1).contiguous()
+    hg = torch.empty(M, 2 * INNER, device="cuda", dtype=torch.float16)
+    y = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.ff_fwd(x, w1p, b1p, w2, b2, hg, y)
+    w2d, w1d = w2.t().contiguous(), w1p.t().contiguous()      # the dgrad operands: ff.net.2.weight^T [inner, C], packed proj weight^T [C, 2 inner]
+    dx = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.ff_bwd(dy, w2d, w1d, hg, dx, R=R)
+    # torch: the gradient of u @ w2^T with u = h * gelu(g) taken at the stored (fp16) projections, d(proj) rounded to fp16 like the operand of the
+    # second product
+    blocks = hg.float().reshape(M, INNER // 32, 2, 32)
+    h = blocks[:, :, 0].reshape(M, INNER).requires_grad_(True)
+    g = blocks[:, :, 1].reshape(M, INNER).requires_grad_(True)
+    u = h * F.gelu(g)
+    du = dy.float() @ w2.float()
+    u.backward(du)
+    dh, dg = h.grad.half().float(), g.grad.half().float()
+    ref = dh @ w1[:INNER].float() + dg @ w1[INNER:].float() + (R.float() if R is not None else 0)
+    parity("ff_bwd d(x)", dx, ref, 2e-3, 3e-3, ch_dim=1, ch_rel=3e-3)
+    # the launches it replaces
+    dproj = torch.empty(M, 2 * INNER, device="cuda", dtype=torch.float16)
+    dx2 = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.gemm(dy, w2d, dproj, act=L.ACT_GEGLU_GRAD, C2=hg)
+    ops.gemm(dproj, w1d, dx2, R=R)
+    assert rel_err(dx, dx2) < 3e-4
+
+
+def test_ff_fused_rejects_what_it_does_not_cover():
+    ops, L = _ops()
+    d = L.FfDesc()
+    d.M, d.C, d.inner = 100, C, INNER
+    assert L.lib().tb_ff_fwd(d, None) == -22 and L.lib().tb_ff_bwd(d, None) == -22

@@ -63,6 +63,20 @@ class AttnDesc(C.Structure):
     ]
 
 
+class FfDesc(C.Structure):
+    """tb_ff_desc (include/textboost_hip.h): the fused GEGLU feed-forward of the C = 320 transformer blocks"""
+    _fields_ = [
+        ("M", C.c_int64), ("C", C.c_int32), ("inner", C.c_int32),
+        ("X", C.c_void_p), ("ldx", C.c_int64),
+        ("W1", C.c_void_p), ("ldw1", C.c_int64),
+        ("W2", C.c_void_p), ("ldw2", C.c_int64),
+        ("b1", C.c_void_p), ("b2", C.c_void_p),
+        ("HG", C.c_void_p), ("ldhg", C.c_int64),
+        ("R", C.c_void_p), ("ldr", C.c_int64),
+        ("Y", C.c_void_p), ("ldy", C.c_int64),
+    ]
+
+
 _lib = None
 
 _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -70,6 +84,10 @@ _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
     "tb_gemm_ln_epilogue_ok": ([C.c_int64, C.c_int64, C.c_int64], C.c_int),
     "tb_gemm_subpixel_ok": ([_I, _I, _I, _I, _I], C.c_int),
+    "tb_ff_fused_ok": ([C.c_int64, _I, _I], C.c_int),
+    "tb_ff_fwd": ([C.POINTER(FfDesc), _VP], C.c_int),
+    "tb_ff_bwd": ([C.POINTER(FfDesc), _VP], C.c_int),
+    "tb_ff_debug": ([_VP], C.c_int),
     "tb_last_hip_error": ([], C.c_char_p),
     "tb_mfma_peak_probe": ([_VP, _I, _I, _VP], C.c_int),
     "tb_gemm_set_variant": ([_I], C.c_int),

@@ -482,6 +482,49 @@ def kpl_mse(h, h0, dh, partial, loss_out, loss_scale, weight):
                                L.ptr(partial), L.ptr(loss_out), L.ptr(loss_scale), weight, M, D, L.stream()), "tb_kpl_mse")
 
 
+def ff_fused_ok(M, C, inner, dtype=torch.float16):
+    """can the GEGLU feed-forward of this shape run as the fused launches `ff_fwd` / `ff_bwd` (csrc/ff_fused.hip: C = 320, 128-row tiles)?"""
+    return dtype == torch.float16 and bool(L.lib().tb_ff_fused_ok(M, C, inner))
+
+
+def _ff_desc(x, w1, w2, hg, y, R, b1=None, b2=None):
+    d = L.FfDesc()
+    d.M, d.C, d.inner = x.shape[0], x.shape[1], hg.shape[1] // 2
+    d.X, d.ldx = L.ptr(x), x.stride(0)
+    d.W1, d.ldw1 = L.ptr(w1), w1.stride(0)
+    d.W2, d.ldw2 = L.ptr(w2), w2.stride(0)
+    d.b1, d.b2 = L.ptr(b1), L.ptr(b2)
+    d.HG, d.ldhg = L.ptr(hg), hg.stride(0)
+    if R is not None:
+        d.R, d.ldr = L.ptr(R), R.stride(0)
+    d.Y, d.ldy = L.ptr(y), y.stride(0)
+    return d
+
+
+def ff_fwd(x, w1p, b1p, w2, b2, hg, y, R=None):
+    """BasicTransformerBlock.ff in one launch: hg[M, 2 inner] = x @ w1p^T + b1p (packed [h32|g32] rows, kept for the backward),
+    y = (h * gelu(g)) @ w2^T + b2 (+ R).  Same operands as gemm(act=ACT_GEGLU, C2=hg) followed by gemm(R=...)."""
+    M, C = x.shape
+    inner = hg.shape[1] // 2
+    d = _ff_desc(x, w1p, w2, hg, y, R, b1p, b2)
+    byt = 2.0 * (M * C + 3 * C * inner + M * 2 * inner + M * C * (2 if R is not None else 1))
+    with _rec("ff_fused_kernel<false>", 2.0 * M * C * 3 * inner, byt):
+        L.check(L.lib().tb_ff_fwd(d, L.stream()), "tb_ff_fwd")
+    return y
+
+
+def ff_bwd(dy, w2d, w1d, hg, dx, R=None):
+    """its backward in one launch: du = dy @ w2d^T (w2d = ff.net.2.weight^T [inner, C]); dh = du gelu(g), dg = du h gelu'(g);
+    dx = [dh | dg] @ w1d^T (w1d = packed ff.net.0.proj.weight^T [C, 2 inner]) (+ R)."""
+    M, C = dy.shape
+    inner = hg.shape[1] // 2
+    d = _ff_desc(dy, w2d, w1d, hg, dx, R)
+    byt = 2.0 * (M * C + 3 * C * inner + M * 2 * inner + M * C * (2 if R is not None else 1))
+    with _rec("ff_fused_kernel<true>", 2.0 * M * C * 3 * inner, byt):
+        L.check(L.lib().tb_ff_bwd(d, L.stream()), "tb_ff_bwd")
+    return dx
+
+
 def geglu_bwd(dout, raw, dproj):
     M, inner = dout.shape
     assert dout.dtype == torch.float16, "fp32 mode runs the GEGLU backward in the ff.net.2 dgrad epilogue (TB_ACT_GEGLU_GRAD)"

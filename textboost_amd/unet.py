@@ -30,6 +30,8 @@ import os as _os
 # GEGLU backward fused into the ff.net.2 dgrad GEMM's epilogue: with the lean wide-tile epilogue it saves the d(gated) round trip
 # (A/B in one process: 35.23 -> 35.06 ms per step); through the 4-wave kernels' generic epilogue it was slower than the streaming kernel
 FUSE_GEGLU_BWD = _os.environ.get("TB_FUSE_GEGLU_BWD", "1") == "1"
+# the whole GEGLU feed-forward of the C = 320 blocks as one launch per direction (csrc/ff_fused.hip): the gated tensor / d(proj) never go to memory
+FUSE_FF = _os.environ.get("TB_FUSE_FF", "1") == "1"
 MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  # A/B switch (see the up-block forward)
 # LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
 # residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
@@ -403,30 +405,40 @@ class HipUNet:
             ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
             ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
         raw = self.buf(prefix + ".raw", M, 8 * C)
-        gated = self.scratch("b", M, 4 * C)
-        ops.gemm(l3, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.b"], act=L.ACT_GEGLU, C2=raw)
-        t3 = self.scratch("a", M, C)
-        ops.gemm(gated, P[tb + ".ff.net.2.w"], t3, bias=P[tb + ".ff.net.2.b"], R=t2)
+        fuse_ff = FUSE_FF and ops.ff_fused_ok(M, C, 4 * C, self.dtype)
+        if fuse_ff:
+            t3 = self.scratch("a2" if fuse_ln else "b", M, C)   # (not scratch "a": l3 is being read)
+            ops.ff_fwd(l3, P[tb + ".ff1.w"], P[tb + ".ff1.b"], P[tb + ".ff.net.2.w"], P[tb + ".ff.net.2.b"], raw, t3, R=t2)
+        else:
+            gated = self.scratch("b", M, 4 * C)
+            ops.gemm(l3, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.b"], act=L.ACT_GEGLU, C2=raw)
+            t3 = self.scratch("a", M, C)
+            ops.gemm(gated, P[tb + ".ff.net.2.w"], t3, bias=P[tb + ".ff.net.2.b"], R=t2)
         ops.gemm(t3, P[prefix + ".proj_out.w"], out, bias=P[prefix + ".proj_out.b"], R=x)
         stop_after_cross = (tb + ".attn2") == self.first_xattn
 
         def bwd(dout, dx):
             dt3 = self.scratch("g1", M, C)
             ops.gemm(dout, P[prefix + ".proj_out.wd"], dt3)
-            dproj = self.scratch("gc", M, 8 * C)
-            if FUSE_GEGLU_BWD or self.dtype == torch.float32:   # ff.net.2 dgrad with the GEGLU backward fused into its epilogue
-                ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
-            else:
-                dgated = self.scratch("gb", M, 4 * C)
-                ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dgated)
-                ops.geglu_bwd(dgated, raw, dproj)
             dt2 = self.scratch("g3", M, C)
-            if fuse_ln:
-                ops.gemm(dproj, P[tb + ".ff1.wd"], dt2, R=dt3, ln_bwd=(P[tb + ".norm3.g"], ls3, t2))
-            else:
+            if fuse_ff:   # ff.net.2 dgrad, GEGLU backward and ff.net.0 dgrad in one launch; the LayerNorm backward behind it
                 dl3 = self.scratch("g2", M, C)
-                ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
+                ops.ff_bwd(dt3, P[tb + ".ff.net.2.wd"], P[tb + ".ff1.wd"], raw, dl3)
                 ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
+            else:
+                dproj = self.scratch("gc", M, 8 * C)
+                if FUSE_GEGLU_BWD or self.dtype == torch.float32:   # ff.net.2 dgrad with the GEGLU backward fused into its epilogue
+                    ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dproj, act=L.ACT_GEGLU_GRAD, C2=raw)
+                else:
+                    dgated = self.scratch("gb", M, 4 * C)
+                    ops.gemm(dt3, P[tb + ".ff.net.2.wd"], dgated)
+                    ops.geglu_bwd(dgated, raw, dproj)
+                if fuse_ln:
+                    ops.gemm(dproj, P[tb + ".ff1.wd"], dt2, R=dt3, ln_bwd=(P[tb + ".norm3.g"], ls3, t2))
+                else:
+                    dl3 = self.scratch("g2", M, C)
+                    ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
+                    ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
             do2 = self.scratch("g1", M, C)
             ops.gemm(dt2, P[tb + ".attn2.to_out.0.wd"], do2)
             dq2 = self.scratch("g2", M, C)
