@@ -139,10 +139,10 @@ def mfma_busy_table():
     return None
 
 
-def cpu_baseline_leg(max_seconds=170.0, n_steps=10, b1_seconds=40.0):
+def cpu_baseline_leg(max_seconds=260.0, n_steps=10, b1_seconds=60.0):
     """oracle/ (the eager-PyTorch fp32 restatement of the reference step) timed on this box's host cores:
-    (1) up to `n_steps` optimizer steps at B=1 of the same SD1.5 shapes (config 1's batch), the first two discarded as warm-up, MEDIAN of
-    the rest, bounded by `b1_seconds`; (2) when the budget allows, ONE real step at the metric's batch 8 -- the like-for-like number.
+    (1) 7 to `n_steps` optimizer steps at B=1 of the same SD1.5 shapes (config 1's batch), the first two discarded as warm-up, MEDIAN of
+    the rest (at least five), the steps beyond the seventh bounded by `b1_seconds`; (2) when the budget allows, ONE real step at the metric's batch 8 -- the like-for-like number.
     `value` is the real B=8 step when it ran, else the B=1 median scaled by 8 (`scaled` says which)."""
     from oracle import train_step as ts
     from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
@@ -189,7 +189,7 @@ def cpu_baseline_leg(max_seconds=170.0, n_steps=10, b1_seconds=40.0):
     t_begin = time.perf_counter()
     for i in range(n_steps):
         times.append(one(1))
-        if time.perf_counter() - t_begin > b1_seconds and len(times) >= 3:
+        if time.perf_counter() - t_begin > b1_seconds and len(times) >= 7:   # at least 5 timed steps behind the two warm-up ones
             break
     skip = 2 if len(times) >= 4 else 1
     timed = sorted(times[skip:])

@@ -295,9 +295,11 @@ def test_random_shape_sweep_of_the_whole_item_pipeline():
             assert np.array_equal(got["pixel_values"][b].cpu().numpy(), pv), (case, b, h, w, size, cfg, center)
 
 
-def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch):
+@pytest.mark.parametrize("G", [1, 2])
+def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch, G):
     """Resume (train_textboost.py:959-981): a run interrupted at checkpoint-2 and resumed to step 4 sees the same samples (index streams
-    fast-forwarded, torch / numpy / `random` states restored from random_states_0.pkl) as the uninterrupted run."""
+    fast-forwarded, torch / numpy / `random` states restored from random_states_0.pkl) as the uninterrupted run -- also with
+    --gradient_accumulation_steps G > 1, where an optimizer step consumed G batches."""
     import sys
     pytest.importorskip("PIL")
     from PIL import Image
@@ -312,7 +314,8 @@ def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     base = ["--pretrained_model_name_or_path", "/nonexistent/sd15", "--instance_data_dir", str(data), "--train_batch_size", "2", "--resolution",
             "64", "--placeholder_token", "<dog>", "--initializer_token", "dog", "--lora_rank", "4", "--mixed_precision", "fp16", "--seed", "11",
-            "--augment", "paug", "--augment_inversion", "--augment_p", "0.9", "--checkpointing_steps", "2", "--emb_learning_rate", "1e-2"]
+            "--augment", "paug", "--augment_inversion", "--augment_p", "0.9", "--checkpointing_steps", "2", "--emb_learning_rate", "1e-2",
+            "--gradient_accumulation_steps", str(G)]
     prompts = {}
 
     def run(out, extra):
@@ -335,7 +338,7 @@ def test_cli_resume_replays_the_feeder_streams(tmp_path, monkeypatch):
     run(str(tmp_path / "part"), ["--max_train_steps", "2"])
     resumed = run(str(tmp_path / "part"), ["--max_train_steps", "4", "--resume_from_checkpoint", "latest"])
     a, bc = prompts[str(tmp_path / "full")], prompts[str(tmp_path / "part")]
-    assert len(a) == 4 and bc == a  # same indices, same augmented prompts, batch by batch across the interruption
+    assert len(a) == 4 * G and bc == a  # same indices, same augmented prompts, batch by batch across the interruption
     assert torch.allclose(full, resumed, rtol=0, atol=2e-3) and not torch.equal(full, torch.zeros_like(full))
 
 

@@ -535,7 +535,7 @@ def test_unet_crossattn_kv_lora_step_matches_oracle(tmp_path):
     assert torch.equal(hip_unet.kv_lora_A, A0) and torch.equal(hip_unet.kv_lora_B, B0) and torch.equal(step.m_unet, m0)
     ckpt.save_unet_adapters(hip_unet, str(tmp_path / "unet"), "base")
     from safetensors.torch import load_file
-    sd = load_file(str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    sd = load_file(str(tmp_path / "unet" / "adapter_model.safetensors"))
     assert len(sd) == 64 and sd["mid_block.attentions.0.transformer_blocks.0.attn2.to_v.lora_A.default.weight"].shape == (r, D)
 
 
@@ -553,7 +553,7 @@ def test_cli_unet_crossattn_kv(tmp_path):
             "--max_train_steps", "3", "--checkpointing_steps", "2", "--placeholder_token", "<dog>", "--lora_rank", "4", "--seed", "1",
             "--unet_params_to_train", "crossattn_kv"]
     T.main(T.parse_args(base))
-    sd = load_file(os.path.join(out, "unet", "diffusion_pytorch_model.safetensors"))
+    sd = load_file(os.path.join(out, "unet", "adapter_model.safetensors"))
     assert len(sd) == 64
     assert any(v.abs().max() > 0 for k, v in sd.items() if "lora_B" in k), "the UNet adapters did not train"
     assert os.path.exists(os.path.join(out, "checkpoint-2", "model_1.safetensors"))

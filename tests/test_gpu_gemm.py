@@ -169,10 +169,11 @@ def test_gemm_rejects_bad_args():
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(8, 64, 128, 64, 64), (8, 128, 320, 64, 64), (8, 64, 640, 32, 32), (8, 64, 2048, 16, 16),
                                             (2, 192, 1280, 64, 64), (2, 64, 128, 48, 128), (1, 128, 64, 24, 256), (1, 64, 128, 8, 512), (4, 64, 128, 96, 96),
-                                            (8, 128, 64, 48, 48), (16, 64, 64, 32, 24)])
+                                            (8, 128, 64, 48, 48), (16, 64, 64, 32, 24), (8, 640, 1280, 8, 8), (4, 1280, 1280, 8, 8)])
 def test_conv3x3_halo_kernel_fwd_and_dgrad(B, Cin, Cout, H, W):
-    """shapes that take the LDS-halo path (whole image rows per 128-pixel tile, or 128-pixel segments of rows 128 / 256 / 512 wide
-    as in the VAE encoder; >= 200 tiles), checked against F.conv2d and against the per-tap gather kernel (halo path switched off)."""
+    """shapes that take the LDS-halo path (whole image rows per 128-pixel tile, 128-pixel segments of rows 128 / 256 / 512 wide
+    as in the VAE encoder, or -- round 4 -- two whole 8x8 images per tile, each with its own zero border; >= 200 tiles incl. k-slices),
+    checked against F.conv2d and against the per-tap gather kernel (halo path switched off)."""
     ops, L = _ops()
     torch.manual_seed(7)
     x = torch.randn(B, Cin, H, W, device="cuda").half()
@@ -182,12 +183,16 @@ def test_conv3x3_halo_kernel_fwd_and_dgrad(B, Cin, Cout, H, W):
     xn = nhwc(x).view(B * H * W, Cin)
     geo = dict(B=B, Hin=H, Win=W, Cin=Cin, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=0)
     outs = []
-    for halo in (1, 0):
+    for halo in (3, 0):
         L.lib().tb_gemm_set_variant(7000 + halo)
         out = torch.empty(B * H * W, Cout, device="cuda", dtype=torch.float16)
         ops.gemm(xn, pack_conv_w(w), out, bias=bias, R=res, conv=geo)
         outs.append(out)
-    L.lib().tb_gemm_set_variant(7001)
+        if halo and H * W < 128:   # the two-images-per-tile case must really run the halo kernel
+            cfg = (__import__("ctypes").c_int * 5)()
+            L.lib().tb_gemm_last_config(cfg)
+            assert cfg[2] == 2, "the shape must take conv_halo_kernel"
+    L.lib().tb_gemm_set_variant(7003)
     ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * W, Cout) + res.float()
     assert rel_err(outs[0], ref) < 2e-3
     assert rel_err(outs[0], outs[1]) < 1e-3   # same products, different fp32 summation order (chunk-outer vs tap-outer)

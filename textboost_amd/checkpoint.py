@@ -72,13 +72,15 @@ def load_unet_lora_state_dict(unet, sd):
 def save_unet_adapters(unet, out_dir: str, base_model_name_or_path: str):
     """<out>/unet/ (:1237-1239).  The reference's `unet.save_pretrained` writes the WHOLE fp32 UNet (3.4 GB: the frozen base weights under
     `.base_layer.` names plus the adapters); no reader of the output layout loads it (inference.py / eval_dreambooth.py never open unet/).
-    Written here: the adapter tensors under exactly those parameter names, plus a note naming the base model whose weights are unchanged."""
+    Written here in peft's adapter layout, so that the file name does not promise a loadable diffusers model: `adapter_model.safetensors` (the
+    adapter tensors under the parameter names `unet.add_adapter` gives them) + `adapter_config.json` naming the base model whose weights are unchanged."""
     os.makedirs(out_dir, exist_ok=True)
-    save_file(unet_lora_state_dict(unet), os.path.join(out_dir, "diffusion_pytorch_model.safetensors"), metadata={"format": "pt"})
-    with open(os.path.join(out_dir, "adapter_note.json"), "w") as f:
-        json.dump({"contains": "cross-attention to_k / to_v LoRA adapters only", "r": unet.kv_r, "lora_alpha": unet.kv_r,
-                   "target_modules": ["attn2.to_k", "attn2.to_v"], "base_model_name_or_path": base_model_name_or_path,
-                   "base_weights": "unchanged (frozen): load them from base_model_name_or_path/unet"}, f, indent=2, sort_keys=True)
+    save_file(unet_lora_state_dict(unet), os.path.join(out_dir, "adapter_model.safetensors"), metadata={"format": "pt"})
+    cfg = adapter_config(unet.kv_r, base_model_name_or_path)
+    cfg["target_modules"] = ["attn2.to_k", "attn2.to_v"]
+    cfg["base_weights"] = "unchanged (frozen): load them from base_model_name_or_path/unet"
+    with open(os.path.join(out_dir, "adapter_config.json"), "w") as f:
+        json.dump(cfg, f, indent=2, sort_keys=True)
 
 
 def adapter_config(rank: int, base_model_name_or_path: str) -> dict:

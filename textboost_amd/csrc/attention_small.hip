@@ -140,18 +140,21 @@ __global__ __launch_bounds__(1024) void attn_bwd_small_kernel(const tb_attn_desc
 }  // namespace
 
 // true when the short-sequence kernel takes this backward (attention.hip asks before its generic dispatch)
+static int g_small_lds_ok = -1;   // does the device grant sizeof(SmallLds) of dynamic LDS to the kernel?  (asked once; a part with 64 KB says no and
+                                  // attention.hip's generic dQ + dK/dV launches take the call instead of a TB_ELAUNCH)
 bool tb_attn_small_bwd_ok(const tb_attn_desc& d) {
+  if (g_small_lds_ok < 0)
+    g_small_lds_ok = hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallLds)) == hipSuccess;
+  if (!g_small_lds_ok) {
+    (void)hipGetLastError();
+    return false;
+  }
   return d.hd == SM_HD && d.Sq == d.Skv && d.Sq <= SM_T && d.Sq >= 1 && d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0 &&
          d.lddo % 8 == 0 && ((uintptr_t)d.Q) % 16 == 0 && ((uintptr_t)d.K) % 16 == 0 && ((uintptr_t)d.V) % 16 == 0 && ((uintptr_t)d.O) % 16 == 0 &&
          ((uintptr_t)d.dO) % 16 == 0 && d.LSE && d.dQ && d.dK && d.dV;
 }
 int tb_attn_small_bwd(const tb_attn_desc& d, hipStream_t s) {
-  const size_t lds = sizeof(SmallLds);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TB_ELAUNCH;
-    attr_done = true;
-  }
+  const size_t lds = sizeof(SmallLds);   // (granted: tb_attn_small_bwd_ok set the attribute)
   hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(d.H, d.B), dim3(1024), lds, s, d);
   TB_CHECK_LAUNCH();
   return TB_OK;

@@ -734,8 +734,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   const int wm = wave >> 1, wn = wave & 1;
   // tile = R image rows x TW = min(W, 64) columns (R * TW = 128 output pixels): whole rows for W <= 64, a 2 x 64 block for wider maps
   // (the same 4 x 66 halo and 3 blocks per CU as the 64-wide case; a 1 x 128 row segment would need 3 x 130 halo pixels and 66 KB)
+  // Maps smaller than a tile (8x8: H * W = 64, round 4): the tile is 128 / (H W) WHOLE images, the halo a stack of per-image (H + 2) x (W + 2) blocks
+  // (each image keeps its own zero border: a tap must not reach into the neighbouring image) -- the per-tap gather of gemm_kernel moved 9 x 16 KB of
+  // activations per channel chunk through the LDS-DMA path that bounds these launches, the halo is 25 KB.
   const int TW = 1 << wshift, W = p.Wout, H = p.Hout, R = BM >> wshift;
-  const int HC = TW + 2, NH = (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
+  const int hw_img = H * W;
+  const bool multi = hw_img < BM;                       // host: then W == TW and BM % hw_img == 0
+  const int HC = TW + 2, HIMG = (H + 2) * HC;           // halo pixels per image (multi)
+  const int NH = multi ? (BM / hw_img) * HIMG : (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
   f16* Hs = smem;
   f16* Wst = smem + NH8 * BK;  // two weight stages of BN x 64 halfs
 
@@ -759,8 +765,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   const int64_t n0 = (int64_t)tn * BN;
   const int hw = H * W;
   const int tiles_x = W >> wshift, tiles_img = (H / R) * tiles_x;  // tiles per image row-block / per image
-  const int b = tm / tiles_img;
-  const int trem = tm - b * tiles_img;
+  const int b = multi ? tm * (BM / hw_img) : tm / tiles_img;
+  const int trem = multi ? 0 : tm - b * tiles_img;
   const int y0 = (trem / tiles_x) * R, x0 = (trem % tiles_x) << wshift;  // first image row / column of the tile
   const int64_t m0 = (int64_t)b * hw + (int64_t)y0 * W + x0;             // output row of the tile's first pixel
 
@@ -773,10 +779,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   for (int i = 0; i < MAXHI; ++i) {
     const int j = wave + 4 * i;  // instruction index; rows j*8 .. j*8+7 of the halo image
     const int hr = j * 8 + rl;
-    const int hy = hr / HC, hx = hr - hy * HC;
+    const int img = multi ? hr / HIMG : 0, hr1 = hr - img * HIMG;   // (multi: image of the stack, halo pixel inside it)
+    const int hy = hr1 / HC, hx = hr1 - hy * HC;
     const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
     const bool ok = j < NI && hr < NH && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    h_ptr[i] = ok ? (const f16*)p.A + ((int64_t)b * hw + (int64_t)yy * W + xx) * p.lda + ((cp ^ SWZ(hr)) << 3) : zero;
+    h_ptr[i] = ok ? (const f16*)p.A + ((int64_t)(b + img) * hw + (int64_t)yy * W + xx) * p.lda + ((cp ^ SWZ(hr)) << 3) : zero;
     h_step[i] = ok ? BK : 0;
   }
   const f16* w_ptr[BI];
@@ -818,7 +825,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int ml = wm * WTM + i * 32 + l31;
-    hrow0[i] = (ml >> wshift) * HC + (ml & (TW - 1));
+    const int img = multi ? ml / hw_img : 0, ml1 = ml - img * hw_img;
+    hrow0[i] = img * HIMG + (ml1 >> wshift) * HC + (ml1 & (TW - 1));
   }
 
   for (int c = c_begin; c < c_end; ++c) {
@@ -875,7 +883,7 @@ int g_inkernel_reduce = 0;  // split-K launches with tb_gemm_desc.sync reduce in
                             // reducer launch, but the agent-scope partial stores / loads it needs make the step 35.1 ms against 31.3 (scratch/ab_step.py)
 int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
 int g_order = 0;    // tile order: 0 = 8-row groups (default), 1 = n-fastest, 2 = m-fastest (tb_gemm_set_variant(3000 + v))
-int g_halo = 1;     // 3x3 stride-1 convs on whole image rows use conv_halo_kernel (tb_gemm_set_variant(7000 + {0,1}))
+int g_halo = 3;     // 3x3 stride-1 convs use conv_halo_kernel: bit 0 = tiles of whole image rows, bit 1 = tiles of whole small images (8x8 maps) (tb_gemm_set_variant(7000 + bits))
 int g_ablate = 0;   // profiling only (tb_gemm_set_variant(2000 + bits)): 1 = skip k-loop loads, 2 = skip k-loop MFMAs
 int g_variant = 0;  // tuning knob (tb_gemm_set_variant): 0 = BK64 x 2 stages, 1 = BK32 x 3 stages, 2 = BK32 x 2 stages
 
@@ -950,7 +958,8 @@ template <int BN>
 int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
   const int tiles_m = (int)(d.M / 128), tiles_n = (int)((d.N + BN - 1) / BN);
   const int TW = 1 << wshift, R = 128 >> wshift;
-  const int nh8 = ((R + 2) * (TW + 2) + 7) & ~7;
+  const int hw_img = d.Hout * d.Wout;
+  const int nh8 = ((hw_img < 128 ? (128 / hw_img) * (d.Hout + 2) * (TW + 2) : (R + 2) * (TW + 2)) + 7) & ~7;
   size_t lds = (size_t)nh8 * 128 + 2 * (size_t)BN * 128;
   if (lds < (size_t)128 * BN * sizeof(float)) lds = (size_t)128 * BN * sizeof(float);
   g_last_cfg[0] = 128, g_last_cfg[1] = BN, g_last_cfg[2] = 2, g_last_cfg[3] = 642, g_last_cfg[4] = S;
@@ -983,6 +992,7 @@ inline int halo_wshift(int W, int H) {
   if (W & ((1 << sh) - 1)) return 0;
   if (sh < 3) return 0;
   const int R = 128 >> sh;
+  if (H * W < 128) return (W == (1 << sh) && 128 % (H * W) == 0) ? sh : 0;   // whole small images per tile (8x8 maps: two), see conv_halo_kernel
   return (H % R == 0) ? sh : 0;
 }
 
@@ -1007,7 +1017,7 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
 #endif
   const int64_t blocks = ((d.M + 127) / 128) * ((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
   if (MODE == TB_A_CONV3X3 && g_halo && d.stride == 1 && !d.upsample && !d.transposed && !d.shift && d.Hin == d.Hout && d.Win == d.Wout &&
-      halo_wshift(d.Wout, d.Hout) > 0) {
+      halo_wshift(d.Wout, d.Hout) > 0 && ((int64_t)d.Hout * d.Wout >= 128 ? (g_halo & 1) : ((g_halo & 2) && d.M % 128 == 0))) {
     // too few tiles for 256 CUs: split the 64-channel chunks over S blocks per tile (fp32 partials + the split-K reducer)
     int Sh = 1;
     const int kpt = d.Cin / 64;

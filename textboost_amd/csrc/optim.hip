@@ -32,7 +32,9 @@ __global__ void scaler_update_kernel(float* __restrict__ st, float max_norm, flo
                                      float backoff_factor, float growth_interval, int use_scaler, float grad_div) {
   const float scale = st[TB_ST_LOSS_SCALE];
   const float ss_lora = st[TB_ST_SUMSQ_LORA], ss_emb = st[TB_ST_SUMSQ_EMB];
-  const bool found_inf = !(isfinite(ss_lora) && isfinite(ss_emb));
+  // GradScaler.unscale_'s inf check exists only under the scaler (fp16 mode: text-encoder groups only, the UNet adapters need the fp32 mode); without
+  // it (no-AMP run) torch's optimizer.step() is never skipped, whatever the gradients hold
+  const bool found_inf = use_scaler && !(isfinite(ss_lora) && isfinite(ss_emb));
   // grad_div = data-parallel world size: the gradient buffer holds the all-reduce SUM, DDP's mean is folded into the coefficients here
   const float inv = 1.f / (scale * grad_div);
   const float total = sqrtf(ss_lora) * inv;                      // norm of the unscaled LoRA grads

@@ -166,6 +166,12 @@ def main(args):
         # DDIM instance's value) and steps_offset are inherited from the model's own scheduler
         scfg_path = os.path.join(mdir, "scheduler", "scheduler_config.json")
         scfg = json.load(open(scfg_path)) if os.path.exists(scfg_path) else None
+        if args.unet_params_to_train == "crossattn_kv":
+            # log_validation (:453-531) samples with the TRAINED unet (accelerator.unwrap_model(unet), fp32 in this mode); the sampler here is a
+            # separate fp16 UNet built from the base weights, so its images would silently miss the K/V adapters being trained
+            raise NotImplementedError("--validation_prompts together with --unet_params_to_train crossattn_kv: the validation sampler is an fp16 "
+                                      "UNet without the cross-attention K/V adapters; drop --validation_prompts (the adapters are saved to "
+                                      "<output_dir>/unet/ and in every checkpoint)")
         sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),  # (validation images: fp16 pipeline in both modes)
                              HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5,
                              scheduler_config=scfg, scheduler=args.validation_scheduler)
@@ -355,10 +361,11 @@ def main(args):
         if path:
             ckpt.load_trainer_state(step, path)  # also restores the torch / numpy / `random` generator states the feeder draws from
             first_step = int(os.path.basename(path.rstrip("/")).split("-")[1])
+            consumed = first_step * args.gradient_accumulation_steps * B   # every micro batch of every optimizer step drew B samples
             if index_stream is not None:          # the Wrapper streams are pure functions of (seed, position): fast-forward them
-                index_stream.take(first_step * B)
+                index_stream.take(consumed)
             if prior_feeder is not None:
-                prior_feeder.stream.take(first_step * B)
+                prior_feeder.stream.take(consumed)
     if is_main:
         logger.info("mean_norm %.6f | added tokens %s | world %d | per-GPU batch %d | precision %s", step.mean_norm, list(added_tokens) +
                     list(aug_token_dict), world, B, "fp32 (no mixed precision, no GradScaler)" if fp32_mode else "fp16 mixed precision")
