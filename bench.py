@@ -328,7 +328,7 @@ def main():
     ap.add_argument("--fp8-attn", action="store_true",
                     help="BASELINE.json configs[4]: e4m3 P.V in the forward of the hd = 40 self-attention layers (secondary measurement; "
                          "the metric's numerics are fp16)")
-    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16",
+    ap.add_argument("--precision", choices=["fp16", "fp32", "bf16"], default="fp16",
                     help="fp16 = --mixed_precision fp16, the reference driver's mode and the BASELINE.json metric; fp32 = the reference's default "
                          "no-AMP mode (README command; exact-fp32 MFMA at 1/16 of the fp16 matrix rate) -- a secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -440,6 +440,9 @@ def main():
         if args.fp8_attn:
             metric = metric[:-1] + ", fp8 P.V in the self-attention forward)"
             workload += "; e4m3 P.V (v_mfma_scale_f32_32x32x64_f8f6f4) in the forward of the 64x64-map self-attention layers (BASELINE.json configs[4])"
+        if args.precision == "bf16":
+            metric = metric[:-1] + ", bf16 mixed precision)"
+            workload += "; --mixed_precision bf16: the bfloat16 build of the kernel library (v_mfma_f32_*_bf16), no GradScaler"
         if args.precision == "fp32":
             metric = metric[:-1] + ", fp32 no-AMP mode)"
             workload += "; fp32 (no mixed precision) mode: every weight / activation / gradient fp32, v_mfma_f32_32x32x2_f32, no GradScaler"
@@ -454,7 +457,7 @@ def main():
             # global step; sps is the rate of the slowest rank (the timed region ends at a barrier, dt is the max over ranks)
             "metric": metric, "value": round(sps * world, 4), "unit": "steps/s",
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16"}.get(args.precision, "f16"), "data": "synthetic",
             "config": {"workload": workload,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "images_per_s": round(sps * args.batch * world, 2)},

@@ -24,6 +24,9 @@ extern "C" {
 typedef void* tb_stream_t; /* hipStream_t */
 
 /* ---- dtype / activation codes ------------------------------------------------------------- */
+/* TB_F16 = the 16-bit float of the BUILD: IEEE half in libtextboost_hip.so, bfloat16 in libtextboost_hip_bf16.so (the same sources compiled with
+ * -DTB_BF16: the reference's --mixed_precision bf16, train_textboost.py:298-308 / :930-934).  Every "fp16" in the comments below reads "the
+ * build's half type"; fp32 accumulation, statistics, losses and the optimizer are identical in both builds. */
 enum { TB_F16 = 0, TB_F32 = 1 };
 enum { TB_ACT_NONE = 0, TB_ACT_QUICK_GELU = 1, TB_ACT_GEGLU = 2, TB_ACT_SILU = 3, TB_ACT_QUICK_GELU_GRAD = 4, TB_ACT_GELU = 5,
        TB_ACT_GELU_GRAD = 6, TB_ACT_GEGLU_GRAD = 7,

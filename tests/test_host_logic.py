@@ -38,15 +38,30 @@ def test_library_exports_every_symbol_in_header():
     hdr = open(os.path.join(ROOT, "include", "textboost_hip.h")).read()
     names = set(re.findall(r"\b(tb_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 30
-    lib = ctypes.CDLL(_lib.LIB_PATH)
-    for n in sorted(names):
-        assert hasattr(lib, n), f"{n} declared in include/textboost_hip.h but not exported"
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_BF16):   # the fp16 build and the bfloat16 build (-DTB_BF16) share one C-ABI
+        lib = ctypes.CDLL(path)
+        for n in sorted(names):
+            assert hasattr(lib, n), f"{n} declared in include/textboost_hip.h but not exported by {os.path.basename(path)}"
     assert names == set(_lib._SIGS.keys()), names ^ set(_lib._SIGS.keys())
+
+
+def test_half_kind_switch_selects_the_library_and_the_dtype():
+    from textboost_amd import _lib
+    assert _lib.half_kind() == "fp16" and _lib.half_dtype() == torch.float16
+    prev = _lib.set_half("bf16")
+    try:
+        assert prev == "fp16" and _lib.half_dtype() == torch.bfloat16
+        h = _lib.lib()
+        assert h._name == _lib.LIB_PATH_BF16
+    finally:
+        _lib.set_half("fp16")
+    assert _lib.lib()._name == _lib.LIB_PATH and _lib.half_dtype() == torch.float16
 
 
 def test_missing_library_fails_loudly(monkeypatch):
     from textboost_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtextboost_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()

@@ -9,6 +9,8 @@ import torch  # noqa: F401  (must be imported first so libamdhip64.so.7 resolves
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtextboost_hip" + os.environ.get("TB_LIB_SUFFIX", "") + ".so")
+# the same sources compiled with -DTB_BF16: every 16-bit operand / activation is bfloat16 (the reference's --mixed_precision bf16)
+LIB_PATH_BF16 = os.path.join(_PKG, "libtextboost_hip_bf16" + os.environ.get("TB_LIB_SUFFIX", "") + ".so")
 
 TB_F16, TB_F32 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU_GRAD, ACT_GELU, ACT_GELU_GRAD, ACT_GEGLU_GRAD = 0, 1, 2, 3, 4, 5, 6, 7
@@ -173,17 +175,42 @@ _SIGS = {
 IMG_LANCZOS, IMG_BICUBIC = 1, 3
 
 
+_half = "fp16"     # the 16-bit float of the ACTIVE library: one process runs one numeric mode (like the reference's accelerator)
+_libs = {}
+
+
+def set_half(kind: str):
+    """select the library every `lib()` call returns: "fp16" (libtextboost_hip.so) or "bf16" (libtextboost_hip_bf16.so, same C-ABI, TB_F16 then
+    means bfloat16).  Returns the previous kind."""
+    global _half, _lib
+    assert kind in ("fp16", "bf16"), kind
+    prev, _half = _half, kind
+    _lib = _libs.get(kind)
+    return prev
+
+
+def half_kind() -> str:
+    return _half
+
+
+def half_dtype():
+    """torch dtype of the active library's 16-bit float"""
+    return torch.bfloat16 if _half == "bf16" else torch.float16
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH_BF16 if _half == "bf16" else LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -m textboost_amd.build` (hipcc --offload-arch=gfx950). "
+                f"{path} is missing: build it with `python -m textboost_amd.build` (hipcc --offload-arch=gfx950). "
                 "textboost_amd has no CPU fallback.")
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(path)
         for name, (args, res) in _SIGS.items():
             fn = getattr(_lib, name)  # AttributeError here = library older than the header
             fn.argtypes, fn.restype = args, res
+        _libs[_half] = _lib
     return _lib
 
 

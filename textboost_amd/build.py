@@ -24,12 +24,22 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+LIB_BF16 = os.path.join(PKG, f"libtextboost_hip_bf16{SUFFIX}.so")
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """both libraries: the fp16 one (returned) and, from the same sources with -DTB_BF16, the bfloat16 one of --mixed_precision bf16"""
+    lib = _build_one(LIB, os.path.join(PKG, "build" + SUFFIX), [], force, verbose)
+    if os.environ.get("TB_SKIP_BF16", "0") != "1":
+        _build_one(LIB_BF16, os.path.join(PKG, "build_bf16" + SUFFIX), ["-DTB_BF16"], force, verbose)
+    return lib
+
+
+def _build_one(LIB: str, objdir: str, defs, force: bool, verbose: bool) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
     newest_hdr = max([os.path.getmtime(h) for h in hdrs] + [0.0])
-    objdir = os.path.join(PKG, "build" + SUFFIX)
-    extra = os.environ.get("TB_CFLAGS", "").split()
+    extra = list(defs) + os.environ.get("TB_CFLAGS", "").split()
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []

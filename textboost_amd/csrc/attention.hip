@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
       }
 #pragma unroll
       for (int j = 0; j < KS; ++j)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s[kt], 0, 0, 0);
+        s[kt] = TB_MFMA_32x32x16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s[kt]);
     }
     TB_PRIO(0);
     // masking is needed only on the ragged last tile / the causal diagonal: wave-uniform test keeps it off the common path
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
         const f16x8 pf = pack8(s[kt], 8 * jj);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Vt, d, l31, kt * 32 + 16 * jj, hi), pf, o[d], 0, 0, 0);
+          o[d] = TB_MFMA_32x32x16(frag_tr(Vt, d, l31, kt * 32 + 16 * jj, hi), pf, o[d]);
       }
     TB_PRIO(0);
     if (PF) {
@@ -616,9 +616,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
       for (int g = 0; g < QG; ++g)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          s[g][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][0], qf[g][0], negm[g], 0, 0, 0);
+          s[g][kt] = TB_MFMA_32x32x16(kf[kt][0], qf[g][0], negm[g]);
 #pragma unroll
-          for (int j = 1; j < KS; ++j) s[g][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][j], qf[g][j], s[g][kt], 0, 0, 0);
+          for (int j = 1; j < KS; ++j) s[g][kt] = TB_MFMA_32x32x16(kf[kt][j], qf[g][j], s[g][kt]);
         }
     }
     // V^T fragments of the whole tile (shared by the query groups): issued now, they arrive under the softmax arithmetic below
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
         for (int g = 0; g < QG; ++g) {
           const f16x8 pf = pack8(s[g][kt], 8 * jj);
 #pragma unroll
-          for (int d = 0; d < DT; ++d) o[g][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[d], pf, o[g][d], 0, 0, 0);
+          for (int d = 0; d < DT; ++d) o[g][d] = TB_MFMA_32x32x16(a[d], pf, o[g][d]);
         }
       }
     TB_PF(2)
@@ -895,8 +895,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
       for (int j = 0; j < KS; ++j) {
         const f16x8 kfr = *(const f16x8*)(Ks + rm_lane + kt * 32 * PCB + j * 32);
         const f16x8 vfr = *(const f16x8*)(Ks + TILE_B + rm_lane + kt * 32 * PCB + j * 32);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, qf[j], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr, dof[j], dp, 0, 0, 0);
+        s = TB_MFMA_32x32x16(kfr, qf[j], s);
+        dp = TB_MFMA_32x32x16(vfr, dof[j], dp);
       }
       f16x4 ktf[2][DT][2];  // K^T fragments of this 32-key half: issued behind the score products, they arrive under the exponentials
       __builtin_amdgcn_sched_barrier(0);
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
           f16x8 a;
 #pragma unroll
           for (int e = 0; e < 4; ++e) a[e] = ktf[jj][d][0][e], a[4 + e] = ktf[jj][d][1][e];
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, dsf, dq[d], 0, 0, 0);
+          dq[d] = TB_MFMA_32x32x16(a, dsf, dq[d]);
         }
       }
     }
@@ -1060,8 +1060,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const tb_attn_
       for (int j = 0; j < KS; ++j) {
         const f16x8 qfr = *(const f16x8*)(Qs + rm_lane + qt * 32 * PCB + j * 32);
         const f16x8 dofr = *(const f16x8*)(Qs + TILE_B + rm_lane + qt * 32 * PCB + j * 32);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[j], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[j], dp, 0, 0, 0);
+        s = TB_MFMA_32x32x16(qfr, kf[j], s);
+        dp = TB_MFMA_32x32x16(dofr, vf[j], dp);
       }
       // transposed fragments of this 32-query half: issued behind the score products, they arrive under the exponentials
       f16x4 qtf[2][DT][2], dotf[2][DT][2];
@@ -1099,8 +1099,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const tb_attn_
             a[e] = dotf[jj][d][0][e], a[4 + e] = dotf[jj][d][1][e];
             c[e] = qtf[jj][d][0][e], c[4 + e] = qtf[jj][d][1][e];
           }
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c, dsf, dk[d], 0, 0, 0);
+          dv[d] = TB_MFMA_32x32x16(a, pf, dv[d]);
+          dk[d] = TB_MFMA_32x32x16(c, dsf, dk[d]);
         }
       }
     }
@@ -1291,8 +1291,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
       }
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Vs, kt * 32 + l31, 2 * j + hi), dof[j], dp, 0, 0, 0);
+        s = TB_MFMA_32x32x16(frag_rm<WD>(Ks, kt * 32 + l31, 2 * j + hi), qf[j], s);
+        dp = TB_MFMA_32x32x16(frag_rm<WD>(Vs, kt * 32 + l31, 2 * j + hi), dof[j], dp);
       }
       const bool need_mask = (kv0 + kt * 32 + 32 > p.Skv) || (p.causal && kv0 + kt * 32 + 31 > qblk + wave * 32) || (qblk + wave * 32 + 32 > p.Sq);
       if (need_mask) {
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
         const f16x8 dsf = pack8(s, 8 * jj);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Kt, d, l31, kt * 32 + 16 * jj, hi), dsf, dq[d], 0, 0, 0);
+          dq[d] = TB_MFMA_32x32x16(frag_tr(Kt, d, l31, kt * 32 + 16 * jj, hi), dsf, dq[d]);
       }
     }
   }
@@ -1425,8 +1425,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
       }
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(Qs, qt * 32 + l31, 2 * j + hi), kf[j], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_rm<WD>(dOs, qt * 32 + l31, 2 * j + hi), vf[j], dp, 0, 0, 0);
+        s = TB_MFMA_32x32x16(frag_rm<WD>(Qs, qt * 32 + l31, 2 * j + hi), kf[j], s);
+        dp = TB_MFMA_32x32x16(frag_rm<WD>(dOs, qt * 32 + l31, 2 * j + hi), vf[j], dp);
       }
       const bool need_mask = (q0 + qt * 32 + 32 > p.Sq) || (kblk + wave * 32 + 32 > p.Skv) || (p.causal && kblk + wave * 32 + 31 > q0 + qt * 32);
       if (need_mask) {
@@ -1452,8 +1452,8 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
         const f16x8 dsf = pack8(dp, 8 * jj);
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(dOt, d, l31, qt * 32 + 16 * jj, hi), pf, dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_tr(Qt, d, l31, qt * 32 + 16 * jj, hi), dsf, dk[d], 0, 0, 0);
+          dv[d] = TB_MFMA_32x32x16(frag_tr(dOt, d, l31, qt * 32 + 16 * jj, hi), pf, dv[d]);
+          dk[d] = TB_MFMA_32x32x16(frag_tr(Qt, d, l31, qt * 32 + 16 * jj, hi), dsf, dk[d]);
         }
       }
     }

@@ -211,14 +211,14 @@ template <int N>
 __device__ __forceinline__ void do_mfma(FwdGroup& g, const f16x8& a) {
   if constexpr (N < 8) {
     constexpr int kt = N >> 2, jj = (N >> 1) & 1, d = N & 1;
-    g.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g.pk[kt][jj], g.o[d], 0, 0, 0);
+    g.o[d] = TB_MFMA_32x32x16(a, g.pk[kt][jj], g.o[d]);
   } else {
     constexpr int j = (N - 8) >> 1, kt = (N - 8) & 1;
     if constexpr (j == 0) {
       const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      g.s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g.qf[0], z, 0, 0, 0);
+      g.s[kt] = TB_MFMA_32x32x16(a, g.qf[0], z);
     } else {
-      g.s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g.qf[j], g.s[kt], 0, 0, 0);
+      g.s[kt] = TB_MFMA_32x32x16(a, g.qf[j], g.s[kt]);
     }
   }
 }
@@ -491,12 +491,12 @@ __device__ __forceinline__ void dkv_mfma(DkvState& st, const f16x8& a, const f32
   constexpr int Q = PAR ^ 1;  // halves k-1 and k+1 have the other parity
   if constexpr (N < 8) {
     constexpr int jj = N >> 2, d = (N >> 1) & 1, which = N & 1;
-    if constexpr (which == 0) st.dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.pp[Q][jj], st.dv[d], 0, 0, 0);
-    else st.dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.ds[Q][jj], st.dk[d], 0, 0, 0);
+    if constexpr (which == 0) st.dv[d] = TB_MFMA_32x32x16(a, st.pp[Q][jj], st.dv[d]);
+    else st.dk[d] = TB_MFMA_32x32x16(a, st.ds[Q][jj], st.dk[d]);
   } else {
     constexpr int j = (N - 8) >> 1, which = (N - 8) & 1;
-    if constexpr (which == 0) st.s[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.kf[j], j == 0 ? s_init : st.s[Q], 0, 0, 0);
-    else st.dp[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.vf[j], j == 0 ? dp_init : st.dp[Q], 0, 0, 0);
+    if constexpr (which == 0) st.s[Q] = TB_MFMA_32x32x16(a, st.kf[j], j == 0 ? s_init : st.s[Q]);
+    else st.dp[Q] = TB_MFMA_32x32x16(a, st.vf[j], j == 0 ? dp_init : st.dp[Q]);
   }
 }
 template <int N, int LO, int HI, int PAR, bool SM>
@@ -742,11 +742,11 @@ __device__ __forceinline__ void dq_mfma(DqState& st, const f16x8& a) {
   constexpr int Q = PAR ^ 1;
   if constexpr (N < 4) {
     constexpr int jj = N >> 1, d = N & 1;
-    st.dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.ds[Q][jj], st.dq[d], 0, 0, 0);
+    st.dq[d] = TB_MFMA_32x32x16(a, st.ds[Q][jj], st.dq[d]);
   } else {
     constexpr int j = (N - 4) >> 1, which = (N - 4) & 1;
-    if constexpr (which == 0) st.s[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.qf[j], j == 0 ? st.neg_lse : st.s[Q], 0, 0, 0);
-    else st.dp[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, st.dof[j], j == 0 ? st.neg_delta : st.dp[Q], 0, 0, 0);
+    if constexpr (which == 0) st.s[Q] = TB_MFMA_32x32x16(a, st.qf[j], j == 0 ? st.neg_lse : st.s[Q]);
+    else st.dp[Q] = TB_MFMA_32x32x16(a, st.dof[j], j == 0 ? st.neg_delta : st.dp[Q]);
   }
 }
 template <int N, int LO, int HI, int PAR, bool SM>

@@ -33,7 +33,7 @@ __device__ __forceinline__ f32x16 tile_xyT(const f16* X, int ldx, int i0, const 
   for (int ks = 0; ks < K / 16; ++ks) {
     const f16x8 a = *(const f16x8*)(X + (i0 + l31) * ldx + ks * 16 + 8 * hi);
     const f16x8 b = *(const f16x8*)(Y + (j0 + l31) * ldy + ks * 16 + 8 * hi);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    acc = TB_MFMA_32x32x16(a, b, acc);
   }
   return acc;
 }

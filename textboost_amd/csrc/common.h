@@ -3,10 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The library's 16-bit float: IEEE half by default; -DTB_BF16 builds the SAME sources with bfloat16 operands (libtextboost_hip_bf16.so: the
+// reference's --mixed_precision bf16, train_textboost.py:298-308, :930-934 -- bf16 MFMA runs at the fp16 rate on gfx950, fp32 accumulation and
+// statistics are unchanged).  `f16` therefore reads "the half type of this build" everywhere below.
+#ifdef TB_BF16
+typedef __bf16 f16;
+#define TB_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define TB_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#else
 typedef _Float16 f16;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+#define TB_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define TB_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(2))) f16 f16x2;
+typedef __attribute__((ext_vector_type(4))) f16 f16x4;
+typedef __attribute__((ext_vector_type(8))) f16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

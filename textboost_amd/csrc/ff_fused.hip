@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc_a[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks % 3][a], xf[i][ks], acc_a[a][i], 0, 0, 0);
+          for (int i = 0; i < 2; ++i) acc_a[a][i] = TB_MFMA_16x16x32(wf[ks % 3][a], xf[i][ks], acc_a[a][i]);
         FF_SB();
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc_o[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj % 3][s], uf[s][i], acc_o[i][jj], 0, 0, 0);
+          for (int i = 0; i < 2; ++i) acc_o[i][jj] = TB_MFMA_16x16x32(wf[jj % 3][s], uf[s][i], acc_o[i][jj]);
         FF_SB();
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});

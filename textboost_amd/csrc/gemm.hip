@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)  // transposed accumulator: rows = n (from W), cols = m (from A)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = TB_MFMA_32x32x16(bf[j], af[i], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
     }
 #else
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)  // transposed accumulator: rows = n (from W), cols = m (from A)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = TB_MFMA_32x32x16(bf[kk][j], af[kk][i], acc[i][j]);
 #endif
   };
   if constexpr (NST == 2) {
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = TB_MFMA_32x32x16(bf[j], af[i], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)  // transposed: rows of D = output columns (from W), columns of D = output rows (from A)
-              if (!(G8_ABL & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+              if (!(G8_ABL & 1)) acc[i][j] = TB_MFMA_16x16x32(bf[s][j], af[s][i], acc[i][j]);
               else asm volatile("" ::"v"(bf[s][j]), "v"(af[s][i]));
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* __restrict__ out,
     }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k & 1], b[(k >> 1) & 1], acc[k & 7], 0, 0, 0);
+    for (int k = 0; k < 16; ++k) acc[k & 7] = TB_MFMA_32x32x16(a[k & 1], b[(k >> 1) & 1], acc[k & 7]);
   }
   float s = 0.f;
   for (int k = 0; k < 8; ++k)

@@ -160,10 +160,10 @@ __device__ __forceinline__ void lora_panel_dot(const f16* __restrict__ Lm, int64
       const bool ok = m < M;
       lv[u] = ok ? *(const f16x8*)(Lm + m * ldl + c0 + g * 8) : z8;
       if (r == RR && ((lds_ | s0) % RR) == 0) {  // one aligned vector per row (r = 4: 8 bytes, r = 8: 16 bytes)
-        typedef __attribute__((ext_vector_type(RR))) _Float16 hvec;
+        typedef __attribute__((ext_vector_type(RR))) f16 hvec;
         hvec h;
 #pragma unroll
-        for (int j = 0; j < RR; ++j) h[j] = (_Float16)0.f;
+        for (int j = 0; j < RR; ++j) h[j] = (f16)0.f;
         if (ok) h = *(const hvec*)(Sm + m * lds_ + s0);
 #pragma unroll
         for (int j = 0; j < RR; ++j) sv[u][j] = (float)h[j];

@@ -10,7 +10,10 @@ from . import _lib as L
 
 
 def _dt(t):
-    return L.TB_F32 if t.dtype == torch.float32 else L.TB_F16
+    if t.dtype == torch.float32:
+        return L.TB_F32
+    assert t.dtype == L.half_dtype(), f"{t.dtype} operand but the active library computes in {L.half_kind()} (textboost_amd._lib.set_half)"
+    return L.TB_F16
 
 
 # ---- optional per-launch timing (bench.py roofline leg): HIP events on torch's current stream, which is the stream every
@@ -86,9 +89,9 @@ def _gemm_sync_counters(dev):
     return t
 
 
-def subpixel_ok(B, Hc, Wc, Cin, N, dtype=torch.float16):
+def subpixel_ok(B, Hc, Wc, Cin, N, dtype=None):
     """can nearest-x2 + conv3x3 over a coarse [B, Hc, Wc, Cin] map run as four 2x2-tap sub-pixel convolutions (`gemm(..., conv=dict(upsample=2 | 3))`)?"""
-    return dtype == torch.float16 and bool(L.lib().tb_gemm_subpixel_ok(B, Hc, Wc, Cin, N))
+    return dtype in (None, L.half_dtype()) and bool(L.lib().tb_gemm_subpixel_ok(B, Hc, Wc, Cin, N))
 
 
 def pack_subpixel_weights(w):
@@ -109,12 +112,13 @@ def pack_subpixel_weights(w):
                     ws = sum(w32[:, :, ky, kx] for ky in KY[py][a] for kx in KY[px][c])   # [Co, Ci]
                     fwd[2 * py + px, :, 2 * a + c, :] = ws
                     dg[:, 2 * py + px, 2 * (1 - a) + (1 - c), :] = ws.t()
-    return fwd.reshape(4 * Co, 4 * Ci).half().contiguous(), dg.reshape(Ci, 16 * Co).half().contiguous()
+    hd = L.half_dtype()
+    return fwd.reshape(4 * Co, 4 * Ci).to(hd).contiguous(), dg.reshape(Ci, 16 * Co).to(hd).contiguous()
 
 
-def gemm_ln_ok(M, N, K, dtype=torch.float16):
+def gemm_ln_ok(M, N, K, dtype=None):
     """can a fp16 Linear of this shape carry a fused LayerNorm epilogue (`gemm(..., ln_fwd=... / ln_bwd=...)`)?"""
-    return dtype == torch.float16 and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
+    return dtype in (None, L.half_dtype()) and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
 
 
 class SplitKPartials:
@@ -242,9 +246,9 @@ def groupnorm_ws(B, HW, C, G=32):
     return int(L.lib().tb_groupnorm_ws_floats(B, HW, C, G))
 
 
-def groupnorm_splitk_ok(B, HW, C, G=32, dtype=torch.float16):
+def groupnorm_splitk_ok(B, HW, C, G=32, dtype=None):
     """can GroupNorm over [B*HW, C] take its input straight from split-K partials (`groupnorm_fwd/bwd(..., partials=)`)?"""
-    return DEFER_SPLITK and dtype == torch.float16 and bool(L.lib().tb_groupnorm_splitk_ok(B, HW, C, G))
+    return DEFER_SPLITK and dtype in (None, L.half_dtype()) and bool(L.lib().tb_groupnorm_splitk_ok(B, HW, C, G))
 
 
 def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, G=32, eps=1e-5, silu=False, partials=None):
@@ -482,9 +486,9 @@ def kpl_mse(h, h0, dh, partial, loss_out, loss_scale, weight):
                                L.ptr(partial), L.ptr(loss_out), L.ptr(loss_scale), weight, M, D, L.stream()), "tb_kpl_mse")
 
 
-def ff_fused_ok(M, C, inner, dtype=torch.float16):
+def ff_fused_ok(M, C, inner, dtype=None):
     """can the GEGLU feed-forward of this shape run as the fused launches `ff_fwd` / `ff_bwd` (csrc/ff_fused.hip: C = 320, 128-row tiles)?"""
-    return dtype == torch.float16 and bool(L.lib().tb_ff_fused_ok(M, C, inner))
+    return dtype in (None, L.half_dtype()) and bool(L.lib().tb_ff_fused_ok(M, C, inner))
 
 
 def _ff_desc(x, w1, w2, hg, y, R, b1=None, b2=None):
@@ -527,7 +531,7 @@ def ff_bwd(dy, w2d, w1d, hg, dx, R=None):
 
 def geglu_bwd(dout, raw, dproj):
     M, inner = dout.shape
-    assert dout.dtype == torch.float16, "fp32 mode runs the GEGLU backward in the ff.net.2 dgrad epilogue (TB_ACT_GEGLU_GRAD)"
+    assert dout.dtype != torch.float32, "fp32 mode runs the GEGLU backward in the ff.net.2 dgrad epilogue (TB_ACT_GEGLU_GRAD)"
     L.check(L.lib().tb_geglu_bwd(L.ptr(dout), dout.stride(0), L.ptr(raw), raw.stride(0), L.ptr(dproj), dproj.stride(0), M, inner,
                                  L.stream()), "tb_geglu_bwd")
 

@@ -17,6 +17,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import ops
+from . import _lib as L
 
 
 class DPMSolverPP2M:
@@ -167,7 +168,7 @@ class HipSampler:
         B, h, w = self.B, unet.H, unet.W
         self.x = torch.zeros(B, 4, h, w, device=dev)
         self.m_prev = torch.zeros(B, 4, h, w, device=dev)
-        self.x2 = torch.zeros(2 * B, 4, h, w, device=dev, dtype=torch.float16)
+        self.x2 = torch.zeros(2 * B, 4, h, w, device=dev, dtype=L.half_dtype())
         self.t_dev = [torch.full((2 * B,), t, dtype=torch.int64, device=dev) for t in self.timesteps]
         self.generator: Optional[torch.Generator] = None
 
@@ -181,7 +182,7 @@ class HipSampler:
         self.m_prev.zero_()
         self.x2[:B].copy_(self.x)
         self.x2[B:].copy_(self.x)
-        ehs = torch.cat([uncond_ehs, cond_ehs]).to(torch.float16).contiguous()
+        ehs = torch.cat([uncond_ehs, cond_ehs]).to(L.half_dtype()).contiguous()
         n = self.x[0].numel()
         for i in range(self.steps):
             eps2 = self.unet.forward(self.x2, self.t_dev[i], ehs)

@@ -54,8 +54,8 @@ class HipTextEncoder:
         self.geo, self.B, self.T, self.mode, self.dev = geo, batch, geo.max_pos, mode, device
         self.r = lora_rank
         self.scaling = (lora_alpha if lora_alpha is not None else lora_rank) / lora_rank if lora_rank else 0.0
-        self.res_dtype = torch.float32 if mode in ("autocast", "fp32") else torch.float16
-        self.op_dtype = torch.float32 if mode == "fp32" else torch.float16   # Linear / attention operands and activations
+        self.res_dtype = torch.float32 if mode in ("autocast", "fp32") else L.half_dtype()
+        self.op_dtype = torch.float32 if mode == "fp32" else L.half_dtype()   # Linear / attention operands and activations
         self.n_slots = n_slots
         self._bufs: Dict[str, torch.Tensor] = {}
         D, Lr = geo.hidden_size, geo.num_layers
@@ -64,7 +64,7 @@ class HipTextEncoder:
         odt = self.op_dtype
         f16 = lambda t: t.detach().to(odt).to(device).contiguous()
         f32r = lambda t: t.detach().to(odt).to(torch.float32).to(device).contiguous()  # rounded like the operands (not at all in fp32 mode), fp32 storage
-        tbl_dt = torch.float32 if mode in ("autocast", "fp32") else torch.float16
+        tbl_dt = torch.float32 if mode in ("autocast", "fp32") else L.half_dtype()
         self.token_table = sd[pre + "embeddings.token_embedding.weight"].detach().to(tbl_dt).to(device).contiguous()
         self.pos_table = sd[pre + "embeddings.position_embedding.weight"].detach().to(tbl_dt).to(device).contiguous()
         # LayerNorm affine: fp32 params under autocast (LN runs in fp32); fp16-rounded for the half module

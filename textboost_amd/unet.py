@@ -59,17 +59,17 @@ class UNetGeometry:
         return self.num_heads if isinstance(self.num_heads, int) else self.num_heads[level]
 
 
-def _f16(t, dtype=torch.float16):
-    return t.detach().to(dtype)
+def _f16(t, dtype=None):
+    return t.detach().to(L.half_dtype() if dtype is None else dtype)
 
 
-def _f32_via_f16(t, dev, dtype=torch.float16):
+def _f32_via_f16(t, dev, dtype=None):
     """unet.to(fp16) (:937) rounds every parameter to fp16; biases / norm affines are consumed as fp32 here.  In the fp32 (no-AMP) mode
     (`dtype` = float32: weight_dtype stays float32, :930-939) nothing is rounded."""
-    return t.detach().to(dtype).to(torch.float32).to(dev).contiguous()
+    return t.detach().to(L.half_dtype() if dtype is None else dtype).to(torch.float32).to(dev).contiguous()
 
 
-def pack_conv3x3(w, dev, dtype=torch.float16):
+def pack_conv3x3(w, dev, dtype=None):
     """[Co,Ci,3,3] -> fwd [Co, 9*Ci] (k = (ky*3+kx)*Ci + ci) and dgrad [Ci, 9*Co] (k = (ky*3+kx)*Co + co), fp16 (fp32 in the no-AMP mode)."""
     w = _f16(w, dtype).to(dev)
     fwd = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
@@ -77,7 +77,7 @@ def pack_conv3x3(w, dev, dtype=torch.float16):
     return fwd, dg
 
 
-def pack_linear(w, dev, dtype=torch.float16):
+def pack_linear(w, dev, dtype=None):
     w = _f16(w, dtype).to(dev)
     if w.dim() == 4:  # 1x1 conv
         w = w.reshape(w.shape[0], w.shape[1])
@@ -98,13 +98,14 @@ class HipUNet:
     mode) sample / ehs / pred are fp32 as well."""
 
     def __init__(self, geo: UNetGeometry, state_dict: Dict[str, torch.Tensor], batch: int, height: int, width: int,
-                 text_len: int = 77, device="cuda", attn_fp8: bool = False, dtype=torch.float16):
+                 text_len: int = 77, device="cuda", attn_fp8: bool = False, dtype=None):
         """dtype = torch.float16: the reference's --mixed_precision fp16 run (`unet.to(accelerator.device, dtype=weight_dtype)`, :937);
         torch.float32: its default no-AMP run (:298-308, :930-939) -- every weight, activation and gradient fp32 (csrc/f32_path.hip)."""
-        assert dtype in (torch.float16, torch.float32)
+        dtype = L.half_dtype() if dtype is None else dtype   # (the active library's 16-bit float: fp16, or bf16 after _lib.set_half("bf16"))
+        assert dtype in (L.half_dtype(), torch.float32)
         self.geo, self.B, self.H, self.W, self.T, self.dev = geo, batch, height, width, text_len, device
         self.dtype = dtype
-        assert not (attn_fp8 and dtype != torch.float16)
+        assert not (attn_fp8 and dtype != torch.float16)   # (the e4m3 P.V forward exists for the fp16 build only)
         # BASELINE.json configs[4]: e4m3 P.V in the forward of the hd = 40 self-attention layers (opt-in; fp16 everywhere else and in the backward)
         self.attn_fp8 = attn_fp8
         self._fp8_ws = None
@@ -250,7 +251,7 @@ class HipUNet:
             if i < len(ch) - 1:
                 conv(f"up_blocks.{i}.upsamplers.0.conv")
                 name = f"up_blocks.{i}.upsamplers.0.conv"
-                if wdt == torch.float16 and ops.subpixel_ok(self.B, self.H >> level, self.W >> level, c, c, wdt):
+                if wdt != torch.float32 and ops.subpixel_ok(self.B, self.H >> level, self.W >> level, c, c, wdt):
                     P[name + ".wsub"], P[name + ".wdsub"] = ops.pack_subpixel_weights(sd[name + ".weight"].to(dev).to(wdt))
             prev = c
         # hoisted projections
@@ -444,7 +445,7 @@ class HipUNet:
             dq2 = self.scratch("g2", M, C)
             delta = self.scratch("delta", B * heads, HW, torch.float32)
             dk2, dv2 = self.dkv_all[:, ko:ko + C], self.dkv_all[:, ko + C:ko + 2 * C]
-            xws = self.scratch("xattn_ws", 16 * 2 * B * T, C, torch.float32) if self.dtype == torch.float16 else None
+            xws = self.scratch("xattn_ws", 16 * 2 * B * T, C, torch.float32) if self.dtype != torch.float32 else None
             ops.attention_bwd(q2, k2, v2, o2, lse2, do2, delta, dq2, dk2, dv2, B, heads, HW, T, hd, ws=xws)
             if stop_after_cross:
                 return
@@ -460,7 +461,7 @@ class HipUNet:
             dqkv = self.scratch("gq", M, 3 * C)
             # ws: 2 x [B, heads, HW] floats -- lets the hd = 40 / 64x64-map layers take the LDS-DMA staged dK/dV kernel (the dQ kernel
             # publishes -lse log2 e and -delta there for it); other shapes ignore it
-            sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 64, 80) and HW % 128 == 0 and self.dtype == torch.float16 else None
+            sws = self.scratch("sattn_ws", 2 * B * heads, HW, torch.float32) if hd in (40, 64, 80) and HW % 128 == 0 and self.dtype != torch.float32 else None
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, lse1, do1, delta, dqkv[:, :C], dqkv[:, C:2 * C],
                               dqkv[:, 2 * C:], B, heads, HW, HW, hd, ws=sws)
             dt0 = self.scratch("g3", M, C)

@@ -146,7 +146,8 @@ class HipVAEEncoder:
         P["moments.b"] = bfold.to(dev).contiguous()
 
     # ------------------------------------------------------------------ buffers
-    def buf(self, name, rows, cols, dtype=torch.float16):
+    def buf(self, name, rows, cols, dtype=None):
+        dtype = L.half_dtype() if dtype is None else dtype
         t = self._bufs.get(name)
         if t is None or t.shape != (rows, cols) or t.dtype != dtype:
             t = torch.empty(rows, cols, device=self.dev, dtype=dtype)

@@ -38,13 +38,18 @@ def build_step(batch=8, latent=64, unet_geo: UNetGeometry = models.SD15_UNET, cl
     """Config 2 of BASELINE.json by default: SD1.5 UNet + CLIP-L, per-GPU batch 8, 512^2 (64^2 latents), LoRA r=4, KPL on,
     18 added token vectors (2 placeholder + 16 augmentation vectors).
     precision: "fp16" = the reference driver's --mixed_precision fp16 (run_textboost_db.py:150); "fp32" = its default no-AMP mode
-    (train_textboost.py:298-308, the README command): fp32 everywhere, no GradScaler."""
-    assert precision in ("fp16", "fp32")
+    (train_textboost.py:298-308, the README command): fp32 everywhere, no GradScaler; "bf16" = --mixed_precision bf16 (:930-934: bf16 UNet /
+    teacher, bf16 autocast operands in the trainable encoder, no GradScaler -- accelerate creates one for fp16 only): the process switches to the
+    bfloat16 build of the library (`_lib.set_half("bf16")`)."""
+    assert precision in ("fp16", "fp32", "bf16")
+    from . import _lib
+    if precision != "fp32":
+        _lib.set_half(precision)
     f32 = precision == "fp32"
-    hyper = hyper or (StepHyper(use_grad_scaler=False, init_scale=1.0) if f32 else StepHyper())
+    hyper = hyper or (StepHyper(use_grad_scaler=False, init_scale=1.0) if precision != "fp16" else StepHyper())
     usd = models.random_state_dict(models.unet_shapes(unet_geo), weight_seed, device=device)
     unet = HipUNet(unet_geo, usd, batch, latent, latent, text_len=clip_geo.max_pos, device=device, attn_fp8=attn_fp8,
-                   dtype=torch.float32 if f32 else torch.float16)
+                   dtype=torch.float32 if f32 else _lib.half_dtype())
     del usd
     csd = models.random_state_dict(models.clip_shapes(clip_geo), weight_seed + 1, device=device)
     teacher = HipTextEncoder(clip_geo, csd, batch, mode="fp32" if f32 else "half", device=device)

@@ -144,7 +144,10 @@ def main(args):
     # unset / "no" = the default: weight_dtype float32, everything in fp32, no GradScaler (accelerate launch would otherwise take the mode from its
     # own config file; there is none here, so the flag alone decides)
     fp32_mode = args.mixed_precision in (None, "no")
-    adt = torch.float32 if fp32_mode else torch.float16
+    bf16_mode = args.mixed_precision == "bf16"   # (:930-934) weight_dtype = bf16; accelerate's GradScaler exists for fp16 only
+    from textboost_amd import _lib as _L
+    _L.set_half("bf16" if bf16_mode else "fp16")   # which build of the kernel library this process computes with
+    adt = torch.float32 if fp32_mode else _L.half_dtype()
     unet = HipUNet(unet_geo, usd, B, latent, latent, text_len=clip_geo.max_pos, device=dev, dtype=adt)
     # ---- validation sampling (:453-531, :1212-1228): prompts must arrive tokenised (no tokenizer offline)
     val_ids_path = os.path.join(args.instance_data_dir or "", "validation_input_ids.pt")
@@ -234,7 +237,7 @@ def main(args):
         pred_type = json.load(open(sched_cfg)).get("prediction_type", "epsilon")
         if pred_type not in ("epsilon", "v_prediction"):
             raise ValueError(f"Unknown prediction type {pred_type}")  # :1075
-    hp = StepHyper(prediction_type=pred_type, use_grad_scaler=not fp32_mode, init_scale=1.0 if fp32_mode else 65536.0,
+    hp = StepHyper(prediction_type=pred_type, use_grad_scaler=not (fp32_mode or bf16_mode), init_scale=1.0 if (fp32_mode or bf16_mode) else 65536.0,
                    grad_accum=args.gradient_accumulation_steps,
                    lr=args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1), emb_lr=args.emb_learning_rate,
                    beta1=args.adam_beta1, beta2=args.adam_beta2, wd=args.adam_weight_decay, eps=args.adam_epsilon,
@@ -255,9 +258,6 @@ def main(args):
         unet.enable_kv_lora(args.lora_rank, seed=None if args.seed is None else args.seed + 1)
         logger.info("Added LoRA to U-Net")  # :721
     # options that change the step's arithmetic and are not built fail loudly instead of silently training something else
-    if args.mixed_precision == "bf16":
-        raise NotImplementedError("--mixed_precision bf16 is not built: fp16 (the reference driver's setting, run_textboost_db.py:150) and the "
-                                  "default no-AMP fp32 mode (:298-308, the README command) are")
     if args.text_encoder_use_attention_mask:
         raise NotImplementedError("--text_encoder_use_attention_mask has no runnable reference behaviour: the collate function hands "
                                   "encode_prompt a Python LIST of masks (textboost/dataset.py:427-454) and `attention_mask.to(device)` "
@@ -368,7 +368,7 @@ def main(args):
                 prior_feeder.stream.take(consumed)
     if is_main:
         logger.info("mean_norm %.6f | added tokens %s | world %d | per-GPU batch %d | precision %s", step.mean_norm, list(added_tokens) +
-                    list(aug_token_dict), world, B, "fp32 (no mixed precision, no GradScaler)" if fp32_mode else "fp16 mixed precision")
+                    list(aug_token_dict), world, B, "fp32 (no mixed precision, no GradScaler)" if fp32_mode else ("bf16 mixed precision (no GradScaler)" if bf16_mode else "fp16 mixed precision"))
         print("Mean norm:", step.mean_norm)
 
     def run_validation(done):
