@@ -952,6 +952,7 @@ int g_force_tile = 0;        // profiling: 1 = 64x64, 2 = 128x64, 3 = 128x128 fo
 int g_split_min_tiles = 8;   // k-tiles per slice lower bound (tb_gemm_set_variant(4000 + n))
 int g_split_blocks = 256;    // split only when the un-split grid has fewer blocks than this (5000 + n)
 int g_split_minnk = 32;      // ... and at least this many k-tiles (6000 + n)
+int g_nosplit64 = 1;         // see dispatch_tile (tb_gemm_set_variant(9600 + {0,1}))
 int g_split_target = 384;  // split K until about this many blocks exist (A/B: 256 22.7, 384 23.05, 512 22.6, 768 22.6, off 20.2 steps/s)  (tb_gemm_set_variant(1000 + n))
 
 template <int BN>
@@ -1047,6 +1048,14 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
     const int64_t fit = d.ws_bytes / (int64_t)(d.M * npad * sizeof(float));
     if (want > fit) want = fit;
     if (want > 1) S = (int)want;
+    // Long-K Linear layers whose un-split 64x64 grid is most of one chip round (224..512 blocks: the text encoder's N = 768 projections at
+    // M = 1232 / 1848, K = 2368 / 3072) run faster on the 4-stage 64x64 ring than as 128x128 split-K slices plus the reducer launch
+    // (scratch/te_gemm_ab.py, cold weights: 1848x768x3072 29.2 -> 24.6 us, 1232x768x3072 25.2 -> 20.9, 1232x768x2368 23.2 -> 17.4; smaller grids --
+    // 512x1280x5120: 160 blocks -- and larger ones -- 2048x1280x5120: 640 blocks, 2 stages -- keep the split: 27.3 vs 30.9, 47.0 vs 67.5 us)
+    if (MODE == TB_A_LINEAR && S > 1 && g_nosplit64) {
+      const int64_t b64 = ((d.M + 63) / 64) * ((d.N + 63) / 64);
+      if (b64 >= 224 && b64 <= 512) return launch<64, 64, MODE>(d, s);
+    }
   }
 #ifndef TB_SMALL_TILE_BLOCKS
 #define TB_SMALL_TILE_BLOCKS 320  // A/B on one MI355X: 96 -1.6 %, 192 base, 320 +1.0 %, 512 -1.0 % steps/s
@@ -1066,6 +1075,7 @@ extern "C" void tb_gemm_last_config(int* out5) {
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
   if (v >= 9900) g_phase = v - 9900;
+  else if (v >= 9600 && v < 9700) g_nosplit64 = v - 9600;
   else if (v >= 9800) g_inkernel_reduce = v - 9800;
   else if (v >= 9000) g_conv_narrow = v - 9000;
   else if (v >= 8000) g_force_tile = v - 8000;

@@ -155,6 +155,12 @@ def main(args):
     if args.validation_prompts and tokenizer is not None:
         val_ids = torch.zeros(len(args.validation_prompts), clip_geo.max_pos, dtype=torch.int64)  # filled once the tokens are registered
     sampler = None
+    if args.validation_prompts and args.unet_params_to_train == "crossattn_kv":
+        # log_validation (:453-531) samples with the TRAINED unet (accelerator.unwrap_model(unet), fp32 in this mode); the sampler here is a
+        # separate fp16 UNet built from the base weights, so its images would silently miss the K/V adapters being trained
+        raise NotImplementedError("--validation_prompts together with --unet_params_to_train crossattn_kv: the validation sampler is an fp16 "
+                                  "UNet without the cross-attention K/V adapters; drop --validation_prompts (the adapters are saved to "
+                                  "<output_dir>/unet/ and in every checkpoint)")
     if args.validation_prompts and val_ids is None:
         logger.warning("--validation_prompts given but neither a tokenizer nor %s exists: validation is skipped", val_ids_path)
     if val_ids is not None and is_main:
@@ -169,12 +175,6 @@ def main(args):
         # DDIM instance's value) and steps_offset are inherited from the model's own scheduler
         scfg_path = os.path.join(mdir, "scheduler", "scheduler_config.json")
         scfg = json.load(open(scfg_path)) if os.path.exists(scfg_path) else None
-        if args.unet_params_to_train == "crossattn_kv":
-            # log_validation (:453-531) samples with the TRAINED unet (accelerator.unwrap_model(unet), fp32 in this mode); the sampler here is a
-            # separate fp16 UNet built from the base weights, so its images would silently miss the K/V adapters being trained
-            raise NotImplementedError("--validation_prompts together with --unet_params_to_train crossattn_kv: the validation sampler is an fp16 "
-                                      "UNet without the cross-attention K/V adapters; drop --validation_prompts (the adapters are saved to "
-                                      "<output_dir>/unet/ and in every checkpoint)")
         sampler = HipSampler(HipUNet(unet_geo, usd, 2 * nv, latent, latent, text_len=clip_geo.max_pos, device=dev),  # (validation images: fp16 pipeline in both modes)
                              HipVAEDecoder(VAEGeometry(), dsd, nv, latent, latent, device=dev), steps=25, guidance=7.5,
                              scheduler_config=scfg, scheduler=args.validation_scheduler)
