@@ -252,6 +252,37 @@ def test_geglu_forward_and_backward_epilogues_on_the_wide_tile_kernel(M, C):
         assert rel_err(unpack(dproj.float()), pr.grad) < 3e-3
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(8, 128, 256, 64, 64), (2, 128, 128, 256, 256), (1, 256, 512, 128, 512), (8, 512, 512, 32, 64)])
+def test_conv3x3_wide_tile_128_channels(B, Cin, Cout, H, W):
+    """the 256-pixel x 128-channel tile of gemm8_kernel (round 4: the VAE's channel counts, which the 80-wide wave tiles do not divide), forward
+    with bias + residual and dgrad, against F.conv2d and against the 4-wave LDS-halo kernel."""
+    ops, L = _ops()
+    torch.manual_seed(12)
+    x = torch.randn(B, Cin, H, W, device="cuda").half()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    res = torch.randn(B * H * W, Cout, device="cuda").half()
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cin, Hout=H, Wout=W, stride=1, sign=1, upsample=0, transposed=0)
+    default_bits = L.lib().tb_gemm8_set(39)
+    outs = []
+    for bits in (default_bits, default_bits | 1024):
+        L.lib().tb_gemm8_set(bits)
+        out = torch.empty(B * H * W, Cout, device="cuda", dtype=torch.float16)
+        ops.gemm(nhwc(x).view(B * H * W, Cin), pack_conv_w(w), out, bias=bias, R=res, conv=geo)
+        assert bool(L.lib().tb_gemm8_last(None)) == (bits == default_bits)
+        outs.append(out)
+    L.lib().tb_gemm8_set(default_bits)
+    ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * W, Cout) + res.float()
+    parity("wide-tile conv, 128-channel tiles", outs[0], ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+    assert rel_err(outs[0], outs[1]) < 1e-3
+    dy = torch.randn(B, Cout, H, W, device="cuda").half()
+    dx = torch.empty(B * H * W, Cin, device="cuda", dtype=torch.float16)
+    geo = dict(B=B, Hin=H, Win=W, Cin=Cout, Hout=H, Wout=W, stride=1, sign=-1, upsample=0, transposed=0)
+    ops.gemm(nhwc(dy).view(B * H * W, Cout), pack_conv_w_dgrad(w), dx, conv=geo)
+    parity("wide-tile conv dgrad, 128-channel tiles", dx, nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1)).view(B * H * W, Cin),
+           rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H", [(8, 640, 640, 16), (8, 1280, 1280, 16), (8, 2560, 1280, 16), (4, 1280, 640, 32)])
 def test_conv3x3_wide_tile_split_k(B, Cin, Cout, H):
     """16x16 / small-batch maps give too few 256 x 160 tiles for the chip: gemm8_kernel splits the channel chunks over S workgroups per tile

@@ -1150,6 +1150,9 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     if (256 % TW == 0 && d.Hout % (256 / TW) == 0 && d.M % 256 == 0) {
       if (d.N % 160 == 0 && (d.M / 256) * (d.N / 160) >= 200) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift);
       if (d.N % 80 == 0 && (d.M / 256) * (d.N / 80) >= 200) return launch8<8, 1, 2, 5, true, 3>(d, s, wshift);
+      // 256 pixels x 128 channels (wave tiles 64 x 64): the VAE's 128 / 256 / 512-channel convolutions (AutoencoderKL encoder / decoder,
+      // train_textboost.py:1036-1037 and log_validation), which the 80-wide wave tiles do not divide
+      if (d.N % 128 == 0 && (d.M / 256) * (d.N / 128) >= 200 && !(g8_enable & 1024)) return launch8<4, 2, 4, 4, true, 3>(d, s, wshift);
       // too few tiles for the chip (16x16 maps: 8 x 8 tiles of 256 x 160): split the channel chunks over S workgroups per tile
       if (d.N % 160 == 0 && (g8_enable & 32)) {
         const int tiles = (int)((d.M / 256) * (d.N / 160)), kpt = d.Cin / 64;
@@ -1175,6 +1178,8 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   if (d.N % 320) return 1;
   if (ln_act && (d.M / 128) * (d.N / 320) >= 200 && d.M % 128 == 0) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
-  if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);
+  // (not the 16x16-map qkv projection, M = 2048 x N = 3840 x K = 1280: 384 of these 64x320 tiles take 51.9 us cold against 41.3 us for one round of
+  // 128x128 four-wave tiles -- scratch/shape_sweep.py; the 32x32-map N = 640 layers at M = 8192 are what this tile is for)
+  if (d.M % 64 == 0 && (d.M / 64) * (d.N / 320) >= 200 && (d.M >= 4096 || d.N <= 1280)) return launch8<2, 4, 2, 5, false, 3>(d, s, 30);
   return 1;
 }
