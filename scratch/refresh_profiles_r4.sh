@@ -25,7 +25,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$R/gpurun_out/r04/pmc_sq/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"]).split("(")[0][:70]
-        if any(x in k for x in ("gemm", "conv_halo", "attn_")):
+        if any(x in k for x in ("gemm", "conv_halo", "attn_", "ff_fused")):
             grid = r.get("Grid_Size", "")
             if k.startswith("attn_") and "_il_" in k: k = k + " grid=" + grid   # the L0 self-attention launches have their own symbols
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

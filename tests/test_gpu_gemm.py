@@ -591,3 +591,33 @@ def test_upsampler_convolution_as_sub_pixel_convolutions(B, C, Hc):
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(2 * 8 * 8, 64, device="cuda", dtype=torch.float16), torch.zeros(256, 256, device="cuda", dtype=torch.float16), bad,
                  conv=dict(B=2, Hin=8, Win=8, Cin=64, Hout=16, Wout=16, stride=1, sign=1, upsample=2, transposed=0))
+
+
+@pytest.mark.parametrize("M,N,bias,res", [(32768, 320, True, True), (32768, 960, False, False), (25600, 1280, True, False), (32768, 128, False, True)])
+def test_linear_k320_activation_stationary_kernel(M, N, bias, res):
+    """csrc/lin320.hip (round 4): the K = 320 Linear layers of the 64x64 maps with the 128-row activation tile register-resident, against torch
+    and against the wide-tile kernel it replaces (knob 9400); strided output / residual views."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(13)
+    K = 320
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda") if bias else None
+    Rbuf = torch.randn(M, N + 8, device="cuda").half() if res else None
+    R = Rbuf[:, 4:4 + N] if res else None
+    outs = []
+    for knob in (9401, 9400):
+        L.lib().tb_gemm_set_variant(knob)
+        Cbuf = torch.full((M, N + 16), 3.0, device="cuda", dtype=torch.float16)
+        out = Cbuf[:, 8:8 + N]
+        ops.gemm(A, W, out, bias=b, R=R)
+        cfg = (ctypes.c_int * 5)()
+        L.lib().tb_gemm_last_config(cfg)
+        assert (cfg[3] == 643) == (knob == 9401), list(cfg)      # {128, 64, 3, 643, 1} names the lin320 launch
+        assert (Cbuf[:, :8] == 3).all() and (Cbuf[:, 8 + N:] == 3).all()
+        outs.append(out)
+    L.lib().tb_gemm_set_variant(9401)
+    ref = A.float() @ W.float().T + (b if bias else 0) + (R.float() if res else 0)
+    parity("K = 320 activation-stationary Linear", outs[0], ref, rel=1e-3, maxabs=2e-3, ch_dim=1, ch_rel=2e-3)
+    assert torch.equal(outs[0], outs[1]) or rel_err(outs[0], outs[1]) < 3e-4

@@ -21,6 +21,10 @@
 
 #include "gemm_epi.h"
 
+int tb_lin320_try(const tb_gemm_desc& d, hipStream_t s);  // lin320.hip: activation-stationary tiles for the K = 320 layers of the 64x64 maps; 1 = not covered
+void tb_lin320_set(int on);
+void tb_gemm8_clear_last();
+
 namespace {
 
 // split-K second pass: C = epilogue(sum_s ws[s][m][n]); ws is fp32 [S][M][Npad] with Npad = N rounded up to 8
@@ -1075,6 +1079,7 @@ extern "C" void tb_gemm_last_config(int* out5) {
 extern "C" int tb_gemm_set_variant(int v) {
   const int old = g_variant;
   if (v >= 9900) g_phase = v - 9900;
+  else if (v >= 9400 && v < 9500) tb_lin320_set(v - 9400);
   else if (v >= 9600 && v < 9700) g_nosplit64 = v - 9600;
   else if (v >= 9800) g_inkernel_reduce = v - 9800;
   else if (v >= 9000) g_conv_narrow = v - 9000;
@@ -1139,6 +1144,14 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
   if (d.a_mode == TB_A_CONV3X3 && d.transposed) {
     // phase mode of the transposed gather (gemm_kernel): even maps whose quarter is a whole number of 128-row tiles, no per-row-group bias
     d.transposed = (g_phase && !(d.Hout & 1) && !(d.Wout & 1) && (d.M % 512) == 0 && !d.rowbias && d.Hin * 2 >= d.Hout && d.Win * 2 >= d.Wout) ? 2 : 1;
+  }
+  {
+    const int r3 = tb_lin320_try(d, s);
+    if (r3 != 1) {
+      tb_gemm8_clear_last();
+      g_last_cfg[0] = 128, g_last_cfg[1] = 64, g_last_cfg[2] = 3, g_last_cfg[3] = 643, g_last_cfg[4] = 1;   // (mode 3 = lin320_kernel)
+      return r3;
+    }
   }
   {
     int split8 = 1;

@@ -1056,6 +1056,8 @@ inline int halo_wshift8(int W) {  // tile width: the largest power of two (16..6
 
 }  // namespace
 
+void tb_gemm8_clear_last() { g8_last[0] = 0; }   // (tb_gemm took another kernel family for this launch)
+
 extern "C" int tb_gemm8_set(int v) {
   const int old = g8_enable;
   g8_enable = v;

@@ -220,6 +220,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
                 r.name = f"gemm8_kernel<{c8[0]}, {c8[1]}, {c8[2]}, {c8[3]}, {'true' if c8[4] else 'false'}, {c8[5]}>"
             elif cfg[2] == 2:
                 r.name = f"conv_halo_kernel<{cfg[1]}>"
+            elif cfg[2] == 3:
+                r.name = f"lin320_kernel<{'true' if R is not None else 'false'}>"
             else:
                 r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
     if split is not None and split.value > 1:
