@@ -311,6 +311,14 @@ int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P);
 int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
                 void* dt, int64_t lddt, float* dA /* += */, float* dB /* += */, float* ws, int64_t M, int D, int K, int r, int P,
                 float scaling, tb_stream_t stream);
+/* the same backward as one link of a chain over adapter sets of equal shape (CLIP's layers, last to first; accelerator.backward,
+   train_textboost.py:1108): this set's dt / dB launch also carries the dA panels of the PENDING set (the previous link's x / dt / dA; all
+   three null = none; pend_dt must not be this link's dt), da_now != 0 launches this set's own dA panels behind it (the last link).
+   Per-set arithmetic and summation order are tb_lora_bwd's. */
+int tb_lora_bwd_chain(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
+                      void* dt, int64_t lddt, float* dA /* += */, float* dB /* += */, int64_t M, int D, int K, int r, int P,
+                      float scaling, const void* pend_x, int64_t pend_ldx, const void* pend_dt, int64_t pend_lddt,
+                      float* pend_dA /* += */, int da_now, tb_stream_t stream);
 
 /* ---- optimizer tail: all scalars stay on the device in `state` (fp32[TB_ST_COUNT]) ------------------- */
 enum { TB_ST_LOSS_SCALE = 0, TB_ST_GROWTH_TRACKER = 1, TB_ST_STEP = 2, TB_ST_FOUND_INF = 3, TB_ST_COEF_LORA = 4,

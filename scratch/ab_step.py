@@ -14,6 +14,8 @@ def apply(codes):
         elif c.startswith("attn:"): lib.tb_attention_set_variant(int(c[5:]))
         elif c.startswith("gn:"): lib.tb_groupnorm_set_variant(int(c[3:]))
         elif c.startswith("defer:"): ops.DEFER_SPLITK = bool(int(c[6:]))
+        elif c.startswith("chain:"):
+            import textboost_amd.text_encoder as _te; _te.CHAIN_LORA_BWD = bool(int(c[6:]))
         elif c.startswith("env:"):
             k, v = c[4:].split("=", 1); os.environ[k] = v
         else: lib.tb_gemm_set_variant(int(c))

@@ -334,6 +334,45 @@ def test_lora_backward_ranks(r):
     assert rel_err(dt[:, :P * r], ref_dt) < 3e-3 and dt[:, P * r:].abs().max() == 0
 
 
+@pytest.mark.parametrize("r", [4, 8])
+def test_lora_backward_chain_is_bit_equal_to_per_set_launches(r):
+    """tb_lora_bwd_chain (round 4): three adapter sets walked like the text encoder's layers -- each set's dA panels ride in the next set's dt / dB
+    launch, the last set finishes its own -- against three tb_lora_bwd calls: same arithmetic, same summation order, bit for bit."""
+    from textboost_amd import ops
+    torch.manual_seed(10 + r)
+    M, K, Dm, P, n = 154, 256, 256, 3, 3
+    xs = [torch.randn(M, K, device=dev).half() for _ in range(n)]
+    As = [torch.randn(P * r, K, device=dev) / r for _ in range(n)]
+    Bs = [torch.randn(P * Dm, r, device=dev) * 0.1 for _ in range(n)]
+    dYs = [torch.randn(M, P * Dm, device=dev).half() for _ in range(n)]
+    ts = []
+    for x, A in zip(xs, As):
+        t = torch.zeros(M, 64, device=dev, dtype=torch.float16)
+        ops.lora_down(x, A, t)
+        ts.append(t)
+    ref = []
+    for i in range(n):
+        dt = torch.zeros(M, 64, device=dev, dtype=torch.float16)
+        dA = torch.full_like(As[i], 0.25); dB = torch.full_like(Bs[i], -0.5)      # (+=: the gradients accumulate)
+        ops.lora_bwd(dYs[i], xs[i], ts[i], Bs[i], dt, dA, dB, Dm, K, r, P, scaling=0.5)
+        ref.append((dt, dA, dB))
+    dts = [torch.zeros(M, 64, device=dev, dtype=torch.float16) for _ in range(2)]
+    dAs = [torch.full_like(A, 0.25) for A in As]; dBs = [torch.full_like(B, -0.5) for B in Bs]
+    pending, seen_dt = None, []
+    for i in reversed(range(n)):
+        dt = dts[i & 1]
+        pending = ops.lora_bwd(dYs[i], xs[i], ts[i], Bs[i], dt, dAs[i], dBs[i], Dm, K, r, P, scaling=0.5, pending=pending, defer_da=i > 0)
+        seen_dt.append((i, dt.clone()))
+    assert pending is None
+    for i, dt in seen_dt:
+        assert torch.equal(dt, ref[i][0])
+    for i in range(n):
+        assert torch.equal(dAs[i], ref[i][1]) and torch.equal(dBs[i], ref[i][2]), i
+    # a pending set that shares this link's dt buffer is refused (its dt would be overwritten under the reader)
+    with pytest.raises(RuntimeError):
+        ops.lora_bwd(dYs[0], xs[0], ts[0], Bs[0], dts[0], dAs[0], dBs[0], Dm, K, r, P, pending=(xs[1], dts[0].clone(), dAs[1])[:1] + (dts[0], dAs[1]))
+
+
 def test_lr_multiplier_slot_scales_every_group():
     """state[TB_ST_LR_MULT] = lambda - 1 (lr_scheduler, :911-916/:1135): AdamW and the decay-only rows see lr * lambda."""
     from textboost_amd import _lib as L, ops

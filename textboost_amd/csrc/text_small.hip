@@ -188,12 +188,40 @@ __device__ __forceinline__ void lora_panel_dot(const f16* __restrict__ Lm, int64
   __syncthreads();
 }
 
+template <int RR>
+__device__ __forceinline__ void lora_da_panel(const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ dt, int64_t lddt,
+                                              float* __restrict__ dA, int64_t M, int K, int r, int block, float* lora_smem) {
+  const int tid = threadIdx.x;
+  const int panels = K / LORA_PANEL;
+  const int p = block / panels;
+  const int64_t k0 = (int64_t)(block - p * panels) * LORA_PANEL;
+  lora_panel_dot<RR>(x, ldx, k0, dt, lddt, p * r, r, M, lora_smem);
+  for (int u = tid; u < LORA_PANEL * RR; u += 256) {
+    const int j = u / LORA_PANEL, c = u - j * LORA_PANEL;   // consecutive threads -> consecutive k of one adapter row
+    if (j < r) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int sl = 0; sl < LORA_SLOTS; ++sl) a += lora_smem[(sl * LORA_PANEL + c) * RR + j];
+      dA[(int64_t)(p * r + j) * K + k0 + c] += a;
+    }
+  }
+}
+
 template <int RR>  // RR = 4 (r <= 4) or 8 (r <= 8)
 __global__ __launch_bounds__(256) void lora_bwd_dt_db_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ t, int64_t ldt,
                                                              const float* __restrict__ Bcat, f16* __restrict__ dt, int64_t lddt,
-                                                             float* __restrict__ dB, int64_t M, int D, int r, int P, float scaling, int nslab) {
+                                                             float* __restrict__ dB, int64_t M, int D, int r, int P, float scaling, int nslab,
+                                                             const f16* __restrict__ pend_x, int64_t pend_ldx, const f16* __restrict__ pend_dt,
+                                                             int64_t pend_lddt, float* __restrict__ pend_dA, int K) {
   extern __shared__ __attribute__((aligned(16))) float lora_smem[];
   const int tid = threadIdx.x;
+  const int nb_panels = P * D / LORA_PANEL;
+  if ((int)blockIdx.x >= nslab + nb_panels) {
+    // ---- (c): the dA panels of the adapter set whose dt the PREVIOUS launch of the chain wrote (tb_lora_bwd_chain): they depend on nothing this
+    // launch produces, and slabs + panels of one text-encoder layer do not fill the chip
+    lora_da_panel<RR>(pend_x, pend_ldx, pend_dt, pend_lddt, pend_dA, M, K, r, (int)blockIdx.x - nslab - nb_panels, lora_smem);
+    return;
+  }
   if ((int)blockIdx.x < nslab) {
     // ---- (a): 16 rows, 16 threads per row; thread c of a row takes the 8-column groups n = 8 c (mod 128)
     float* Bs = lora_smem;  // [P * D][RR], fp16-rounded
@@ -287,20 +315,8 @@ template <int RR>
 __global__ __launch_bounds__(256) void lora_bwd_da_kernel(const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ dt, int64_t lddt,
                                                           float* __restrict__ dA, int64_t M, int K, int r, int P) {
   extern __shared__ __attribute__((aligned(16))) float lora_smem[];
-  const int tid = threadIdx.x;
-  const int panels = K / LORA_PANEL;
-  const int p = (int)blockIdx.x / panels;
-  const int64_t k0 = (int64_t)((int)blockIdx.x - p * panels) * LORA_PANEL;
-  lora_panel_dot<RR>(x, ldx, k0, dt, lddt, p * r, r, M, lora_smem);
-  for (int u = tid; u < LORA_PANEL * RR; u += 256) {
-    const int j = u / LORA_PANEL, c = u - j * LORA_PANEL;   // consecutive threads -> consecutive k of one adapter row
-    if (j < r) {
-      float a = 0.f;
-#pragma unroll 8
-      for (int sl = 0; sl < LORA_SLOTS; ++sl) a += lora_smem[(sl * LORA_PANEL + c) * RR + j];
-      dA[(int64_t)(p * r + j) * K + k0 + c] += a;
-    }
-  }
+  (void)P;
+  lora_da_panel<RR>(x, ldx, dt, lddt, dA, M, K, r, (int)blockIdx.x, lora_smem);
 }
 
 }  // namespace
@@ -394,14 +410,20 @@ extern "C" int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P) 
   return 4;  // the round-3 kernels need no scratch (kept in the ABI: callers still pass a pointer)
 }
 
-extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
-                           void* dt, int64_t lddt, float* dA, float* dB, float* ws, int64_t M, int D, int K, int r, int P,
-                           float scaling, tb_stream_t stream) {
+// One adapter set's backward as a link of a chain (the text encoder walks its layers last to first): the dt / dB launch of THIS set also carries
+// the dA panels of the PENDING set (pend_x / pend_dt / pend_dA of the previous link: same M, K, r, P; null = none), whose inputs are complete
+// and which nothing later in the layer waits for; da_now != 0 launches this set's own dA panels behind it (the last link, or a caller
+// that does not chain).  Arithmetic and summation order per set are those of tb_lora_bwd.
+extern "C" int tb_lora_bwd_chain(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
+                                 void* dt, int64_t lddt, float* dA, float* dB, int64_t M, int D, int K, int r, int P, float scaling,
+                                 const void* pend_x, int64_t pend_ldx, const void* pend_dt, int64_t pend_lddt, float* pend_dA, int da_now,
+                                 tb_stream_t stream) {
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
-  (void)ws;
   if (!dY || !x || !t || !Bcat || !dt || !dA || !dB || r <= 0 || r > 8 || P <= 0 || P * r > LORA_MAXR || M <= 0) return TB_EINVAL;
   if (D % LORA_PANEL || K % LORA_PANEL || lddy % 8 || ldx % 8) return TB_EINVAL;  // 16-byte vector accesses, panels inside one adapter
   if (((uintptr_t)dY) % 16 || ((uintptr_t)x) % 16) return TB_EINVAL;
+  const bool pend = pend_x || pend_dt || pend_dA;
+  if (pend && (!pend_x || !pend_dt || !pend_dA || pend_ldx % 8 || ((uintptr_t)pend_x) % 16 || pend_dt == dt)) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nslab = (int)((M + LORA_DT_ROWS - 1) / LORA_DT_ROWS);
   const int RR = r <= 4 ? 4 : 8;
@@ -409,19 +431,29 @@ extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t 
   const size_t b_bytes = (size_t)P * D * RR * sizeof(float);
   const size_t lds1 = red_bytes > b_bytes ? red_bytes : b_bytes;
   if (lds1 > 160 * 1024) return TB_EINVAL;
+  const int nda = P * (K / LORA_PANEL);
 #define TB_LORA_BWD(RRV)                                                                                                                        \
   {                                                                                                                                             \
     if (lds1 > 64 * 1024 &&                                                                                                                     \
         hipFuncSetAttribute((const void*)lora_bwd_dt_db_kernel<RRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
       return TB_ELAUNCH;                                                                                                                        \
-    hipLaunchKernelGGL(lora_bwd_dt_db_kernel<RRV>, dim3(nslab + P * D / LORA_PANEL), dim3(256), lds1, s, (const f16*)dY, lddy, (const f16*)t,   \
-                       ldt, Bcat, (f16*)dt, lddt, dB, M, D, r, P, scaling, nslab);                                                              \
-    hipLaunchKernelGGL(lora_bwd_da_kernel<RRV>, dim3(P * (K / LORA_PANEL)), dim3(256), red_bytes, s, (const f16*)x, ldx, (const f16*)dt, lddt,  \
-                       dA, M, K, r, P);                                                                                                         \
+    hipLaunchKernelGGL(lora_bwd_dt_db_kernel<RRV>, dim3(nslab + P * D / LORA_PANEL + (pend ? nda : 0)), dim3(256), lds1, s, (const f16*)dY,     \
+                       lddy, (const f16*)t, ldt, Bcat, (f16*)dt, lddt, dB, M, D, r, P, scaling, nslab, (const f16*)pend_x, pend_ldx,            \
+                       (const f16*)pend_dt, pend_lddt, pend_dA, K);                                                                             \
+    if (da_now)                                                                                                                                 \
+      hipLaunchKernelGGL(lora_bwd_da_kernel<RRV>, dim3(nda), dim3(256), red_bytes, s, (const f16*)x, ldx, (const f16*)dt, lddt, dA, M, K, r,    \
+                         P);                                                                                                                    \
   }
   if (RR == 4) TB_LORA_BWD(4)
   else TB_LORA_BWD(8)
 #undef TB_LORA_BWD
   TB_CHECK_LAUNCH();
   return TB_OK;
+}
+
+extern "C" int tb_lora_bwd(const void* dY, int64_t lddy, const void* x, int64_t ldx, const void* t, int64_t ldt, const float* Bcat,
+                           void* dt, int64_t lddt, float* dA, float* dB, float* ws, int64_t M, int D, int K, int r, int P,
+                           float scaling, tb_stream_t stream) {
+  (void)ws;
+  return tb_lora_bwd_chain(dY, lddy, x, ldx, t, ldt, Bcat, dt, lddt, dA, dB, M, D, K, r, P, scaling, nullptr, 0, nullptr, 0, nullptr, 1, stream);
 }

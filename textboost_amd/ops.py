@@ -609,9 +609,13 @@ def kv_lora_pack(B, col_base, w2, r, scaling=1.0):
 _lora_ws = {}
 
 
-def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None, w2_fwd=None):
+def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None, w2_fwd=None, pending=None, defer_da=False):
+    """pending / defer_da (16-bit modes): the chained form, tb_lora_bwd_chain -- `pending` = the (x, dt, dA) this function returned for the previous
+    adapter set (its dA panels ride in this set's dt / dB launch), defer_da=True returns this set's (x, dt, dA) instead of launching its dA
+    panels; the caller hands it to the next call (dt buffers of consecutive links must differ) or finishes it with lora_bwd_finish."""
     M = x.shape[0]
     if dY.dtype == torch.float32:
+        assert pending is None and not defer_da
         # fp32 (no-AMP) mode: the same three products as csrc/text_small.hip lora_bwd_fused_kernel, as exact-fp32 GEMMs on transposed views
         #   (a) dt = dY @ W2 (W2 = the packed block-diagonal scaling * B, [P*D, 64])       (b) dB_p += scaling * dY_p^T @ t_p
         #   (c) dA += dt[:, :P*r]^T @ x
@@ -623,6 +627,15 @@ def lora_bwd(dY, x, t, Bcat, dt, dA, dB, D, K, r, P, scaling=1.0, ws=None, w2_fw
         dAv = dA.view(P * r, K)
         gemm_f32_t(dt, x, dAv, P * r, K, M, a_trans=True, w_trans=True, R=dAv)
         return
+    if pending is not None or defer_da:
+        px, pdt, pdA = pending if pending is not None else (None, None, None)
+        assert pending is None or px.shape == x.shape      # (a pending dt that IS this link's dt: refused by the library)
+        L.check(L.lib().tb_lora_bwd_chain(L.ptr(dY), dY.stride(0), L.ptr(x), x.stride(0), L.ptr(t), t.stride(0), L.ptr(Bcat), L.ptr(dt),
+                                          dt.stride(0), L.ptr(dA), L.ptr(dB), M, D, K, r, P, scaling,
+                                          L.ptr(px) if pending else None, px.stride(0) if pending else 0,
+                                          L.ptr(pdt) if pending else None, pdt.stride(0) if pending else 0,
+                                          L.ptr(pdA) if pending else None, 0 if defer_da else 1, L.stream()), "tb_lora_bwd_chain")
+        return (x, dt, dA) if defer_da else None
     if ws is None:
         key = (M, D, K, r, P, x.device, _ws_slot)  # one per concurrently running stream (workspace_slot)
         ws = _lora_ws.get(key)

@@ -17,6 +17,7 @@ Trainable state lives in three flat fp32 buffers so the optimizer / all-reduce s
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -26,6 +27,7 @@ from . import _lib as L
 from . import ops
 
 EOS_ID = 49407  # textboost/text_encoder.py:71
+CHAIN_LORA_BWD = os.environ.get("TB_CHAIN_LORA_BWD", "1") != "0"   # A/B knob: 0 = one dt/dB + one dA launch per layer
 
 
 @dataclass
@@ -245,6 +247,7 @@ class HipTextEncoder:
         dh16 = None if full32 else self.buf(gs + "dh16", M, D, f16)
         ops.layernorm_bwd(d_out, h_last, self.lnf_g, self._bufs[s + "lsf"], dh, dx16=dh16)
         dh_other = self.buf(gs + "dh_b", M, D, f32)
+        pending = None
         for i in reversed(range(geo.num_layers)):
             W = self.Wl[i]
             p = f"{s}l{i}."
@@ -267,9 +270,16 @@ class HipTextEncoder:
                               dqkv[:, 2 * D:], B, H, T, T, hd, causal=True)
             dx1 = self.buf(gs + "dx", M, D, f16)
             if self.r:
-                dt = self.buf(gs + "dt", M, 64, f16)
-                ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, grad_A[i], grad_B[i], D, D, self.r, 3,
-                             self.scaling, w2_fwd=self.w2_fwd[i])
+                if full32 or not CHAIN_LORA_BWD:
+                    dt = self.buf(gs + "dt", M, 64, f16)
+                    ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, grad_A[i], grad_B[i], D, D, self.r, 3,
+                                 self.scaling, w2_fwd=self.w2_fwd[i])
+                else:
+                    # chained: this layer's dA panels (dt^T x1, needed by nothing in the backward) ride in the NEXT layer's dt / dB launch,
+                    # which leaves a third of the chip idle -- 11 launches fewer; two dt buffers alternate
+                    dt = self.buf(gs + f"dt{i & 1}", M, 64, f16)
+                    pending = ops.lora_bwd(dqkv, x1, self._bufs[p + "t"][:M], self.lora_B[i], dt, grad_A[i], grad_B[i], D, D, self.r, 3,
+                                           self.scaling, pending=pending, defer_da=i > 0)
                 ops.gemm(dqkv, W["qkv.wd"], dx1, A2=dt, W2=self.w2_dgrad[i])
             else:
                 ops.gemm(dqkv, W["qkv.wd"], dx1)
