@@ -319,6 +319,7 @@ int tb_lora_bwd_chain(const void* dY, int64_t lddy, const void* x, int64_t ldx, 
                       void* dt, int64_t lddt, float* dA /* += */, float* dB /* += */, int64_t M, int D, int K, int r, int P,
                       float scaling, const void* pend_x, int64_t pend_ldx, const void* pend_dt, int64_t pend_lddt,
                       float* pend_dA /* += */, int da_now, tb_stream_t stream);
+int tb_lora_set_variant(int v);   /* profiling: 0 = the dt slabs of tb_lora_bwd load dY in loops, 1 (default) = all loads up front; returns the old value */
 
 /* ---- optimizer tail: all scalars stay on the device in `state` (fp32[TB_ST_COUNT]) ------------------- */
 enum { TB_ST_LOSS_SCALE = 0, TB_ST_GROWTH_TRACKER = 1, TB_ST_STEP = 2, TB_ST_FOUND_INF = 3, TB_ST_COEF_LORA = 4,

@@ -1,0 +1,42 @@
+"""Where the 20-24 us of the 6.7-GFLOP Linear shapes of levels 1 / 2 go: cold launches (rotating operands in a graph) of the 4-wave kernel
+under its ablation knobs (tb_gemm_set_variant(2000 + bits): 1 = no k-loop loads, 2 = no MFMAs, 4 = no epilogue).  usage: lin_ablate.py"""
+import sys, os, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from textboost_amd import ops, _lib as L
+lib = L.lib()
+dev = "cuda"
+def bench(M, N, K, codes, reset, reps=5):
+    nW = 64
+    As = [torch.randn(M, K, device=dev).half() for _ in range(8)]
+    Ws = [torch.randn(N, K, device=dev).half() * 0.05 for _ in range(nW)]
+    Os = [torch.empty(M, N, device=dev, dtype=torch.float16) for _ in range(8)]
+    big = torch.empty(600 << 20, device=dev, dtype=torch.uint8)   # flushed between replays: weights and activations come from HBM
+    for c in codes: lib.tb_gemm_set_variant(c)
+    if codes: old8 = lib.tb_gemm8_set(0); lib.tb_gemm_set_variant(9400)   # the 4-wave kernel (it has the ablation knobs)
+    def run():
+        for i in range(nW): ops.gemm(As[i % 8], Ws[i], Os[i % 8])
+    run(); torch.cuda.synchronize()
+    cfg = (ctypes.c_int * 5)(); lib.tb_gemm_last_config(cfg)
+    g8 = bool(lib.tb_gemm8_last(None))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g): run()
+    g.replay(); torch.cuda.synchronize()
+    tot = 0.0
+    for _ in range(reps):
+        big.fill_(1)
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        s.record(); g.replay(); e.record(); torch.cuda.synchronize()
+        tot += s.elapsed_time(e)
+    for c in reset: lib.tb_gemm_set_variant(c)
+    if codes: lib.tb_gemm8_set(old8); lib.tb_gemm_set_variant(9401)
+    return tot / (reps * nW) * 1e3, ("g8 " if g8 else "") + f"{cfg[0]}x{cfg[1]} st{cfg[3] % 10} S{cfg[4]}"
+no8 = [8001]   # force the 4-wave 64x64 tile (its ablation knobs)
+variants = [("default", [], []),
+            ("4-wave 64x64", [8001], [8000]), ("  no loads", [8001, 2001], [8000, 2000]), ("  no MFMA", [8001, 2002], [8000, 2000]),
+            ("  no epilogue", [8001, 2004], [8000, 2000]), ("  no loads, no MFMA", [8001, 2003], [8000, 2000]), ("  nothing", [8001, 2007], [8000, 2000]),
+            ("4-wave 128x128", [8003], [8000]), ("  no loads", [8003, 2001], [8000, 2000]), ("  no MFMA", [8003, 2002], [8000, 2000]), ("  nothing", [8003, 2007], [8000, 2000])]
+for M, N, K in [(2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320)]:
+    print(f"{M}x{N}x{K}", flush=True)
+    for name, codes, reset in variants:
+        t, cfg = bench(M, N, K, codes, reset)
+        print(f"    {name:22s} {t:7.1f} us   {cfg}", flush=True)

@@ -310,12 +310,13 @@ def test_geglu_grad_epilogue_matches_separate_kernel():
     assert rel_err(dproj, pack_geglu(pr.grad.T.contiguous()).T) < 3e-3
 
 
-@pytest.mark.parametrize("r", [2, 4, 8])
-def test_lora_backward_ranks(r):
-    """tb_lora_bwd at the generic, rank-4 and rank-8 instantiations (the reference default r=4; SD2.1 config r=8) vs autograd."""
+@pytest.mark.parametrize("r,Dm", [(2, 192), (4, 192), (8, 192), (4, 768), (8, 768), (4, 1024)])
+def test_lora_backward_ranks(r, Dm):
+    """tb_lora_bwd at the generic, rank-4 and rank-8 instantiations (the reference default r=4; SD2.1 config r=8) vs autograd; Dm = 768 / 1024
+    take the dt slabs that hold every dY vector of a thread at once (CLIP-L / OpenCLIP-H widths)."""
     from textboost_amd import ops
     torch.manual_seed(r)
-    M, K, Dm, P = 154, 256, 192, 3
+    M, K, P = 154, 256, 3
     x = torch.randn(M, K, device=dev).half()
     A = torch.randn(P * r, K, device=dev) / r
     Bc = torch.randn(P * Dm, r, device=dev) * 0.1
@@ -334,13 +335,13 @@ def test_lora_backward_ranks(r):
     assert rel_err(dt[:, :P * r], ref_dt) < 3e-3 and dt[:, P * r:].abs().max() == 0
 
 
-@pytest.mark.parametrize("r", [4, 8])
-def test_lora_backward_chain_is_bit_equal_to_per_set_launches(r):
+@pytest.mark.parametrize("r,Dm", [(4, 256), (8, 256), (4, 768), (8, 768), (4, 1024)])
+def test_lora_backward_chain_is_bit_equal_to_per_set_launches(r, Dm):
     """tb_lora_bwd_chain (round 4): three adapter sets walked like the text encoder's layers -- each set's dA panels ride in the next set's dt / dB
     launch, the last set finishes its own -- against three tb_lora_bwd calls: same arithmetic, same summation order, bit for bit."""
     from textboost_amd import ops
     torch.manual_seed(10 + r)
-    M, K, Dm, P, n = 154, 256, 256, 3, 3
+    M, K, P, n = 154, 256, 3, 3      # (Dm = 768 / 1024: the dt slabs hold all of a thread's dY vectors at once)
     xs = [torch.randn(M, K, device=dev).half() for _ in range(n)]
     As = [torch.randn(P * r, K, device=dev) / r for _ in range(n)]
     Bs = [torch.randn(P * Dm, r, device=dev) * 0.1 for _ in range(n)]

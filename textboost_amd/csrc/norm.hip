@@ -793,8 +793,9 @@ __global__ __launch_bounds__(GNS_T) void gn_slice_bwd_kernel(const f16* __restri
 }
 // NV (dwords per thread) the slice kernels would need, 0 when they do not apply: even groups of <= 128 channels, strides even, enough slices
 // to occupy the chip, and the slice must fit the registers of 1024 threads (forward <= 44, backward <= 22 dwords per thread: x and dy live)
-int g_gn_fused = 3;  // tb_groupnorm_set_variant bits: 1 = one-pass 256-thread kernels for the small maps with 8-aligned groups, 2 = one-pass slice
-                     // kernels for the large maps (round 4); 0 = always the two-pass kernels
+int g_gn_fused = 11;  // tb_groupnorm_set_variant bits: 1 = one-pass 256-thread kernels for the small maps with 8-aligned groups, 2 = one-pass slice
+                     // kernels for the large maps (round 4), 4 = slice backward at 22 dwords per thread (opt-in), 8 = the hoisted-load LayerNorm + LoRA-down
+                     // kernel (ln_fwd_kernel<.., 12>); 0 = always the two-pass kernels
 inline int gn_slice_nv(int B, int HW, int C, int G, bool bwd) {
   if (!(g_gn_fused & 2) || G <= 0 || C % G) return 0;
   const int gs = C / G;
@@ -860,7 +861,10 @@ __device__ __forceinline__ void store8<float>(float* p, const float* v) {
   *(f32x4*)(p + 4) = b;
 }
 
-template <typename T, typename TO>
+// RF = 0: the generic kernel.  RF = 12 (R <= 12 adapter rows, C <= 1024: CLIP-L's q / k / v adapters at r = 4): every adapter-row load of the
+// fused down projection is issued at the top, next to the row's own loads, so the LayerNorm statistics run under their latency (one wave per
+// row and two waves per SIMD: nothing else hides it), and the 12 cross-lane reductions are one halving butterfly (17 shuffles, not 72).
+template <typename T, typename TO, int RF = 0>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, int64_t ldx, TO* __restrict__ Y, int64_t ldy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ stats, int64_t M, int C, float eps,
@@ -871,6 +875,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
   const int nv = C >> 3;
   float v[LN_MAXV][8];
   float s = 0.f;
+  constexpr int RFN = RF ? RF : 1, RFK = 2;   // (RF: nv <= 128 -- two vectors of 8 per lane)
+  f32x4 fa0[RFN][RFK], fa1[RFN][RFK];
+  const bool fast_lora = RF && loraA && row < lora_rows;
+  if (RF) {
+#pragma unroll
+    for (int k = 0; k < RFK; ++k) {
+      const int vi = lane + 64 * k;
+#pragma unroll
+      for (int j = 0; j < RFN; ++j) {
+        fa0[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fa1[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (fast_lora && vi < nv) {
+          const float* ap = loraA + (int64_t)(j < R ? j : R - 1) * C + vi * 8;   // (clamped duplicate, not stored)
+          fa0[j][k] = *(const f32x4*)ap;
+          fa1[j][k] = *(const f32x4*)(ap + 4);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < LN_MAXV; ++k) {
     int vi = lane + 64 * k;
@@ -913,7 +936,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, in
       for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
     }
   }
-  if (loraA && row < lora_rows) {  // (rows >= lora_rows: a frozen batch riding along -- their rows of tdown are zeroed below)
+  if (RF && fast_lora) {
+    // per-lane partial sums in the generic path's order (k ascending, the two halves of a vector pairwise), then the halving butterfly: at
+    // distance o a lane keeps the half of its values its bit selects and hands the other half over -- the same pairs are added at every level
+    // as in the 6-step butterfly of each value on its own, so the sums are the same bit for bit; value j ends in the lanes with (lane >> 2) == j
+    float a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < RFN; ++j)
+#pragma unroll
+      for (int k = 0; k < RFK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[j] += v[k][e] * (float)(f16)fa0[j][k][e] + v[k][4 + e] * (float)(f16)fa1[j][k][e];
+#define TB_HALVE(N_, O_)                                                                   \
+  {                                                                                        \
+    const bool up = lane & (O_);                                                           \
+    _Pragma("unroll") for (int i = 0; i < (N_); ++i) {                                     \
+      const float send = up ? a[i] : a[i + (N_)], keep = up ? a[i + (N_)] : a[i];          \
+      a[i] = keep + __shfl_xor(send, (O_), 64);                                            \
+    }                                                                                      \
+  }
+    TB_HALVE(8, 32)
+    TB_HALVE(4, 16)
+    TB_HALVE(2, 8)
+    TB_HALVE(1, 4)
+#undef TB_HALVE
+    a[0] += __shfl_xor(a[0], 2, 64);
+    a[0] += __shfl_xor(a[0], 1, 64);
+    const int j = lane >> 2;
+    if ((lane & 3) == 0 && j < R) tdown[row * ldt + j] = (f16)a[0];
+  } else if (loraA && row < lora_rows) {  // (rows >= lora_rows: a frozen batch riding along -- their rows of tdown are zeroed below)
     // fused LoRA down projection (lora_A of peft lora.Linear on the normalised row): tdown[row, j] = sum_k y[row,k] * fp16(A[j,k]);
     // the row is still in registers, the R <= 24 adapter rows are L2 resident
     // four adapter rows at a time: their loads and their butterfly reductions are independent, so the load latencies and the six dependent
@@ -1121,7 +1174,9 @@ static int ln_fwd_launch(const void* x, int64_t ldx, int x_dtype, void* y, int64
   if (loraA && (!tdown || R <= 0 || R > 64 || ((uintptr_t)loraA) % 16)) return TB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 3) / 4));
-  if (x_dtype == TB_F32 && y_dtype == TB_F16)
+  if (x_dtype == TB_F32 && y_dtype == TB_F16 && loraA && R <= 12 && C <= 1024 && (g_gn_fused & 8))   // (bit 8 of tb_groupnorm_set_variant)
+    hipLaunchKernelGGL((ln_fwd_kernel<float, f16, 12>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt, lora_rows);
+  else if (x_dtype == TB_F32 && y_dtype == TB_F16)
     hipLaunchKernelGGL((ln_fwd_kernel<float, f16>), grid, dim3(256), 0, s, (const float*)x, ldx, (f16*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt, lora_rows);
   else if (x_dtype == TB_F32 && y_dtype == TB_F32)
     hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, stats, M, C, eps, loraA, R, tdown, ldt, lora_rows);

@@ -207,7 +207,7 @@ __device__ __forceinline__ void lora_da_panel(const f16* __restrict__ x, int64_t
   }
 }
 
-template <int RR>  // RR = 4 (r <= 4) or 8 (r <= 8)
+template <int RR, int NG>  // RR = 4 (r <= 4) or 8 (r <= 8); NG = D / 128 when the slabs hold every dY vector of a thread at once (P <= 3), else 0
 __global__ __launch_bounds__(256) void lora_bwd_dt_db_kernel(const f16* __restrict__ dY, int64_t lddy, const f16* __restrict__ t, int64_t ldt,
                                                              const float* __restrict__ Bcat, f16* __restrict__ dt, int64_t lddt,
                                                              float* __restrict__ dB, int64_t M, int D, int r, int P, float scaling, int nslab,
@@ -224,18 +224,35 @@ __global__ __launch_bounds__(256) void lora_bwd_dt_db_kernel(const f16* __restri
   }
   if ((int)blockIdx.x < nslab) {
     // ---- (a): 16 rows, 16 threads per row; thread c of a row takes the 8-column groups n = 8 c (mod 128)
-    float* Bs = lora_smem;  // [P * D][RR], fp16-rounded
-    if (r == RR) {  // same layout: a 16-byte copy, eight vectors in flight per thread
-      const int nvec = P * D * RR / 4;
-      for (int u0 = tid; u0 < nvec; u0 += 256 * 8) {
-        f32x4 v[8];
+    // Every global load of the block is issued before anything waits: the thread's dY vectors of all P adapters (<= LORA_DYV), then its share
+    // of B.  (As loops of [load, use] the block was a chain of 2 + 2 P dependent round trips, and with 150-190 blocks on 256 CUs nothing else
+    // covers them: 15.4 us per launch on the text encoder's critical path.)
+    const int i = tid >> 4, c = tid & 15;
+    const int64_t m = (int64_t)blockIdx.x * LORA_DT_ROWS + i;
+    const bool live = m < M;
+    constexpr bool hoist = NG > 0;   // (host: D == 128 NG, P <= 3)
+    constexpr int NGN = NG ? NG : 1;
+    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 dyv[3][NGN];
+    if (hoist) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+      for (int pq = 0; pq < 3; ++pq)
+#pragma unroll
+        for (int u = 0; u < NGN; ++u)
+          dyv[pq][u] = (live && pq < P) ? *(const f16x8*)(dY + m * lddy + (int64_t)pq * D + c * 8 + 128 * u) : z8;
+    }
+    float* Bs = lora_smem;  // [P * D][RR], fp16-rounded
+    if (r == RR) {  // same layout: a 16-byte copy, twelve vectors in flight per thread
+      const int nvec = P * D * RR / 4;
+      for (int u0 = tid; u0 < nvec; u0 += 256 * 12) {
+        f32x4 v[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
           const int u = u0 + 256 * q;
           v[q] = u < nvec ? *(const f32x4*)(Bcat + (int64_t)u * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 12; ++q) {
           const int u = u0 + 256 * q;
           if (u < nvec) {
 #pragma unroll
@@ -251,20 +268,29 @@ __global__ __launch_bounds__(256) void lora_bwd_dt_db_kernel(const f16* __restri
       }
     }
     __syncthreads();
-    const int i = tid >> 4, c = tid & 15;
-    const int64_t m = (int64_t)blockIdx.x * LORA_DT_ROWS + i;
-    const bool live = m < M;
     for (int p = 0; p < P; ++p) {
       float acc[RR];
 #pragma unroll
       for (int j = 0; j < RR; ++j) acc[j] = 0.f;
-      if (live) {
+      if (live && hoist) {
+        // (same order as the loop below: the thread's column groups ascending, e, j)
+#pragma unroll
+        for (int u = 0; u < NGN; ++u) {
+          const float* bp = Bs + ((int64_t)p * D + c * 8 + 128 * u) * RR;
+          const f16x8 dv = p == 0 ? dyv[0][u] : (p == 1 ? dyv[1][u] : dyv[2][u]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = (float)dv[e];
+#pragma unroll
+            for (int j = 0; j < RR; ++j) acc[j] += d * bp[e * RR + j];
+          }
+        }
+      } else if (live) {
         for (int nb = c * 8; nb < D; nb += 128 * 4) {  // four column groups per batch, loads first
           f16x8 dy[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int n = nb + 128 * u;
-            const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
             dy[u] = n < D ? *(const f16x8*)(dY + m * lddy + (int64_t)p * D + n) : z8;
           }
 #pragma unroll
@@ -319,6 +345,7 @@ __global__ __launch_bounds__(256) void lora_bwd_da_kernel(const f16* __restrict_
   lora_da_panel<RR>(x, ldx, dt, lddt, dA, M, K, r, (int)blockIdx.x, lora_smem);
 }
 
+int g_lora_hoist = 1;   // tb_lora_set_variant: 0 = the dt slabs load dY in loops (A/B)
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
@@ -410,6 +437,12 @@ extern "C" int64_t tb_lora_bwd_ws_floats(int64_t M, int D, int K, int r, int P) 
   return 4;  // the round-3 kernels need no scratch (kept in the ABI: callers still pass a pointer)
 }
 
+extern "C" int tb_lora_set_variant(int v) {   // A/B knob; returns the previous value
+  const int old = g_lora_hoist;
+  g_lora_hoist = v;
+  return old;
+}
+
 // One adapter set's backward as a link of a chain (the text encoder walks its layers last to first): the dt / dB launch of THIS set also carries
 // the dA panels of the PENDING set (pend_x / pend_dt / pend_dA of the previous link: same M, K, r, P; null = none), whose inputs are complete
 // and which nothing later in the layer waits for; da_now != 0 launches this set's own dA panels behind it (the last link, or a caller
@@ -432,20 +465,25 @@ extern "C" int tb_lora_bwd_chain(const void* dY, int64_t lddy, const void* x, in
   const size_t lds1 = red_bytes > b_bytes ? red_bytes : b_bytes;
   if (lds1 > 160 * 1024) return TB_EINVAL;
   const int nda = P * (K / LORA_PANEL);
-#define TB_LORA_BWD(RRV)                                                                                                                        \
+  const int NG = (g_lora_hoist && P <= 3 && (D == 768 || D == 1024)) ? D / 128 : 0;
+#define TB_LORA_BWD(RRV, NGV)                                                                                                                   \
   {                                                                                                                                             \
     if (lds1 > 64 * 1024 &&                                                                                                                     \
-        hipFuncSetAttribute((const void*)lora_bwd_dt_db_kernel<RRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)    \
+        hipFuncSetAttribute((const void*)lora_bwd_dt_db_kernel<RRV, NGV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=            \
+            hipSuccess)                                                                                                                         \
       return TB_ELAUNCH;                                                                                                                        \
-    hipLaunchKernelGGL(lora_bwd_dt_db_kernel<RRV>, dim3(nslab + P * D / LORA_PANEL + (pend ? nda : 0)), dim3(256), lds1, s, (const f16*)dY,     \
-                       lddy, (const f16*)t, ldt, Bcat, (f16*)dt, lddt, dB, M, D, r, P, scaling, nslab, (const f16*)pend_x, pend_ldx,            \
-                       (const f16*)pend_dt, pend_lddt, pend_dA, K);                                                                             \
+    hipLaunchKernelGGL((lora_bwd_dt_db_kernel<RRV, NGV>), dim3(nslab + P * D / LORA_PANEL + (pend ? nda : 0)), dim3(256), lds1, s,              \
+                       (const f16*)dY, lddy, (const f16*)t, ldt, Bcat, (f16*)dt, lddt, dB, M, D, r, P, scaling, nslab, (const f16*)pend_x,      \
+                       pend_ldx, (const f16*)pend_dt, pend_lddt, pend_dA, K);                                                                   \
     if (da_now)                                                                                                                                 \
       hipLaunchKernelGGL(lora_bwd_da_kernel<RRV>, dim3(nda), dim3(256), red_bytes, s, (const f16*)x, ldx, (const f16*)dt, lddt, dA, M, K, r,    \
                          P);                                                                                                                    \
   }
-  if (RR == 4) TB_LORA_BWD(4)
-  else TB_LORA_BWD(8)
+  if (RR == 4) {
+    if (NG == 6) TB_LORA_BWD(4, 6) else if (NG == 8) TB_LORA_BWD(4, 8) else TB_LORA_BWD(4, 0)
+  } else {
+    if (NG == 6) TB_LORA_BWD(8, 6) else TB_LORA_BWD(8, 0)   // (<8, 8>: 32 dY vectors + the B staging spill)
+  }
 #undef TB_LORA_BWD
   TB_CHECK_LAUNCH();
   return TB_OK;
