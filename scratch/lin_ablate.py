@@ -30,12 +30,22 @@ def bench(M, N, K, codes, reset, reps=5):
     for c in reset: lib.tb_gemm_set_variant(c)
     if codes: lib.tb_gemm8_set(old8); lib.tb_gemm_set_variant(9401)
     return tot / (reps * nW) * 1e3, ("g8 " if g8 else "") + f"{cfg[0]}x{cfg[1]} st{cfg[3] % 10} S{cfg[4]}"
+import sys as _s
+if len(_s.argv) > 1 and _s.argv[1] == "stages":
+    variants = [("default", [], []),
+                ("64x64 st2", [8001, 10], [8000, 9]), ("64x64 st3", [8001, 14], [8000, 9]), ("64x64 st4", [8001, 15], [8000, 9]),
+                ("128x64 st2", [8002, 0], [8000, 0]), ("128x64 st3", [8002, 4], [8000, 0]), ("128x64 st4", [8002, 5], [8000, 0]), ("128x64 st6", [8002, 6], [8000, 0]),
+                ("128x128 st2", [8003, 0], [8000, 0]), ("128x128 st3", [8003, 4], [8000, 0]), ("128x128 st4", [8003, 5], [8000, 0])]
+    shapes = [(2048, 1280, 1280), (8192, 640, 640), (2048, 1280, 2560), (8192, 640, 1920), (512, 1280, 1280)]
+else:
+    variants = None
 no8 = [8001]   # force the 4-wave 64x64 tile (its ablation knobs)
-variants = [("default", [], []),
+_v0 = [("default", [], []),
             ("4-wave 64x64", [8001], [8000]), ("  no loads", [8001, 2001], [8000, 2000]), ("  no MFMA", [8001, 2002], [8000, 2000]),
             ("  no epilogue", [8001, 2004], [8000, 2000]), ("  no loads, no MFMA", [8001, 2003], [8000, 2000]), ("  nothing", [8001, 2007], [8000, 2000]),
             ("4-wave 128x128", [8003], [8000]), ("  no loads", [8003, 2001], [8000, 2000]), ("  no MFMA", [8003, 2002], [8000, 2000]), ("  nothing", [8003, 2007], [8000, 2000])]
-for M, N, K in [(2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320)]:
+if variants is None: variants, shapes = _v0, [(2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320)]
+for M, N, K in shapes:
     print(f"{M}x{N}x{K}", flush=True)
     for name, codes, reset in variants:
         t, cfg = bench(M, N, K, codes, reset)
