@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textboost_amd import ops, _lib as L
 lib = L.lib()
 dev = "cuda"
+WARM = os.environ.get('TB_WARM', '0')   # 1: four weight matrices, no flush (weights L2 / Infinity-Cache warm); 2: cold weights, ONE warm activation buffer
 def bench(M, N, K, codes, reset, reps=5):
-    nW = 64
+    nW = 4 if WARM == '1' else 64
     As = [torch.randn(M, K, device=dev).half() for _ in range(8)]
     Ws = [torch.randn(N, K, device=dev).half() * 0.05 for _ in range(nW)]
     Os = [torch.empty(M, N, device=dev, dtype=torch.float16) for _ in range(8)]
@@ -14,7 +15,7 @@ def bench(M, N, K, codes, reset, reps=5):
     for c in codes: lib.tb_gemm_set_variant(c)
     if codes: old8 = lib.tb_gemm8_set(0); lib.tb_gemm_set_variant(9400)   # the 4-wave kernel (it has the ablation knobs)
     def run():
-        for i in range(nW): ops.gemm(As[i % 8], Ws[i], Os[i % 8])
+        for i in range(nW): ops.gemm(As[0 if WARM == '2' else i % 8], Ws[i], Os[i % 8])
     run(); torch.cuda.synchronize()
     cfg = (ctypes.c_int * 5)(); lib.tb_gemm_last_config(cfg)
     g8 = bool(lib.tb_gemm8_last(None))
@@ -23,7 +24,7 @@ def bench(M, N, K, codes, reset, reps=5):
     g.replay(); torch.cuda.synchronize()
     tot = 0.0
     for _ in range(reps):
-        big.fill_(1)
+        if WARM == '0': big.fill_(1)
         s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
         s.record(); g.replay(); e.record(); torch.cuda.synchronize()
         tot += s.elapsed_time(e)

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       if (!CONV || k < WI) issue_slot(k, lc, ltap, st % NS, -2, -1, 0);
   }
   if (NS == 2) cnt_prev = 0;
+  int cnt_hist = cnt_prev;   // loads this wave issued in the previous step (prologue: the youngest stage)
   wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
   if (!CONV && t < BN) {
     bias_s[t] = bias_v;
@@ -479,7 +480,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
         __builtin_amdgcn_sched_barrier(0);
         // after the step's last issue: everything except THIS step's loads has landed (this wave's part), i.e. the next step's stage
-        if (h == HALVES - 1) wait_vmcnt(cnt_step);
+        if (h == HALVES - 1) {
+          // (NS >= 4, Linear: the stage two steps ahead may stay in flight as well -- what must have landed is the NEXT step's stage)
+          wait_vmcnt(!CONV && NS >= 4 ? cnt_step + cnt_hist : cnt_step);
+          cnt_hist = cnt_step;
+        }
 #if G8_PROF
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         G8_PF(0)
@@ -1177,6 +1182,16 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   if (!(g8_enable & 128) && !ln_act && d.act != TB_ACT_GEGLU && d.act != TB_ACT_GEGLU_GRAD && d.K <= 640 && (d.N > 320 || (g8_enable & 256)) && d.N % 160 == 0 && d.M % 128 == 0 &&
       (d.M / 128) * (d.N / 160) >= ((g8_enable & 512) ? 256 : 512))
     return launch8<4, 2, 2, 5, false, 2>(d, s, 30);
+  // One 128 x 80 tile per CU with a 4-stage ring for the 16x16-map Linear layers (M = 2048, N = 1280: 16 x 16 tiles): their launches are bound by
+  // the bytes that go through the L2 -> LDS path (scratch/lin_ablate.py, scratch/ubench/ldsdma_bw.hip: ~100 GB/s per CU whatever is in flight) --
+  // 2.5 resident 64x64 tiles of the four-wave kernel move 820 KB per CU at K = 1280, this tile 532 KB
+  if (!(g8_enable & 2048) && !ln_act && (d.act == TB_ACT_NONE || d.act == TB_ACT_SILU) && d.N % 80 == 0 && d.M % 128 == 0 && d.K >= 640 && d.K <= 2560) {
+    const int64_t tiles = (d.M / 128) * (d.N / 80);
+    if (tiles >= 200 && tiles <= 256) return launch8<8, 1, 1, 5, false, 4>(d, s, 30);
+    // ... and 128 x 160 for the 32x32-map layers (M = 8192, N = 640: 64 x 4 tiles; 369 KB per CU at K = 640 against 491 KB for the 64 x 320 tile)
+    const int64_t tiles160 = d.N % 160 == 0 ? (d.M / 128) * (d.N / 160) : 0;
+    if (!(g8_enable & 4096) && tiles160 >= 200 && tiles160 <= 256) return launch8<4, 2, 2, 5, false, 4>(d, s, 30);
+  }
   if (d.N % 320) return 1;
   if (ln_act && (d.M / 128) * (d.N / 320) >= 200 && d.M % 128 == 0) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
