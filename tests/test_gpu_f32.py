@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from parity import parity
+from test_gpu_gemm import rel_err
 
 pytestmark = pytest.mark.gpu
 dev = "cuda"
@@ -537,6 +538,38 @@ def test_unet_crossattn_kv_lora_step_matches_oracle(tmp_path):
     from safetensors.torch import load_file
     sd = load_file(str(tmp_path / "unet" / "adapter_model.safetensors"))
     assert len(sd) == 64 and sd["mid_block.attentions.0.transformer_blocks.0.attn2.to_v.lora_A.default.weight"].shape == (r, D)
+
+
+def test_validation_sampler_unet_gets_the_crossattn_kv_adapters_folded_in():
+    """log_validation samples with the TRAINED unet (train_textboost.py:453-531); the validation sampler is a separate fp16
+    UNet without adapter support, so under --unet_params_to_train crossattn_kv it loads attn2.to_k / to_v with the adapters folded in
+    (HipUNet.merged_kv_weight -> load_kv_weight).  The fp32 training UNet WITH adapters, the fp32 UNet with merged weights and NO adapters
+    (1e-5: the same product re-associated), and the fp16 sampler UNet with merged weights (fp16 tolerance) predict the same noise; without
+    the fold the fp16 UNet is measurably off."""
+    from textboost_amd.unet import HipUNet
+    B, hw, D, r = 2, 16, 64, 4
+    ref, hip = _small_unet_f32(B, hw, D, seed=5)
+    hip.enable_kv_lora(r, seed=1)
+    hip.kv_lora_B.normal_(std=0.3)           # (trained adapters: B is zero at initialisation)
+    hip.pack_kv_lora()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 4, hw, hw, generator=g).to(dev)
+    t = torch.tensor([17, 801]).to(dev)
+    ehs = torch.randn(B * 77, D, generator=g).to(dev)
+    pred_train = hip.forward(x, t, ehs).clone()
+    merged = hip.merged_kv_weight()
+    assert merged.dtype == torch.float32 and (merged - hip.P["kv_all.w"]).abs().max() > 1e-3
+    plain32 = HipUNet(hip.geo, ref.state_dict(), B, hw, hw, text_len=77, device=dev, dtype=torch.float32)
+    pred_base = plain32.forward(x, t, ehs).clone()
+    plain32.load_kv_weight(merged)
+    parity("fp32 UNet, adapters folded into to_k / to_v", plain32.forward(x, t, ehs), pred_train, rel=1e-5, maxabs=1e-5)
+    sampler_unet = HipUNet(hip.geo, ref.state_dict(), B, hw, hw, text_len=77, device=dev)       # the sampler's: fp16, no adapters
+    half = sampler_unet.P["kv_all.w"].dtype
+    off = rel_err(sampler_unet.forward(x.to(half), t, ehs.to(half)), pred_train)
+    sampler_unet.load_kv_weight(merged)
+    on = rel_err(sampler_unet.forward(x.to(half), t, ehs.to(half)), pred_train)
+    base_gap = rel_err(pred_base, pred_train)
+    assert on < 5e-3 and base_gap > 5 * on and off > 5 * on, (on, off, base_gap)
 
 
 def test_cli_unet_crossattn_kv(tmp_path):

@@ -162,6 +162,23 @@ class HipUNet:
         if getattr(self, "kv_r", 0):
             ops.kv_lora_pack(self.kv_lora_B, self.kv_col_base, self.kv_w2, self.kv_r, self.kv_scaling)
 
+    def merged_kv_weight(self):
+        """attn2.to_k / to_v weights with the adapters folded in, fp32 [kv_total, Dc]: W + W2 A_all (W2 = the block-structured scaling * B of
+        pack_kv_lora) -- what a UNet WITHOUT adapter support loads to compute the same projections.  The validation sampler
+        (train_textboost.py:453-531 samples with the trained unet) takes it: tests/test_gpu_f32.py."""
+        assert getattr(self, "kv_r", 0)
+        self.pack_kv_lora()
+        n2r, Dc = self.kv_w2.shape[1], self.geo.cross_attention_dim
+        base = self.P["kv_all.w"].float()
+        out = torch.empty_like(base)
+        ops.gemm_f32_t(self.kv_w2, self.kv_lora_A.view(n2r, Dc), out, self.kv_total, Dc, n2r, w_trans=True, R=base)
+        return out
+
+    def load_kv_weight(self, W):
+        """replace every attn2.to_k / to_v weight (fp32 [kv_total, Dc], the layout of merged_kv_weight) in this executor's operand dtype"""
+        assert tuple(W.shape) == tuple(self.P["kv_all.w"].shape)
+        self.P["kv_all.w"].copy_(W.to(self.P["kv_all.w"].dtype))
+
     # ------------------------------------------------------------------ weights
     def _pack(self, sd):
         dev, geo, wdt = self.dev, self.geo, self.dtype

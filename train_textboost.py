@@ -155,12 +155,6 @@ def main(args):
     if args.validation_prompts and tokenizer is not None:
         val_ids = torch.zeros(len(args.validation_prompts), clip_geo.max_pos, dtype=torch.int64)  # filled once the tokens are registered
     sampler = None
-    if args.validation_prompts and args.unet_params_to_train == "crossattn_kv":
-        # log_validation (:453-531) samples with the TRAINED unet (accelerator.unwrap_model(unet), fp32 in this mode); the sampler here is a
-        # separate fp16 UNet built from the base weights, so its images would silently miss the K/V adapters being trained
-        raise NotImplementedError("--validation_prompts together with --unet_params_to_train crossattn_kv: the validation sampler is an fp16 "
-                                  "UNet without the cross-attention K/V adapters; drop --validation_prompts (the adapters are saved to "
-                                  "<output_dir>/unet/ and in every checkpoint)")
     if args.validation_prompts and val_ids is None:
         logger.warning("--validation_prompts given but neither a tokenizer nor %s exists: validation is skipped", val_ids_path)
     if val_ids is not None and is_main:
@@ -384,6 +378,11 @@ def main(args):
         empty[:, 0] = BOS
         cond = te_val.forward(ids).clone()
         uncond = te_val.forward(empty).clone()
+        if getattr(unet, "kv_r", 0):
+            # --unet_params_to_train crossattn_kv: log_validation samples with the TRAINED unet (:453-531).  The sampler is a separate fp16 UNet
+            # without adapter support: it gets the attn2.to_k / to_v weights with the current adapters folded in (W + scaling * B A in fp32,
+            # rounded once to fp16)
+            sampler.unet.load_kv_weight(unet.merged_kv_weight())
         if args.seed is not None:
             sampler.generator = torch.Generator(device=dev).manual_seed(args.seed)
         images = sampler.sample(cond, uncond)
