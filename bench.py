@@ -91,8 +91,9 @@ def roofline_leg(step):
     for pf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
-            if name in pmc:
-                roof["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
+            key = name if name in pmc else (name[:-1] + ", 0>" if name.endswith(">") and name[:-1] + ", 0>" in pmc else None)  # (the trace's symbol
+            if key:                                                                                  # carries the defaulted SUB template argument)
+                roof["traffic"] = round(pmc[key]["hbm_bytes_per_launch"])
                 roof["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
                 break
         except (OSError, ValueError, KeyError):
