@@ -656,3 +656,36 @@ def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
         ref = F.silu(ref)      # (tb_gemm: the activation acts on acc + bias + residual)
     parity("128 x 80 one-per-CU Linear tile", outs[0], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
     assert rel_err(outs[0], outs[1]) < 3e-4
+
+
+@pytest.mark.parametrize("K,bias,res", [(5120, True, True), (10240, False, False)])
+def test_linear_long_k_two_slices_of_128x160_tiles(K, bias, res):
+    """the 16x16-map long-K Linear layers (M = 2048, N = 1280: ff.net.2, the GEGLU-projection dgrad) as 16 x 8 tiles of 128 x 160 in two k-slices on the
+    8-wave kernel (one workgroup per CU, fp32 partials + the reducer launch), against torch and against the 128 x 128 split-K launches of the
+    4-wave kernel they replace (tb_gemm8_set bit 8192)."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(19)
+    M, N = 2048, 1280
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda") if bias else None
+    R = torch.randn(M, N + 8, device="cuda").half()[:, 8:] if res else None
+    prev = L.lib().tb_gemm8_set(39)
+    outs = []
+    try:
+        for bits in (39, 39 | 8192):
+            L.lib().tb_gemm8_set(bits)
+            Cbuf = torch.full((M, N + 16), 3.0, device="cuda", dtype=torch.float16)
+            out = Cbuf[:, 8:8 + N]
+            ops.gemm(A, W, out, bias=b, R=R)
+            last = (ctypes.c_int * 6)()
+            took = bool(L.lib().tb_gemm8_last(last))
+            assert (took and list(last)[:4] == [4, 2, 2, 5]) == (bits == 39), list(last)
+            assert (Cbuf[:, :8] == 3).all() and (Cbuf[:, 8 + N:] == 3).all()
+            outs.append(out)
+    finally:
+        L.lib().tb_gemm8_set(prev)
+    ref = A.float() @ W.float().T + (b if bias else 0) + (R.float() if res else 0)
+    parity("long-K Linear, two k-slices of 128 x 160 tiles", outs[0], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
+    assert rel_err(outs[0], outs[1]) < 3e-4

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // ---- epilogue: accumulators -> padded fp32 tile in LDS -> (row, 8 columns) units with 16-byte global accesses.  A thread keeps ONE
   // column group (bias loaded once) and walks rows; all residual / auxiliary loads of its units are issued before the arithmetic.
   float* Cs = reinterpret_cast<float*>(smem_raw);
-  if (CONV && Ssplit > 1) {  // raw fp32 partial of this k-slice
+  if (Ssplit > 1) {  // raw fp32 partial of this k-slice (Linear tiles: wshift = 30, so the row of tile row r is m0 + r)
     float* const dst0 = ws + (int64_t)slice * p.M * npad + n;
     const int64_t Mtot = p.M;
 #pragma unroll 1
@@ -1013,7 +1013,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   const int tiles_m = (int)((SUB == 1 ? d.M / 4 : d.M) / BM), tiles_n = (int)(d.N / BN);
   const int64_t npad = (d.N + 7) & ~(int64_t)7;
   if (SUB == 1 && S != 4) return TB_EINVAL;
-  if (SUB != 1 && S > 1 && (!CONV || !d.ws || (size_t)S * (size_t)d.M * (size_t)npad * 4 > d.ws_bytes)) return 1;
+  if (SUB != 1 && S > 1 && (!d.ws || (size_t)S * (size_t)d.M * (size_t)npad * 4 > d.ws_bytes)) return 1;
   int a_rows;
   if (CONV) {
     const int TW = 1 << wshift, R = BM >> wshift;
@@ -1191,6 +1191,15 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     // ... and 128 x 160 for the 32x32-map layers (M = 8192, N = 640: 64 x 4 tiles; 369 KB per CU at K = 640 against 491 KB for the 64 x 320 tile)
     const int64_t tiles160 = d.N % 160 == 0 ? (d.M / 128) * (d.N / 160) : 0;
     if (!(g8_enable & 4096) && tiles160 >= 200 && tiles160 <= 256) return launch8<4, 2, 2, 5, false, 4>(d, s, 30);
+  }
+  // long-K layers of the 16x16 maps (ff.net.2 and the GEGLU-projection dgrad at C = 1280: M = 2048, N = 1280, K = 5120 / 10240): 16 x 8 tiles of
+  // 128 x 160 (14 fragment reads per 20 MFMAs) cut into two k-slices = one workgroup per CU; fp32 partials + the caller's reducer
+  if (!(g8_enable & 8192) && !ln_act && (d.act == TB_ACT_NONE || d.act == TB_ACT_SILU) && d.N % 160 == 0 && d.M % 128 == 0 && d.K >= 4096 && d.ws) {
+    const int64_t tiles160 = (d.M / 128) * (d.N / 160);
+    if (tiles160 * 2 >= 200 && tiles160 * 2 <= 256) {
+      const int r = launch8<4, 2, 2, 5, false, 4>(d, s, 30, 2);
+      if (r != 1) return r;
+    }
   }
   if (d.N % 320) return 1;
   if (ln_act && (d.M / 128) * (d.N / 320) >= 200 && d.M % 128 == 0) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
