@@ -185,6 +185,39 @@ def test_attention_fwd_software_pipelined_kernel(B, H, Sq, Skv):
     assert rel_err(res[0][0], res[1][0]) < 1e-3
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,hd", [(2, 8, 4096, 77, 40), (8, 8, 4096, 77, 40), (2, 8, 1024, 77, 40), (1, 5, 1152, 77, 64), (2, 4, 1024, 50, 40),
+                                           (1, 3, 2048, 96, 24), (1, 2, 1280, 65, 8)])
+def test_attention_fwd_short_key_kernel(B, H, Sq, Skv, hd):
+    """attn_xs_fwd_kernel (round 4): cross-attention on the prompt (33 .. 96 keys, hd <= 64, >= 1024 queries) with all keys staged once, K held in
+    registers and 1 / 2 / 4 query tiles per wave, against fp32 attention and against the general flash kernel it replaces for these shapes
+    (tb_attention_set_variant bit 16384): ragged key counts (50, 65, 77, 96), head dims with and without padding, one dominant key per head."""
+    from textboost_amd import _lib as L
+    ops = _ops()
+    torch.manual_seed(11)
+    C = H * hd
+    q = torch.randn(B * Sq, C, device="cuda").half()
+    kv = torch.randn(B * Skv, 2 * C, device="cuda").half()
+    k, v = kv[:, :C], kv[:, C:]
+    for h in range(H):   # a dominant key in the last (partly masked) 32-key tile
+        k.view(B, Skv, C)[0, Skv - 2, h * hd:(h + 1) * hd] = q.view(B, Sq, C)[0, 9 + h, h * hd:(h + 1) * hd] * 3
+    oref, lref = ref_attention(q.float().reshape(B, Sq, C), k.float().reshape(B, Skv, C), v.float().reshape(B, Skv, C), H, False)
+    res = []
+    prev = L.lib().tb_attention_set_variant(1)
+    try:
+        for variant in (1, 1 | 16384):
+            L.lib().tb_attention_set_variant(variant)
+            o = torch.full((B * Sq, C + 8), 5.0, device="cuda", dtype=torch.float16)[:, :C]
+            lse = torch.empty(B, H, Sq, device="cuda")
+            ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd)
+            assert torch.isfinite(o).all()
+            parity(f"short-key attention O {B}x{H}x{Sq}x{Skv}x{hd} variant {variant}", o.reshape(B, Sq, C), oref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-3)
+            assert ((lse - lref).abs() / lref.abs().clamp_min(1.0)).max().item() < 2e-3    # (the dominant key's score is ~20: relative)
+            res.append((o.clone(), lse))
+    finally:
+        L.lib().tb_attention_set_variant(prev)
+    assert rel_err(res[0][0], res[1][0]) < 1e-3 and (res[0][1] - res[1][1]).abs().max().item() < 5e-4
+
+
 def test_attention_online_softmax_rescale_branch():
     """Force the running max to jump at a late KV tile (cdna guide rule 26): spike one key against one query."""
     ops = _ops()

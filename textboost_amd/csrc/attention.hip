@@ -434,6 +434,129 @@ __global__ __launch_bounds__(256, (DT <= 2 && KS <= 3 && TB_FWD_OCC3 ? 3 : (DT <
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, short key sequences
+// Cross-attention on the prompt (train_textboost.py:1063-1067: 77 keys per head against 4096 / 1024 queries): Skv <= 96, non-causal, DT <= 2.
+// In attn_fwd_kernel such a launch is two 64-key tiles (the second one 80 % masked) with a barrier, a V transpose and a re-base test per tile,
+// for 128 queries per workgroup -- 29 us for 42 MB of Q / O traffic at the 64x64 maps.  Here the K / V^T images of ALL keys are staged once,
+// K is held as MFMA operand fragments in registers, and each wave walks `qtiles` 32-query tiles with no barrier and a plain (single-pass)
+// softmax; the next tile's Q fragments are requested before the current tile's products.  Same arithmetic as attn_fwd_kernel up to the
+// reference point of the exponentials (the row maximum itself instead of a lazily re-based one): O to 1 fp16 ulp, LSE to ~1e-6.
+template <int DT, int KS, int QT>
+__global__ __launch_bounds__(256, 2) void attn_xs_fwd_kernel(const tb_attn_desc p, int remap) {
+  constexpr int qtiles = QT;
+  constexpr int WD = DT * 32;
+  constexpr int TILE = RM<WD>::SIZE + TR<WD>::SIZE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16* const K0 = reinterpret_cast<f16*>(smem_raw);
+  f16* const V0 = K0 + RM<WD>::SIZE;
+  f16* const K1 = K0 + TILE;
+  f16* const V1 = K1 + RM<WD>::SIZE;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlk blk = attn_block(remap);
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.x * 128 * qtiles;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * p.hd;
+  const bool three = p.Skv > KVT;   // keys 64 .. 95 exist
+  // the Q fragments of ALL of the wave's tiles are requested first: one exposed HBM round trip per wave, under the K / V staging
+  f16x8 qall[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) load_row_frags<KS>(qall[qt], Qg, p.ldq, qblk + (qt * 4 + wave) * 32 + l31, p.Sq, p.hd, hi);
+  {
+    TileRegs<WD> kreg, vreg;
+    tile_init<WD>(kreg, p.ldk, p.hd);
+    tile_init<WD>(vreg, p.ldv, p.hd);
+    tile_load<WD, true>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD, true>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+    tile_store<WD, true, false>(kreg, K0, nullptr);
+    tile_store<WD, false, true>(vreg, nullptr, V0);
+    if (three) {
+      tile_load<WD, true>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
+      tile_load<WD, true>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
+      tile_store<WD, true, false>(kreg, K1, nullptr);
+      tile_store<WD, false, true>(vreg, nullptr, V1);
+    }
+  }
+  __syncthreads();
+  f16x8 kf[3][KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    kf[0][j] = frag_rm<WD>(K0, l31, 2 * j + hi);
+    kf[1][j] = frag_rm<WD>(K0, 32 + l31, 2 * j + hi);
+    kf[2][j] = frag_rm<WD>(three ? K1 : K0, l31, 2 * j + hi);
+  }
+  const float c = p.scale * LOG2E;
+#pragma unroll
+  for (int qt = 0; qt < qtiles; ++qt) {
+    const int q = qblk + (qt * 4 + wave) * 32 + l31;
+    f16x8 (&qf)[KS] = qall[qt];
+    scale_frags<KS>(qf, c);  // scores come out of the MFMA in the log2 domain
+    f32x16 s[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      ZERO16(s[kt]);
+      if (kt < 2 || three) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) s[kt] = TB_MFMA_32x32x16(kf[kt][j], qf[j], s[kt]);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + mfma32_row(r, hi);
+        s[kt][r] = key < p.Skv ? s[kt][r] : -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // (key 0 exists: finite)
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(s[kt][r] - mx);
+        s[kt][r] = pv;
+        l += pv;
+      }
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ZERO16(o[d]);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      if (kt < 2 || three) {
+        const f16* Vt = kt < 2 ? V0 : V1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const f16x8 pf = pack8(s[kt], 8 * jj);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) o[d] = TB_MFMA_32x32x16(frag_tr(Vt, d, l31, (kt & 1) * 32 + 16 * jj, hi), pf, o[d]);
+        }
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q < p.Sq) {
+      const float inv = 1.f / l;
+      f16* Og = (f16*)p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * p.hd;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int col = d * 32 + 8 * r4 + 4 * hi;  // 4 consecutive head-dim columns
+          if (col < p.hd) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(o[d][4 * r4 + e] * inv);
+            *(f16x4*)(Og + col) = v;
+          }
+        }
+      if (p.LSE && hi == 0) p.LSE[((int64_t)b * p.H + h) * p.Sq + q] = mx * (1.f / LOG2E) + logf(l);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward, LDS-DMA staged
 // Same arithmetic as attn_fwd_kernel (swapped S^T = K Q^T, FOLDM / ONES tricks, lazy re-base), different operand path -- the register-staged
 // kernel issues ~380 instructions per 14 MFMAs (tile loads into VGPRs, address arithmetic, f16 permutes and 12 LDS stores per thread for
@@ -1519,7 +1642,7 @@ __global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __r
 
 int g_attn_dma = 1;  // tb_attention_set_variant(bits): 1 = LDS-DMA staged forward kernel, 2 = also for hd 80, 4 = NO XCD-aware block remap,
                      // 1024 / 2048 = LDS-DMA kernels instead of the software-pipelined forward / dK-dV kernels (attention_il.hip), 4096 = the
-                     // software-pipelined dQ kernel (opt-in),
+                     // software-pipelined dQ kernel (opt-in), 16384 = the general flash kernel also for short key sequences (no attn_xs_fwd_kernel),
                      // 32 = one query group per wave, 64 = XCD remap also in the backward kernels (measured: forward +14 %, backward -5 %)
                      // (A/B knobs; 8 / 16 = load-path ablations of the DMA kernel)
 
@@ -1574,6 +1697,18 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
       TB_CHECK_LAUNCH();
       return TB_OK;
     }
+  }
+  if constexpr (DT <= 2) if (!d.causal && d.Skv <= 96 && d.Skv > 32 && d.hd % 8 == 0 && d.Sq % 128 == 0 && d.Sq >= 1024 && !(g_attn_dma & 16384)) {
+    // short key sequences (cross-attention on the prompt): attn_xs_fwd_kernel, 256 or 512 queries per workgroup
+    const int qtiles = d.Sq % 512 == 0 && (int64_t)(d.Sq / 512) * d.H * d.B >= 512 ? 4 : (d.Sq % 256 == 0 ? 2 : 1);
+    const size_t ldsx = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16) * 2;
+    const int rmx = ((g_attn_dma >> 2) & 1) ^ 1;
+    const dim3 gx((unsigned)(d.Sq / (128 * qtiles)), d.H, d.B);
+    if (qtiles == 4) hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, 4>), gx, dim3(256), ldsx, s, d, rmx);
+    else if (qtiles == 2) hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, 2>), gx, dim3(256), ldsx, s, d, rmx);
+    else hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, 1>), gx, dim3(256), ldsx, s, d, rmx);
+    TB_CHECK_LAUNCH();
+    return TB_OK;
   }
   if (TB_ATTN_FOLDM && DT <= 2 && d.hd < WD && d.hd < 16 * KS && d.hd % 8 == 0)  // padding in the head dim of BOTH products: see FOLDM
     hipLaunchKernelGGL((attn_fwd_kernel<DT, KS, true, (DT <= 2)>), grid, dim3(256), lds, s, d, ((g_attn_dma >> 2) & 1) ^ 1);
