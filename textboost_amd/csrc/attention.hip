@@ -453,7 +453,24 @@ __global__ __launch_bounds__(256, 2) void attn_xs_fwd_kernel(const tb_attn_desc 
   f16* const V1 = K1 + RM<WD>::SIZE;
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const AttnBlk blk = attn_block(remap);
+  // Workgroup -> (query band, head, batch).  The K / V of a head are a few KB here; what matters is Q and O: a head's slice is hd of the H * hd
+  // halfs of a row, so the H heads of one query band read and write the SAME cache lines.  remap: XCD i takes the (band, batch) pairs i, i + 8, ..
+  // and runs their H heads back to back -- every line is fetched into ONE L2 and written back whole (attn_block's pairing, made for the long-key
+  // kernels, puts the heads of a band on eight different XCDs).
+  AttnBlk blk;
+  {
+    const int gx = gridDim.x, H = gridDim.y, B = gridDim.z;
+    if (remap && ((gx * B) & 7) == 0) {
+      const int lin = blockIdx.x + gx * (blockIdx.y + H * blockIdx.z);
+      const int xcd = lin & 7, k = lin >> 3;
+      const int xb = (k / H) * 8 + xcd;
+      blk.h = k - (k / H) * H;
+      blk.x = xb % gx;
+      blk.b = xb / gx;
+    } else {
+      blk.x = blockIdx.x, blk.h = blockIdx.y, blk.b = blockIdx.z;
+    }
+  }
   const int b = blk.b, h = blk.h;
   const int qblk = blk.x * 128 * qtiles;
   const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
