@@ -15,6 +15,8 @@ groups.append(g)
 big = [x for x in groups if len(x) > 600]
 tight = [x for x in big if (x[-1][2] - x[0][1]) < 1.08 * sum(r[2] - r[1] for r in x)]   # graph replays (kernels abut), not the eager roofline leg
 g = (tight or big)[-1]
+ends = [i for i, r in enumerate(g) if 'renorm_rows_kernel' in r[0]]   # (consecutive replays less than 100 us apart land in one group: keep the last whole step)
+if len(ends) >= 2: g = g[ends[-2] + 1:ends[-1] + 1]
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 t0 = g[0][1]
 def short(n):
