@@ -218,6 +218,46 @@ def test_attention_fwd_short_key_kernel(B, H, Sq, Skv, hd):
     assert rel_err(res[0][0], res[1][0]) < 1e-3 and (res[0][1] - res[1][1]).abs().max().item() < 5e-4
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,hd", [(2, 8, 4096, 77, 40), (2, 8, 1024, 77, 40), (1, 5, 1152, 77, 64), (2, 4, 1024, 50, 40), (1, 3, 2048, 96, 24)])
+def test_attention_bwd_short_key_dq_kernel(B, H, Sq, Skv, hd):
+    """attn_xs_bwd_dq_kernel (round 4): the dQ half of the cross-attention backward for 33 .. 96 keys (K / V staged once and held as register
+    fragments, two query tiles per wave requested up front; also publishes delta for the dK / dV launch) against autograd and against the general
+    kernels (tb_attention_set_variant bit 16384): dQ, dK, dV and delta."""
+    from textboost_amd import _lib as L
+    ops = _ops()
+    torch.manual_seed(12)
+    C = H * hd
+    q = torch.randn(B * Sq, C, device="cuda").half()
+    kv = torch.randn(B * Skv, 2 * C, device="cuda").half()
+    k, v = kv[:, :C], kv[:, C:]
+    do = torch.randn(B * Sq, C, device="cuda").half()
+    qr, kr, vr = [t.float().reshape(B, -1, C).requires_grad_(True) for t in (q, k, v)]
+    oref, _ = ref_attention(qr, kr, vr, H, False)
+    oref.backward(do.float().view(B, Sq, C))
+    res = []
+    prev = L.lib().tb_attention_set_variant(1)
+    try:
+        for variant in (1, 1 | 16384):
+            L.lib().tb_attention_set_variant(variant)
+            o = torch.empty(B * Sq, C, device="cuda", dtype=torch.float16)
+            lse = torch.empty(B, H, Sq, device="cuda")
+            ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd)
+            delta = torch.full((B, H, Sq), 7.0, device="cuda")
+            dq = torch.full((B * Sq, C + 8), 5.0, device="cuda", dtype=torch.float16)[:, :C]
+            dkv = torch.empty(B * Skv, 2 * C, device="cuda", dtype=torch.float16)
+            ws = torch.empty(8 * 2 * B * Skv * C, device="cuda")
+            ops.attention_bwd(q, k, v, o, lse, do, delta, dq, dkv[:, :C], dkv[:, C:], B, H, Sq, Skv, hd, ws=ws)
+            parity(f"short-key dQ variant {variant}", dq.reshape(B, Sq, C), qr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+            parity(f"short-key dK variant {variant}", dkv[:, :C].reshape(B, Skv, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+            parity(f"short-key dV variant {variant}", dkv[:, C:].reshape(B, Skv, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+            dref = (do.float() * o.float()).view(B, Sq, H, hd).sum(-1).permute(0, 2, 1)
+            assert (delta - dref).abs().max().item() < 2e-3 * dref.abs().max().item() + 1e-4
+            res.append(dq.clone())
+    finally:
+        L.lib().tb_attention_set_variant(prev)
+    assert rel_err(res[0], res[1]) < 1e-3
+
+
 def test_attention_online_softmax_rescale_branch():
     """Force the running max to jump at a late KV tile (cdna guide rule 26): spike one key against one query."""
     ops = _ops()

@@ -1473,6 +1473,145 @@ __global__ __launch_bounds__(256, (DT <= 2 ? TB_DQ_OCC : 1)) void attn_bwd_dq_ke
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ, short key sequences
+// The dQ half of the cross-attention backward in the form of attn_xs_fwd_kernel: the K (row-major and transposed) and V images of all <= 96
+// keys staged once, K / V held as register fragments, QT 32-query tiles per wave with all of their Q / dO / O rows requested up front, no
+// barrier in the loop.  Same arithmetic as attn_bwd_dq_kernel (scores in the log2 domain with -lse and -delta as the products' accumulator
+// inputs, dS^T = P (dP - delta), the softmax scale applied at write-out); also publishes delta = rowsum(dO * O) for the dK / dV launch.
+template <int DT, int KS, int QT>
+__global__ __launch_bounds__(256, 2) void attn_xs_bwd_dq_kernel(const tb_attn_desc p, int remap) {
+  constexpr int WD = DT * 32;
+  constexpr int TILE = 2 * RM<WD>::SIZE + TR<WD>::SIZE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16* const K0 = reinterpret_cast<f16*>(smem_raw);
+  f16* const V0 = K0 + RM<WD>::SIZE;
+  f16* const T0 = V0 + RM<WD>::SIZE;
+  f16* const K1 = K0 + TILE;
+  f16* const V1 = K1 + RM<WD>::SIZE;
+  f16* const T1 = V1 + RM<WD>::SIZE;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  AttnBlk blk;   // (query band, batch) pairs per XCD, heads back to back: see attn_xs_fwd_kernel
+  {
+    const int gx = gridDim.x, H = gridDim.y, B = gridDim.z;
+    if (remap && ((gx * B) & 7) == 0) {
+      const int lin = blockIdx.x + gx * (blockIdx.y + H * blockIdx.z);
+      const int xcd = lin & 7, k = lin >> 3;
+      const int xb = (k / H) * 8 + xcd;
+      blk.h = k - (k / H) * H;
+      blk.x = xb % gx;
+      blk.b = xb / gx;
+    } else {
+      blk.x = blockIdx.x, blk.h = blockIdx.y, blk.b = blockIdx.z;
+    }
+  }
+  const int b = blk.b, h = blk.h;
+  const int qblk = blk.x * 128 * QT;
+  const f16* Qg = (const f16*)p.Q + (int64_t)b * p.Sq * p.ldq + h * p.hd;
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * p.hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * p.hd;
+  const f16* dOg = (const f16*)p.dO + (int64_t)b * p.Sq * p.lddo + h * p.hd;
+  const f16* Og = (const f16*)p.O + (int64_t)b * p.Sq * p.ldo + h * p.hd;
+  const bool three = p.Skv > KVT;
+  f16x8 qall[QT][KS], doall[QT][KS], oall[QT][KS];
+  float lse2[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qblk + (qt * 4 + wave) * 32 + l31;
+    load_row_frags<KS>(qall[qt], Qg, p.ldq, q, p.Sq, p.hd, hi);
+    load_row_frags<KS>(doall[qt], dOg, p.lddo, q, p.Sq, p.hd, hi);
+    load_row_frags<KS>(oall[qt], Og, p.ldo, q, p.Sq, p.hd, hi);
+    lse2[qt] = p.LSE[((int64_t)b * p.H + h) * p.Sq + (q < p.Sq ? q : 0)] * LOG2E;
+  }
+  {
+    TileRegs<WD> kreg, vreg;
+    tile_init<WD>(kreg, p.ldk, p.hd);
+    tile_init<WD>(vreg, p.ldv, p.hd);
+    tile_load<WD, true>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD, true>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+    tile_store<WD, true, true>(kreg, K0, T0);
+    tile_store<WD, true, false>(vreg, V0, nullptr);
+    if (three) {
+      tile_load<WD, true>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
+      tile_load<WD, true>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
+      tile_store<WD, true, true>(kreg, K1, T1);
+      tile_store<WD, true, false>(vreg, V1, nullptr);
+    }
+  }
+  __syncthreads();
+  f16x8 kf[3][KS], vf[3][KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    kf[0][j] = frag_rm<WD>(K0, l31, 2 * j + hi);
+    kf[1][j] = frag_rm<WD>(K0, 32 + l31, 2 * j + hi);
+    kf[2][j] = frag_rm<WD>(three ? K1 : K0, l31, 2 * j + hi);
+    vf[0][j] = frag_rm<WD>(V0, l31, 2 * j + hi);
+    vf[1][j] = frag_rm<WD>(V0, 32 + l31, 2 * j + hi);
+    vf[2][j] = frag_rm<WD>(three ? V1 : V0, l31, 2 * j + hi);
+  }
+  const float c = p.scale * LOG2E;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qblk + (qt * 4 + wave) * 32 + l31;
+    const bool qok = q < p.Sq;
+    const int64_t sidx = ((int64_t)b * p.H + h) * p.Sq + (qok ? q : 0);
+    f16x8 (&qf)[KS] = qall[qt];
+    f16x8 (&dof)[KS] = doall[qt];
+    scale_frags<KS>(qf, c);
+    float a = 0.f;   // delta = rowsum(dO * O) (padding chunks of both rows are zero)
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += (float)oall[qt][j][e] * (float)dof[j][e];
+    const float delta = a + __shfl_xor(a, 32, 64);
+    if (qok && hi == 0) p.Delta[sidx] = delta;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ZERO16(dq[d]);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      if (kt < 2 || three) {
+        f32x16 sc, dp;
+        FILL16(sc, -lse2[qt]);
+        FILL16(dp, -delta);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          sc = TB_MFMA_32x32x16(kf[kt][j], qf[j], sc);
+          dp = TB_MFMA_32x32x16(vf[kt][j], dof[j], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + mfma32_row(r, hi);
+          const bool ok = qok && key < p.Skv;
+          sc[r] = ok ? fast_exp2(sc[r]) * dp[r] : 0.f;  // dS^T / scale
+        }
+        const f16* Kt = kt < 2 ? T0 : T1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const f16x8 dsf = pack8(sc, 8 * jj);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) dq[d] = TB_MFMA_32x32x16(frag_tr(Kt, d, l31, (kt & 1) * 32 + 16 * jj, hi), dsf, dq[d]);
+        }
+      }
+    }
+    if (qok) {
+      f16* dQg = (f16*)p.dQ + ((int64_t)b * p.Sq + q) * p.lddq + h * p.hd;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int col = d * 32 + 8 * r4 + 4 * hi;
+          if (col < p.hd) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(dq[d][4 * r4 + e] * p.scale);
+            *(f16x4*)(dQg + col) = v;
+          }
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dK, dV
 // qsplit > 1: blockIdx.x = key_block * qsplit + q_slice; each block covers a slice of the queries and writes its partial
 // dK/dV in fp32 to ws32[slice][{K,V}][B*Skv][H*hd]; a finalize kernel sums the slices in a fixed order (deterministic)
@@ -1787,7 +1926,18 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
         hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DT, KS, PC, NST>), grid, dim3(256), ldsq, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
       }
     }
-    if (!dq_dma) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
+    bool dq_xs = false;
+    if constexpr (DT <= 2) {
+      // short key sequences (cross-attention on the prompt): attn_xs_bwd_dq_kernel, 256 queries per workgroup (128 when Sq is an odd multiple)
+      if (!dq_dma && !dkv_dma && !d.causal && d.Skv <= 96 && d.Skv > 32 && d.Sq % 128 == 0 && d.Sq >= 1024 && !(g_attn_dma & 16384)) {
+        dq_xs = true;
+        const size_t ldsx = 2 * (2 * RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16);
+        const int rmx = ((g_attn_dma >> 2) & 1) ^ 1;
+        if (d.Sq % 256 == 0 && KS <= 3) hipLaunchKernelGGL((attn_xs_bwd_dq_kernel<DT, KS, (KS <= 3 ? 2 : 1)>), dim3(d.Sq / 256, d.H, d.B), dim3(256), ldsx, s, d, rmx);   // (KS = 4 with two tiles in flight spills)
+        else hipLaunchKernelGGL((attn_xs_bwd_dq_kernel<DT, KS, 1>), grid, dim3(256), ldsx, s, d, rmx);
+      }
+    }
+    if (!dq_dma && !dq_xs) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT, KS>), grid, dim3(256), lds, s, d, (g_attn_dma >> 6) & 1, dkv_dma ? 1 : 0);
   }
   if (dkv_dma) {
     if constexpr (DT == 2 && KS == 3) {  // hd = 40: the software-pipelined kernel (attention_il.hip)
