@@ -237,7 +237,8 @@ int tb_attention_bwd(const tb_attn_desc* d, tb_stream_t stream);
  * for hd = 40, 1024 / 2048 = the LDS-DMA forward / dK-dV kernels instead of the software-pipelined ones (csrc/attention_il.hip) for the hd = 40
  * 64x64-map shape, 4096 = the software-pipelined dQ kernel (opt-in), 8192 = the generic dQ + dK/dV launches also for short hd = 64 sequences (the CLIP
  * encoder's 77 x 77 attention otherwise takes csrc/attention_small.hip: the whole backward in one launch), 16384 = the general flash forward also for
- * short key sequences (cross-attention on the prompt, 33 .. 96 keys, otherwise attn_xs_fwd_kernel / attn_xs_bwd_dq_kernel); returns the previous value */
+ * short key sequences (cross-attention on the prompt, 33 .. 96 keys, otherwise attn_xs_fwd_kernel / attn_xs_bwd_dq_kernel), 32768 = the query-split dK / dV launch of short key sequences cuts until 1024 (not 512)
+ * workgroups exist; returns the previous value */
 int tb_attention_set_variant(int bits);
 
 /* ---- scheduler / boundary / loss / misc streaming kernels ------------------------------------------ */

@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __r
 
 int g_attn_dma = 1;  // tb_attention_set_variant(bits): 1 = LDS-DMA staged forward kernel, 2 = also for hd 80, 4 = NO XCD-aware block remap,
                      // 1024 / 2048 = LDS-DMA kernels instead of the software-pipelined forward / dK-dV kernels (attention_il.hip), 4096 = the
-                     // software-pipelined dQ kernel (opt-in), 16384 = the general flash kernel also for short key sequences (no attn_xs_fwd_kernel),
+                     // software-pipelined dQ kernel (opt-in), 16384 = the general flash kernel also for short key sequences (no attn_xs_fwd_kernel), 32768 = query slices of the cross-attention dK / dV launch until 1024 (not 512) workgroups,
                      // 32 = one query group per wave, 64 = XCD remap also in the backward kernels (measured: forward +14 %, backward -5 %)
                      // (A/B knobs; 8 / 16 = load-path ablations of the DMA kernel)
 
@@ -1972,7 +1972,10 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     const int64_t C = (int64_t)d.H * d.hd;
     const int64_t plane2 = 2 * (int64_t)d.B * d.Skv * C;
     if (d.ws && d.ws_floats >= 2 * plane2 && !d.causal && nblk < 512) {
-      qsplit = (int)((1024 + nblk - 1) / nblk);
+      // slices until ~512 workgroups exist: every slice costs a plane of fp32 partials that the finalize launch reads back (memory-bound: 25 MB
+      // and 7.7 us per 64x64-map layer at 16 slices) -- sustained A/B of the step: 1024 -> 512 workgroups -0.13 ms, 256 -0.11, 128 +0.11
+      const int target = (g_attn_dma & 32768) ? 1024 : 512;
+      qsplit = (int)((target + nblk - 1) / nblk);
       const int max_split = (d.Sq + KVT - 1) / KVT;
       if (qsplit > max_split) qsplit = max_split;
       if ((int64_t)qsplit * plane2 > d.ws_floats) qsplit = (int)(d.ws_floats / plane2);
