@@ -186,7 +186,7 @@ def test_attention_fwd_software_pipelined_kernel(B, H, Sq, Skv):
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,hd", [(2, 8, 4096, 77, 40), (8, 8, 4096, 77, 40), (2, 8, 1024, 77, 40), (1, 5, 1152, 77, 64), (2, 4, 1024, 50, 40),
-                                           (1, 3, 2048, 96, 24), (1, 2, 1280, 65, 8)])
+                                           (1, 3, 2048, 96, 24), (1, 2, 1280, 65, 8), (2, 8, 1024, 77, 80), (1, 4, 1152, 77, 96)])
 def test_attention_fwd_short_key_kernel(B, H, Sq, Skv, hd):
     """attn_xs_fwd_kernel (round 4): cross-attention on the prompt (33 .. 96 keys, hd <= 64, >= 1024 queries) with all keys staged once, K held in
     registers and 1 / 2 / 4 query tiles per wave, against fp32 attention and against the general flash kernel it replaces for these shapes

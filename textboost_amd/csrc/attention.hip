@@ -485,13 +485,13 @@ __global__ __launch_bounds__(256, 2) void attn_xs_fwd_kernel(const tb_attn_desc 
     TileRegs<WD> kreg, vreg;
     tile_init<WD>(kreg, p.ldk, p.hd);
     tile_init<WD>(vreg, p.ldv, p.hd);
-    tile_load<WD, true>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
-    tile_load<WD, true>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
+    tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, 0, p.Skv, p.hd);
+    tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, 0, p.Skv, p.hd);
     tile_store<WD, true, false>(kreg, K0, nullptr);
     tile_store<WD, false, true>(vreg, nullptr, V0);
     if (three) {
-      tile_load<WD, true>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
-      tile_load<WD, true>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(kreg, Kg, p.ldk, KVT, p.Skv, p.hd);
+      tile_load<WD, (DT <= 2)>(vreg, Vg, p.ldv, KVT, p.Skv, p.hd);
       tile_store<WD, true, false>(kreg, K1, nullptr);
       tile_store<WD, false, true>(vreg, nullptr, V1);
     }
@@ -1854,13 +1854,13 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
       return TB_OK;
     }
   }
-  if constexpr (DT <= 2) if (!d.causal && d.Skv <= 96 && d.Skv > 32 && d.hd % 8 == 0 && d.Sq % 128 == 0 && d.Sq >= 1024 && !(g_attn_dma & 16384)) {
+  if constexpr (DT <= 3) if (!d.causal && d.Skv <= 96 && d.Skv > 32 && d.hd % 8 == 0 && d.Sq % 128 == 0 && d.Sq >= 1024 && !(g_attn_dma & 16384)) {
     // short key sequences (cross-attention on the prompt): attn_xs_fwd_kernel, 256 or 512 queries per workgroup
-    const int qtiles = d.Sq % 512 == 0 && (int64_t)(d.Sq / 512) * d.H * d.B >= 512 ? 4 : (d.Sq % 256 == 0 ? 2 : 1);
+    const int qtiles = DT <= 2 && d.Sq % 512 == 0 && (int64_t)(d.Sq / 512) * d.H * d.B >= 512 ? 4 : (d.Sq % 256 == 0 ? 2 : 1);   // (hd > 64: four tiles of Q do not fit)
     const size_t ldsx = (RM<WD>::SIZE + TR<WD>::SIZE) * sizeof(f16) * 2;
     const int rmx = ((g_attn_dma >> 2) & 1) ^ 1;
     const dim3 gx((unsigned)(d.Sq / (128 * qtiles)), d.H, d.B);
-    if (qtiles == 4) hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, 4>), gx, dim3(256), ldsx, s, d, rmx);
+    if (qtiles == 4) hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, (DT <= 2 ? 4 : 2)>), gx, dim3(256), ldsx, s, d, rmx);
     else if (qtiles == 2) hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, 2>), gx, dim3(256), ldsx, s, d, rmx);
     else hipLaunchKernelGGL((attn_xs_fwd_kernel<DT, KS, 1>), gx, dim3(256), ldsx, s, d, rmx);
     TB_CHECK_LAUNCH();
