@@ -537,7 +537,15 @@ def test_unet_crossattn_kv_lora_step_matches_oracle(tmp_path):
     ckpt.save_unet_adapters(hip_unet, str(tmp_path / "unet"), "base")
     from safetensors.torch import load_file
     sd = load_file(str(tmp_path / "unet" / "adapter_model.safetensors"))
-    assert len(sd) == 64 and sd["mid_block.attentions.0.transformer_blocks.0.attn2.to_v.lora_A.default.weight"].shape == (r, D)
+    # peft's adapter layout: adapter name stripped, `base_model.model.` prefix -- what set_peft_model_state_dict accepts; round trip
+    assert len(sd) == 64 and sd["base_model.model.mid_block.attentions.0.transformer_blocks.0.attn2.to_v.lora_A.weight"].shape == (r, D)
+    assert not any(".default." in k for k in sd)
+    hip_unet.kv_lora_A.zero_(); hip_unet.kv_lora_B.zero_()
+    ckpt.load_unet_peft_adapter_state_dict(hip_unet, {k: v.cuda() for k, v in sd.items()})
+    assert torch.equal(hip_unet.kv_lora_A, A0) and torch.equal(hip_unet.kv_lora_B, B0)
+    import json
+    cfg = json.load(open(tmp_path / "unet" / "adapter_config.json"))
+    assert set(cfg) == set(ckpt.adapter_config(r, "base"))   # a pure LoraConfig: no extra keys
 
 
 def test_validation_sampler_unet_gets_the_crossattn_kv_adapters_folded_in():

@@ -593,6 +593,30 @@ def test_upsampler_convolution_as_sub_pixel_convolutions(B, C, Hc):
                  conv=dict(B=2, Hin=8, Win=8, Cin=64, Hout=16, Wout=16, stride=1, sign=1, upsample=2, transposed=0))
 
 
+def test_sub_pixel_descs_never_reach_the_four_wave_kernel():
+    """with the 8-wave family switched off (tb_gemm8_set(0), the documented A/B switch) a sub-pixel desc must be refused -- the 4-wave
+    kernel would read `upsample != 0` as the folded 9-tap gather over a K = 4 Cin / 16 Cin weight -- and `subpixel_ok` must say so, so that HipUNet
+    keeps the 9-tap form."""
+    ops, L = _ops()
+    B, C, Hc = 8, 640, 32
+    assert ops.subpixel_ok(B, Hc, Hc, C, C)
+    w = (torch.randn(C, C, 3, 3, device="cuda") / (3 * C ** 0.5)).half()
+    wf, wd = ops.pack_subpixel_weights(w)
+    xn = torch.randn(B * Hc * Hc, C, device="cuda").half()
+    out = torch.empty(B * 4 * Hc * Hc, C, device="cuda", dtype=torch.float16)
+    dx = torch.empty(B * Hc * Hc, C, device="cuda", dtype=torch.float16)
+    old = L.lib().tb_gemm8_set(0)
+    try:
+        assert not ops.subpixel_ok(B, Hc, Hc, C, C)
+        with pytest.raises(RuntimeError):
+            ops.gemm(xn, wf, out, conv=dict(B=B, Hin=Hc, Win=Hc, Cin=C, Hout=2 * Hc, Wout=2 * Hc, stride=1, sign=1, upsample=2, transposed=0))
+        with pytest.raises(RuntimeError):
+            ops.gemm(out, wd, dx, conv=dict(B=B, Hin=2 * Hc, Win=2 * Hc, Cin=C, Hout=Hc, Wout=Hc, stride=1, sign=1, upsample=3, transposed=0))
+    finally:
+        L.lib().tb_gemm8_set(old)
+    assert ops.subpixel_ok(B, Hc, Hc, C, C)
+
+
 @pytest.mark.parametrize("M,N,bias,res", [(32768, 320, True, True), (32768, 960, False, False), (25600, 1280, True, False), (32768, 128, False, True)])
 def test_linear_k320_activation_stationary_kernel(M, N, bias, res):
     """csrc/lin320.hip (round 4): the K = 320 Linear layers of the 64x64 maps with the 128-row activation tile register-resident, against torch

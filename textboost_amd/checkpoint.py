@@ -69,18 +69,30 @@ def load_unet_lora_state_dict(unet, sd):
             unet.kv_lora_B[ko + j * C:ko + (j + 1) * C].copy_(sd[f"{p}.{name}.lora_B.default.weight"])
 
 
+def unet_peft_adapter_state_dict(unet) -> Dict[str, torch.Tensor]:
+    """the same tensors under the keys peft 0.13.2 writes into `adapter_model.safetensors` (`get_peft_model_state_dict`: adapter name stripped,
+    `base_model.model.` prefix), i.e. what `set_peft_model_state_dict` / `PeftModel.from_pretrained` accept -- as `lora_state_dict` does for the encoder"""
+    return {"base_model.model." + k.replace(".default.weight", ".weight"): v for k, v in unet_lora_state_dict(unet).items()}
+
+
+def load_unet_peft_adapter_state_dict(unet, sd):
+    load_unet_lora_state_dict(unet, {k[len("base_model.model."):].replace(".weight", ".default.weight"): v for k, v in sd.items()})
+
+
 def save_unet_adapters(unet, out_dir: str, base_model_name_or_path: str):
     """<out>/unet/ (:1237-1239).  The reference's `unet.save_pretrained` writes the WHOLE fp32 UNet (3.4 GB: the frozen base weights under
     `.base_layer.` names plus the adapters); no reader of the output layout loads it (inference.py / eval_dreambooth.py never open unet/).
     Written here in peft's adapter layout, so that the file name does not promise a loadable diffusers model: `adapter_model.safetensors` (the
     adapter tensors under the parameter names `unet.add_adapter` gives them) + `adapter_config.json` naming the base model whose weights are unchanged."""
     os.makedirs(out_dir, exist_ok=True)
-    save_file(unet_lora_state_dict(unet), os.path.join(out_dir, "adapter_model.safetensors"), metadata={"format": "pt"})
-    cfg = adapter_config(unet.kv_r, base_model_name_or_path)
+    save_file(unet_peft_adapter_state_dict(unet), os.path.join(out_dir, "adapter_model.safetensors"), metadata={"format": "pt"})
+    cfg = adapter_config(unet.kv_r, base_model_name_or_path)          # a pure peft LoraConfig: LoraConfig(**json) must accept every key
     cfg["target_modules"] = ["attn2.to_k", "attn2.to_v"]
-    cfg["base_weights"] = "unchanged (frozen): load them from base_model_name_or_path/unet"
     with open(os.path.join(out_dir, "adapter_config.json"), "w") as f:
         json.dump(cfg, f, indent=2, sort_keys=True)
+    with open(os.path.join(out_dir, "README.txt"), "w") as f:
+        f.write("adapter_model.safetensors holds the cross-attention K/V LoRA tensors only (peft adapter layout). The UNet's base weights are frozen "
+                "and unchanged: load them from <base_model_name_or_path>/unet.\n")
 
 
 def adapter_config(rank: int, base_model_name_or_path: str) -> dict:

@@ -1170,6 +1170,8 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     if (r8 != 1) return r8;
   }
   if (d.act == TB_ACT_LN_FWD || d.act == TB_ACT_LN_BWD) return TB_EINVAL;  // exist in the row-spanning wide tiles only
+  // the sub-pixel descs exist in the 8-wave kernel only: the 4-wave kernel would read `upsample != 0` as the folded 9-tap gather (wrong K / weight layout)
+  if (d.a_mode == TB_A_CONV3X3 && (d.upsample == 2 || d.upsample == 3)) return TB_EINVAL;
   if (d.act == TB_ACT_GEGLU) {
     if (d.N % 128 || d.R || d.rowbias || d.c_dtype != TB_F16) return TB_EINVAL;
     if (d.a_mode != TB_A_LINEAR) return TB_EINVAL;

@@ -1080,6 +1080,7 @@ extern "C" int tb_gemm8_last(int* out5 /* 6 ints */) {
 
 // can the nearest-x2 + conv3x3 pair over a coarse [B, Hc, Wc, Cin] map run as sub-pixel convolutions (tb_gemm_desc.upsample == 2 / 3)?
 extern "C" int tb_gemm_subpixel_ok(int B, int Hc, int Wc, int Cin, int N) {
+  if (!g8_enable) return 0;                          // the sub-pixel descs exist in this kernel family only (tb_gemm8_set(0): callers keep the 9-tap form)
   if (B <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cin % 64 || N <= 0 || N % 80) return 0;
   int sh = 0;
   while (sh < 6 && !(Wc & (1 << sh))) ++sh;

@@ -43,8 +43,7 @@ def build_step(batch=8, latent=64, unet_geo: UNetGeometry = models.SD15_UNET, cl
     bfloat16 build of the library (`_lib.set_half("bf16")`)."""
     assert precision in ("fp16", "fp32", "bf16")
     from . import _lib
-    if precision != "fp32":
-        _lib.set_half(precision)
+    _lib.set_half("fp16" if precision == "fp32" else precision)   # (fp32 mode: the 16-bit helpers -- VAE, sampler -- are the fp16 build's)
     f32 = precision == "fp32"
     hyper = hyper or (StepHyper(use_grad_scaler=False, init_scale=1.0) if precision != "fp16" else StepHyper())
     usd = models.random_state_dict(models.unet_shapes(unet_geo), weight_seed, device=device)

@@ -245,6 +245,10 @@ def main(args):
                                   "every other value trains nothing in the UNet and only writes an unchanged copy of it to <output_dir>/unet")
     if args.unet_params_to_train == "crossattn_kv":
         if not fp32_mode:
+            if args.mixed_precision == "bf16":
+                raise NotImplementedError("--unet_params_to_train crossattn_kv under --mixed_precision bf16 is not built here (the reference trains the "
+                                          "bf16-cast adapter parameters directly, :937, no GradScaler): a capability gap, listed in INTEGRATION.md; "
+                                          "run it without --mixed_precision (fp32)")
             raise NotImplementedError("--unet_params_to_train crossattn_kv needs the fp32 (no --mixed_precision) mode: under fp16 the reference "
                                       "casts the UNet's freshly added LoRA parameters to fp16 (:937) and GradScaler.unscale_ rejects them")
         if args.lora_rank <= 0:
