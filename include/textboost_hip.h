@@ -89,12 +89,29 @@ typedef struct tb_gemm_desc {
    * reduction, the conv epilogue and the GroupNorm in one launch).  *split_out = 1 means the launch was not split and C holds the result as
    * usual.  Honoured for act NONE, fp16 C, alpha == 1 and no C2; never for the phase-ordered stride-2 dgrad. */
   int32_t* split_out;
+  /* LayerNorm folded into the Linear that CONSUMES it (round 5; torch.nn.LayerNorm norm1 / norm2 / norm3 of diffusers BasicTransformerBlock in front
+   * of attn1.to_q/k/v, attn2.to_q and ff.net.0.proj, train_textboost.py:1063-1067; gamma / beta are frozen):
+   *     LN(x) W^T + b  =  rstd (x W'^T - mean c1) + c2,   W' = gamma (.) W (fp16, packed once by the host), c1[n] = sum_k W'[n,k], c2 = b + W beta
+   * so the consumer multiplies the RAW residual stream and the LayerNorm is two per-row scalars in its epilogue -- no LayerNorm launch, no
+   * normalised copy in memory.  The row statistics come from the launch that PRODUCES x:
+   *   rs_out (producer): fp32 [M][rs_ld][2]; the launch writes, for its column tile tn, slot tn of row m = (sum, sum of squares) of the fp16-ROUNDED
+   *          output row over the tile's columns.  8-wave Linear tiles only (act NONE, fp16 C; tb_gemm8_last tells the tile width = N / slots in use);
+   *          tb_gemm returns -22 when the launch would take another kernel.
+   *   rs_in  (consumer): the producer's rs_out with rs_n slots per row in use (row stride rs_ld slots).  Per row: mean = S / K, var = Q / K - mean^2
+   *          (K = the LayerNorm width), rstd = rsqrt(var + ln_eps); epilogue v = rstd (alpha acc - mean ln_gamma[n]) + bias[n] (+ R) for act NONE,
+   *          the same in front of the gate for GEGLU; ln_gamma = c1 (fp32 [N], in W's row order), bias = c2.  When ln_stats != NULL the column
+   *          tile 0 of every row panel writes (mean, rstd) to ln_stats[m] for tb_layernorm_bwd.  rs_n <= 16; no second K source. */
+  float* rs_out; const float* rs_in; int64_t rs_ld; int32_t rs_n;
 } tb_gemm_desc;
 
 int tb_gemm(const tb_gemm_desc* d, tb_stream_t stream);
 /* 1 when a fp16 Linear of this shape takes a tile that spans the whole output row, i.e. TB_ACT_LN_FWD / TB_ACT_LN_BWD are available for it
  * (N == 320, K % 64 == 0, M a multiple of the tile height with at least one chip round of tiles); tb_gemm returns -22 for them otherwise */
 int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K);
+/* 1 when the three LayerNorms of a BasicTransformerBlock of width C over M rows can be folded into the Linear layers behind them
+ * (tb_gemm_desc.rs_out / rs_in): the residual-stream producers (M x C x C) write row statistics and qkv (M x 3C x C), attn2.to_q (M x C x C) and
+ * the GEGLU projection (M x 8C x C) take tiles that apply the fold; *slots = statistic slots per row the producers fill (the consumers' rs_n) */
+int tb_gemm_lnfold_ok(int64_t M, int64_t C, int* slots);
 /* 1 when the pair nearest-x2 upsampling + conv3x3 (diffusers Upsample2D, up_blocks.*.upsamplers.0; train_textboost.py:1063-1067 forward, :1108
  * backward) over a coarse [B, Hc, Wc, Cin] map can run as four 2 x 2-tap SUB-PIXEL convolutions with pre-summed weights (2.25x fewer FLOP, the 4x
  * map is never written): tb_gemm with a_mode = CONV3X3 and

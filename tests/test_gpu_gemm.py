@@ -713,3 +713,84 @@ def test_linear_long_k_two_slices_of_128x160_tiles(K, bias, res):
     ref = A.float() @ W.float().T + (b if bias else 0) + (R.float() if res else 0)
     parity("long-K Linear, two k-slices of 128 x 160 tiles", outs[0], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
     assert rel_err(outs[0], outs[1]) < 3e-4
+
+
+@pytest.mark.parametrize("M,C", [(8192, 640), (2048, 1280)])
+def test_layernorm_folded_into_the_consuming_linear(M, C):
+    """round 5 (tb_gemm_desc.rs_out / rs_in; torch.nn.LayerNorm norm1 / norm2 / norm3 of diffusers BasicTransformerBlock in front of attn1.to_q/k/v,
+    attn2.to_q, ff.net.0.proj -- train_textboost.py:1063-1067): the producer of the residual stream writes per-column-tile (sum, sum of squares) of
+    its fp16 output rows; the Linear behind the LayerNorm multiplies the RAW stream by gamma-folded weights and applies (mean, rstd) in its epilogue.
+    Against torch fp32 (LayerNorm -> Linear / GEGLU) and against the launches it replaces (tb_layernorm_fwd + tb_gemm); non-zero row means and a
+    gamma / beta far from (1, 0) so that a dropped mean, c1 or c2 term fails."""
+    ops, L = _ops()
+    torch.manual_seed(41)
+    slots = ops.lnfold_slots(M, C)
+    assert slots > 0
+    o = torch.randn(M, C, device="cuda").half()
+    Wo = (torch.randn(C, C, device="cuda") / C ** 0.5).half()
+    bo = torch.randn(C, device="cuda")
+    R = (torch.randn(M, C, device="cuda") * 0.7 + torch.randn(M, 1, device="cuda")).half()     # a row mean of order 1
+    gamma, beta = 1 + 0.5 * torch.randn(C, device="cuda"), 0.3 * torch.randn(C, device="cuda")
+    # ---- producer: x = o Wo^T + bo + R, plus the row statistics
+    x = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    rs = torch.full((M, 16, 2), 7.0, device="cuda")
+    ops.gemm(o, Wo, x, bias=bo, R=R, rs_out=rs)
+    x_plain = torch.empty_like(x)
+    ops.gemm(o, Wo, x_plain, bias=bo, R=R)
+    assert torch.equal(x, x_plain)                                   # the statistics do not change the product
+    assert (rs[:, slots:] == 7.0).all()                              # only the slots in use are written
+    tw = C // slots
+    xs = x.float().view(M, slots, tw)
+    assert torch.allclose(rs[:, :slots, 0], xs.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(rs[:, :slots, 1], (xs * xs).sum(-1), rtol=1e-5, atol=1e-3)
+    ln_ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    mean_ref, rstd_ref = x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    # the launches the fold replaces: tb_layernorm_fwd -> tb_gemm
+    l = torch.empty_like(x)
+    st_old = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, l, gamma, beta, st_old)
+    # ---- consumers: qkv (N = 3C, no bias), attn2.to_q (N = C), the GEGLU projection (N = 8C, packed rows)
+    for N, has_bias in ((3 * C, False), (C, False)):
+        W = (torch.randn(N, C, device="cuda") / C ** 0.5).half()
+        b = torch.randn(N, device="cuda") if has_bias else None
+        Wp, c1, c2 = ops.fold_layernorm(W, gamma, beta, b)
+        out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+        st = torch.zeros(M, 2, device="cuda")
+        ops.gemm(x, Wp, out, bias=c2, lnfold=(rs, slots, c1, st, 1e-5))
+        ref = ln_ref @ W.float().T + (b if b is not None else 0)
+        parity(f"folded LN -> Linear {M}x{N}x{C}", out, ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+        old = torch.empty_like(out)
+        ops.gemm(l, W, old, bias=b)
+        assert rel_err(out, old) < 2e-3
+        assert torch.allclose(st[:, 0], mean_ref, rtol=1e-4, atol=1e-4) and torch.allclose(st[:, 1], rstd_ref, rtol=2e-4, atol=1e-5)
+        assert torch.allclose(st, st_old, rtol=3e-4, atol=2e-4)
+    from textboost_amd.unet import pack_geglu_rows
+    Wff = torch.randn(8 * C, C, device="cuda") / C ** 0.5
+    bff = torch.randn(8 * C, device="cuda")
+    Wp, c1, c2 = ops.fold_layernorm(pack_geglu_rows(Wff), gamma, beta, pack_geglu_rows(bff))
+    gated = torch.empty(M, 4 * C, device="cuda", dtype=torch.float16)
+    raw = torch.empty(M, 8 * C, device="cuda", dtype=torch.float16)
+    st = torch.zeros(M, 2, device="cuda")
+    ops.gemm(x, Wp, gated, bias=c2, act=L.ACT_GEGLU, C2=raw, lnfold=(rs, slots, c1, st, 1e-5))
+    proj = ln_ref @ Wff.half().float().T + bff
+    h, g = proj.chunk(2, dim=1)
+    parity(f"folded LN -> GEGLU {M}x{8 * C}x{C}", gated, h.half().float() * F.gelu(g.half().float()), rel=3e-3, maxabs=6e-3, ch_dim=1, ch_rel=4e-3)
+    parity("folded LN -> GEGLU pre-gate projections", raw, pack_geglu_rows(proj.T.contiguous()).T, rel=2e-3, maxabs=4e-3)
+    gated_old, raw_old = torch.empty_like(gated), torch.empty_like(raw)
+    ops.gemm(l, pack_geglu_rows(Wff).half(), gated_old, bias=pack_geglu_rows(bff), act=L.ACT_GEGLU, C2=raw_old)
+    assert rel_err(gated, gated_old) < 3e-3 and rel_err(raw, raw_old) < 2e-3
+    assert torch.allclose(st[:, 1], rstd_ref, rtol=2e-4, atol=1e-5)
+    # backward: the dgrad through W' carries gamma, so tb_layernorm_bwd runs with gamma = 1
+    dy = torch.randn(M, C, device="cuda").half()
+    W = (torch.randn(C, C, device="cuda") / C ** 0.5).half()
+    Wp, c1, c2 = ops.fold_layernorm(W, gamma, beta)
+    g_f = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.gemm(dy, Wp.t().contiguous(), g_f)
+    dx = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.layernorm_bwd(g_f, x, torch.ones(C, device="cuda"), st, dx)
+    xr = x.float().requires_grad_(True)
+    (F.layer_norm(xr, (C,), gamma, beta, 1e-5) @ W.float().T).backward(dy.float())
+    parity("folded LN backward", dx, xr.grad, rel=3e-3, maxabs=6e-3)
+    # requests the tiles cannot serve are refused
+    with pytest.raises(RuntimeError):
+        ops.gemm(o[:512], Wo, x[:512], bias=bo, R=R[:512], rs_out=rs[:512].contiguous())      # 4 row tiles: not an 8-wave one-per-CU launch

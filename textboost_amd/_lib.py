@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
         ("sync", C.c_void_p), ("sync_count", C.c_int64),
         ("split_out", C.POINTER(C.c_int32)),
+        ("rs_out", C.c_void_p), ("rs_in", C.c_void_p), ("rs_ld", C.c_int64), ("rs_n", C.c_int32),
     ]
 
 
@@ -86,6 +87,7 @@ _SIGS = {
     "tb_gemm": ([C.POINTER(GemmDesc), _VP], C.c_int),
     "tb_gemm_ln_epilogue_ok": ([C.c_int64, C.c_int64, C.c_int64], C.c_int),
     "tb_gemm_subpixel_ok": ([_I, _I, _I, _I, _I], C.c_int),
+    "tb_gemm_lnfold_ok": ([_I64, _I64, C.POINTER(C.c_int)], C.c_int),
     "tb_ff_fused_ok": ([C.c_int64, _I, _I], C.c_int),
     "tb_ff_fwd": ([C.POINTER(FfDesc), _VP], C.c_int),
     "tb_ff_bwd": ([C.POINTER(FfDesc), _VP], C.c_int),

@@ -111,6 +111,26 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
   //  (b) barrier; (c) thread t walks (row, 8-column group) units: bias / residual / activation / stores in 16-byte vectors.
   float* Cs = reinterpret_cast<float*>(smem_raw);
   const EpiFlags ef = epi_flags(p);
+  // LayerNorm folded into this Linear (tb_gemm_desc.rs_in, see the header): thread t < BM turns the producer's per-tile (sum, sum of squares)
+  // partials of tile row t into (mean, rstd), kept behind the staging tile (launch_v adds the bytes); the staging barrier below publishes them
+  typedef __attribute__((ext_vector_type(2))) float f32x2e;
+  const bool lnf = p.rs_in != nullptr && S == 1;
+  f32x2e* const rowst = reinterpret_cast<f32x2e*>(smem_raw + (size_t)(BM / PASSES) * BN * sizeof(float));
+  if (lnf && t < BM) {
+    const int64_t mr = m0 + t < p.M ? m0 + t : p.M - 1;
+    const f32x2e* src = reinterpret_cast<const f32x2e*>(p.rs_in) + mr * p.rs_ld;
+    const int rn = p.rs_n;
+    f32x2e pv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pv[j] = j < rn ? src[j] : f32x2e{0.f, 0.f};
+    float sx = 0.f, sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sx += pv[j][0], sq += pv[j][1];
+    const float inv_k = 1.f / (float)p.K, mean = sx * inv_k;
+    const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
+    rowst[t] = f32x2e{mean, rstd};
+    if (n0 == 0 && p.ln_stats && m0 + t < p.M) *reinterpret_cast<f32x2e*>(p.ln_stats + 2 * (m0 + t)) = f32x2e{mean, rstd};
+  }
   // lean-path eligibility and the descriptor fields it uses (block-uniform; see the `fast` branch below)
   const int64_t Mtot = p.M, ldc = p.ldc, ldr = p.ldr;
   const int64_t m_first = m0, m_last_ = m0 + (int64_t)((BM - 1) >> mshift) * mstride + ((BM - 1) & ((1 << mshift) - 1));
@@ -242,6 +262,9 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
 #pragma unroll
             for (int e = 0; e < 8; ++e) b8[e] += rb[e];
           }
+          float c18[8];   // folded LayerNorm: c1 of this thread's 8 columns
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c18[e] = lnf ? p.ln_gamma[n + e] : 0.f;
           float r8[NU][8];
 #pragma unroll
           for (int it = 0; it < NU; ++it) {
@@ -280,10 +303,17 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[4 * q + e] = a[e];
             }
+            if (lnf) {
+              const f32x2e rs = rowst[rp + row];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              v[e] = v[e] * alpha + b8[e] + r8[it][e];
-              if (silu) v[e] = silu_f(v[e]);
+              for (int e = 0; e < 8; ++e) v[e] = rs[1] * (v[e] * alpha - rs[0] * c18[e]) + b8[e] + r8[it][e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + b8[e] + r8[it][e];
+            }
+            if (silu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
             }
             if (act_gelu) {  // the fp16-rounded linear output feeds the activation, as under autocast; it is what the backward re-reads
               f16x8 pre;
@@ -899,9 +929,13 @@ int launch_v(const tb_gemm_desc& d, hipStream_t s, int S) {
   size_t lds = (size_t)NST * (BM + BN) * BKT * sizeof(f16);
   const size_t epi = (size_t)BM * BN * sizeof(float) / (BKT == 32 ? 2 : 1);  // epilogue stages the fp32 tile in LDS (two halves for BK32)
   if (lds < epi) lds = epi;
+  if (d.rs_in) {   // (mean, rstd) per tile row behind the epilogue's staging tile
+    if (S > 1) return TB_EINVAL;
+    if (lds < epi + BM * 8) lds = epi + BM * 8;
+  }
   static bool attr_done = false;
-  if (!attr_done && lds > 65536) {
-    if (hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+  if (!attr_done && lds + 1024 > 65536) {
+    if (hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 1024)) !=
         hipSuccess)
       return TB_ELAUNCH;
     attr_done = true;
@@ -1170,6 +1204,14 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     if (r8 != 1) return r8;
   }
   if (d.act == TB_ACT_LN_FWD || d.act == TB_ACT_LN_BWD) return TB_EINVAL;  // exist in the row-spanning wide tiles only
+  if (d.rs_out) return TB_EINVAL;                                           // row statistics are written by the 8-wave Linear tiles only
+  if (d.rs_in) {   // folded LayerNorm (consumer): the lean epilogue of the un-split 4-wave tiles (the 16x16-map qkv projection)
+    if (d.act != TB_ACT_NONE || d.a_mode != TB_A_LINEAR || d.A2 || d.C2 || d.rowbias || d.c_dtype != TB_F16 || d.ldc % 8 || ((uintptr_t)d.C) % 16 ||
+        (d.R && (d.ldr % 8 || ((uintptr_t)d.R) % 16)) || d.N % 8 || !d.ln_gamma || d.rs_n < 1 || d.rs_n > 16 || d.rs_ld < d.rs_n ||
+        ((uintptr_t)d.rs_in) % 8 || ((uintptr_t)d.ln_stats) % 8)
+      return TB_EINVAL;
+    d.ws = nullptr, d.ws_bytes = 0;   // never split K: the reducer does not know the fold
+  }
   // the sub-pixel descs exist in the 8-wave kernel only: the 4-wave kernel would read `upsample != 0` as the folded 9-tap gather (wrong K / weight layout)
   if (d.a_mode == TB_A_CONV3X3 && (d.upsample == 2 || d.upsample == 3)) return TB_EINVAL;
   if (d.act == TB_ACT_GEGLU) {

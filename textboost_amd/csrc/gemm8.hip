@@ -97,6 +97,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
   }
 }
 
+__device__ __forceinline__ int64_t m0p_of(int tm, int bm) { return (int64_t)tm * bm; }  // first row of Linear row panel tm
+
 // WM x WN waves (WM * WN == 8), each wave (16 MT) x (16 NT) outputs; CONV: 3x3 stride-1 halo convolution, else A rows linear
 //
 // SUB (round 4): the nearest-x2 upsampler convolutions (diffusers Upsample2D = F.interpolate(x, 2, "nearest") + conv3x3: up_blocks.*.upsamplers.0) as
@@ -170,15 +172,32 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // (The conv tiles have no LDS to spare -- 160 KB exactly at 64-wide feature maps -- and amortise it over 45+ k-steps.)
   constexpr int OPB = CONV ? 0 : NS * (BM + BN) * 128;
   constexpr int EPB = (int)G8Epi<BM, BN>::BYTES;
-  float* const bias_s = reinterpret_cast<float*>(smem_raw + (OPB > EPB ? OPB : EPB));
+  constexpr int REDB = (CONV || BM * BN > 128 * 160) ? 0 : (int)(G8Epi<BM, BN>::PR * (BN / 8) * 8);   // row-statistic partials of a producer launch (rs_out), behind the staging tile
+  const int boff = (!CONV && p.rs_out && (OPB > EPB ? OPB : EPB) < EPB + REDB) ? EPB + REDB : (OPB > EPB ? OPB : EPB);   // (launch8 sizes the LDS the same way)
+  float* const bias_s = reinterpret_cast<float*>(smem_raw + boff);
   float bias_v = 0.f;
   if (!CONV && t < BN && p.bias) bias_v = p.bias[n0 + t];
   // fused-LayerNorm epilogues (TB_ACT_LN_FWD / TB_ACT_LN_BWD; host: the tile spans the row, n0 == 0): gamma / beta take the same route
   const bool ln_epi = !CONV && (p.act == TB_ACT_LN_FWD || p.act == TB_ACT_LN_BWD);
+  // LayerNorm folded into THIS Linear (tb_gemm_desc.rs_in): c1 = ln_gamma rides in the gamma slot; thread t < BM sums the producer's per-tile
+  // (sum, sum of squares) partials of row m0 + t -- requested here, in front of the operand prologue, consumed next to bias_s below
+  constexpr bool RS_OK = !CONV && BM * BN <= 128 * 160;   // (the 128x320 tile sits at 243 registers: no room; launch8 refuses the request there)
+  const bool lnf = RS_OK && p.rs_in != nullptr;
   float gam_v = 0.f, bet_v = 0.f;
-  if (ln_epi && t < BN) {
+  if ((ln_epi || lnf) && t < BN) {
     gam_v = p.ln_gamma[n0 + t];
     if (p.act == TB_ACT_LN_FWD) bet_v = p.ln_beta[n0 + t];
+  }
+  typedef __attribute__((ext_vector_type(2))) float f32x2r_t;
+  f32x2r_t rs_part[RS_OK ? 8 : 1];   // slots 0 .. 7 (slots 8 .. 15, when in use, are added where these are consumed)
+  if constexpr (RS_OK) {
+    if (lnf && t < BM) {
+      const int64_t mrow = min(m0p_of(tm, BM) + t, p.M - 1);
+      const f32x2r_t* src = reinterpret_cast<const f32x2r_t*>(p.rs_in) + mrow * p.rs_ld;
+      const int rn = p.rs_n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rs_part[j] = j < rn ? src[j] : f32x2r_t{0.f, 0.f};
+    }
   }
   // epilogue unit geometry (used early by the residual prefetch): a thread keeps ONE 8-column group and walks rows
   using E = G8Epi<BM, BN>;
@@ -395,7 +414,31 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
   if (!CONV && t < BN) {
     bias_s[t] = bias_v;
-    if (ln_epi) bias_s[BN + t] = gam_v, bias_s[2 * BN + t] = bet_v;
+    if (ln_epi || lnf) bias_s[BN + t] = gam_v, bias_s[2 * BN + t] = bet_v;
+  }
+  f32x2r_t* const rowst_s = reinterpret_cast<f32x2r_t*>(bias_s + 3 * BN);   // [BM] (mean, rstd) of the folded LayerNorm
+  if constexpr (RS_OK) {
+    if (lnf && t < BM) {
+      float sx = 0.f, sq = 0.f;
+      if (p.rs_n > 8) {   // (uniform; the 16x16-map producers' 16 tiles of 80 columns)
+        const f32x2r_t* src = reinterpret_cast<const f32x2r_t*>(p.rs_in) + min(m0 + t, p.M - 1) * p.rs_ld;
+        const int rn = p.rs_n;
+        f32x2r_t hi8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hi8[j] = 8 + j < rn ? src[8 + j] : f32x2r_t{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sx += rs_part[j][0], sq += rs_part[j][1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sx += hi8[j][0], sq += hi8[j][1];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sx += rs_part[j][0], sq += rs_part[j][1];
+      }
+      const float inv_k = 1.f / (float)p.K, mean = sx * inv_k;
+      const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
+      rowst_s[t] = f32x2r_t{mean, rstd};
+      if (tn == 0 && p.ln_stats && m0 + t < p.M) *reinterpret_cast<f32x2r_t*>(p.ln_stats + 2 * (m0 + t)) = f32x2r_t{mean, rstd};
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave
   G8_STAMP(1)
@@ -589,11 +632,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     const int hcol = (og >> 2) * 64 + (og & 3) * 8;           // tile-local packed column of h; g is + 32
     const float alpha = p.alpha;
     const int64_t nh = n0 + hcol, ldc = p.ldc, ldc2 = p.ldc2, Mtot = p.M;
-    float bh[8], bg[8];
+    float bh[8], bg[8], ch[8], cgv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       bh[e] = bias_s[hcol + e];
       bg[e] = bias_s[hcol + 32 + e];
+      ch[e] = lnf ? bias_s[BN + hcol + e] : 0.f;         // folded LayerNorm: c1 of the h / g columns
+      cgv[e] = lnf ? bias_s[BN + hcol + 32 + e] : 0.f;
     }
     f16* const C2g = p.C2 ? (f16*)p.C2 + nh : nullptr;
     f16* const Cg = (f16*)p.C + (n0 >> 1) + (og >> 2) * 32 + (og & 3) * 8;
@@ -620,10 +665,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
             const float* cr = Cs + row * LDC + hcol;
             const f32x4_t h0 = *(const f32x4_t*)cr, h1 = *(const f32x4_t*)(cr + 4), g0 = *(const f32x4_t*)(cr + 32), g1 = *(const f32x4_t*)(cr + 36);
             f16x8 oh, og8, oo;
+            const f32x2r_t rs = lnf ? rowst_s[rp + row] : f32x2r_t{0.f, 1.f};   // (mean, rstd); no fold: v = 1 * (acc - 0 * 0) + b
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              oh[e] = (f16)(alpha * (e < 4 ? h0[e] : h1[e - 4]) + bh[e]);
-              og8[e] = (f16)(alpha * (e < 4 ? g0[e] : g1[e - 4]) + bg[e]);
+              oh[e] = (f16)(rs[1] * (alpha * (e < 4 ? h0[e] : h1[e - 4]) - rs[0] * ch[e]) + bh[e]);
+              og8[e] = (f16)(rs[1] * (alpha * (e < 4 ? g0[e] : g1[e - 4]) - rs[0] * cgv[e]) + bg[e]);
               oo[e] = (f16)((float)oh[e] * ((G8_ABL & 16) ? (float)og8[e] : gelu_erf_f((float)og8[e])));  // gate on the fp16-rounded projections, as an fp16 module would
             }
             if ((G8_ABL & 8) && alpha != 12345.f) continue;  // profiling: no global stores
@@ -900,6 +946,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
     }
     auto m_row = [&](int r) -> int64_t { return out_row(r); };
+    // row statistics for the NEXT Linear's folded LayerNorm (producer, tb_gemm_desc.rs_out): per (row, 8-column unit) partials through `red`
+    const bool rs_prod = RS_OK && p.rs_out != nullptr;
+    f32x2r_t* const red = reinterpret_cast<f32x2r_t*>(smem_raw + EPB);   // [PR][UPR], behind the staging tile
     f16x8 rv1[NU];  // second pass: its residual rows are requested before the first pass is staged
     if (PASSES == 2 && Rg && rslot < TPR) {
 #pragma unroll
@@ -943,14 +992,46 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           if (row < PR && m < Mtot) {
             const f32x4_t c0 = *(const f32x4_t*)(Cs + row * LDC + cg * 8), c1 = *(const f32x4_t*)(Cs + row * LDC + cg * 8 + 4);
             f16x8 o;
+            float ssum = 0.f, ssq = 0.f;
+            if (RS_OK && lnf) {
+              const f32x2r_t rs = rowst_s[rp + row];
+              // c1 of this thread's 8 columns: re-read from the LDS per unit (held in registers across the passes it cost the 128x160 tile its
+              // second workgroup per CU: 133 VGPRs)
+              const f32x4_t k0 = *(const f32x4_t*)(bias_s + BN + cg * 8), k1 = *(const f32x4_t*)(bias_s + BN + cg * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float x = (e < 4 ? c0[e] : c1[e - 4]) * alpha + b8[e];
-              if (Rg) x += (float)rv[it][e];
-              if (silu) x = silu_f(x);
-              o[e] = (f16)x;
+              for (int e = 0; e < 8; ++e) {
+                float x = rs[1] * ((e < 4 ? c0[e] : c1[e - 4]) * alpha - rs[0] * (e < 4 ? k0[e] : k1[e - 4])) + b8[e];
+                if (Rg) x += (float)rv[it][e];
+                if (silu) x = silu_f(x);
+                o[e] = (f16)x;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float x = (e < 4 ? c0[e] : c1[e - 4]) * alpha + b8[e];
+                if (Rg) x += (float)rv[it][e];
+                if (silu) x = silu_f(x);
+                o[e] = (f16)x;
+                if (RS_OK) ssum += (float)o[e], ssq += (float)o[e] * (float)o[e];
+              }
             }
             if (!(G8_ABL & 8) || alpha == 12345.f) *(f16x8*)(Cg + m * ldc) = o;
+            if (rs_prod) red[row * UPR + cg] = f32x2r_t{ssum, ssq};
+          }
+        }
+      }
+      if constexpr (RS_OK) {
+        if (rs_prod) {   // the UPR unit partials of a row -> slot tn of the row's statistics
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (t < PR) {
+            const int64_t m = m0 + rp + t;
+            float sx = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < UPR; ++k) {
+              const f32x2r_t v = red[t * UPR + k];
+              sx += v[0], sq += v[1];
+            }
+            if (m < Mtot) reinterpret_cast<f32x2r_t*>(p.rs_out)[m * p.rs_ld + tn] = f32x2r_t{sx, sq};
           }
         }
       }
@@ -1004,6 +1085,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 unsigned long long* g8_dbg = nullptr;  // profiling aid (tb_gemm8_debug): s_memtime stamps of the first and the last block
 int g8_enable = 39;  // tb_gemm8_set(bits): 1 = convolutions, 2 = Linear layers, 4 = GEGLU / GEGLU-backward epilogues take the wide-tile path
 thread_local int g8_split = 1;  // k-slices of the launch tb_gemm8_try is making on this thread (returned through its out-parameter)
+thread_local bool g8_dry = false;   // tb_gemm_lnfold_ok: walk the dispatch rules without launching
 int g8_last[7] = {0, 0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
 template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0>
@@ -1025,10 +1107,16 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   if (CONV && (a_rows8 >> 3) > 8 * 7) return 1;  // more panel load instructions than the kernel issues
   size_t lds = (size_t)(CONV ? 2 : NS) * a_rows8 * 128 + (size_t)NS * BN * 128;
   if (lds < G8Epi<BM, BN>::BYTES) lds = G8Epi<BM, BN>::BYTES;
-  if (!CONV) lds += BN * 12;  // the tile's bias values (+ LayerNorm gamma / beta of the fused-LN epilogues)
+  if ((d.rs_in || d.rs_out) && (CONV || BM * BN > 128 * 160)) return TB_EINVAL;   // (the kernel's RS_OK)
+  if (!CONV) {
+    // `red` ([rows per pass][8-column units] float2, the row-statistic partials of tb_gemm_desc.rs_out) sits behind the epilogue's staging tile
+    const size_t red_end = G8Epi<BM, BN>::BYTES + (size_t)G8Epi<BM, BN>::PR * (BN / 8) * 8;
+    if (d.rs_out && lds < red_end) lds = red_end;
+    lds += BN * 12 + BM * 8;  // the tile's bias values (+ LayerNorm gamma / beta of the fused-LN epilogues, c1 of a folded one) + (mean, rstd) per tile row
+  }
   if (lds > 160 * 1024) return 1;
   static bool attr_done = false;
-  if (!attr_done) {
+  if (!attr_done && !g8_dry) {
     if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return TB_ELAUNCH;
@@ -1044,6 +1132,10 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
       const double cost = c * a_bytes + (8 / c) * w_bytes;
       if (cost < best) xn = c, best = cost;
     }
+  }
+  if (g8_dry) {
+    g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
+    return TB_OK;
   }
   hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
                      wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn);
@@ -1093,6 +1185,39 @@ extern "C" int tb_gemm_subpixel_ok(int B, int Hc, int Wc, int Cin, int N) {
   return 1;
 }
 
+// LayerNorm folded into the consuming Linear (tb_gemm_desc.rs_out / rs_in) for a transformer block of width C over M rows: 1 when the producers of
+// the residual stream (proj_in, attn1.to_out, attn2.to_out: M x C x C with a residual) take an 8-wave tile that writes row statistics AND the three
+// consumers (qkv M x 3C x C, attn2.to_q M x C x C, the GEGLU projection M x 8C x C) take a tile whose epilogue applies the fold; *slots = the
+// producers' column tiles per row (rs_n).  Walks the dispatch rules themselves (dry run), so it cannot drift from them.
+static int gemm8_try(const tb_gemm_desc& d, hipStream_t s);
+extern "C" int tb_gemm_lnfold_ok(int64_t M, int64_t C, int* slots) {
+  if (M <= 0 || C <= 0 || C % 64 || M % 128) return 0;
+  char* const fake = (char*)(uintptr_t)0x10000;   // never dereferenced: the dry run stops in front of the launch
+  tb_gemm_desc d = {};
+  d.M = M, d.K = d.K1 = C, d.lda = C, d.ldw = C, d.a_mode = TB_A_LINEAR, d.alpha = 1.f, d.A = fake, d.W = fake, d.C = fake, d.c_dtype = TB_F16;
+  g8_dry = true;
+  int ok = 1, nslots = 0;
+  {  // producer
+    tb_gemm_desc p = d;
+    p.N = C, p.ldc = C, p.R = fake, p.ldr = C, p.r_dtype = TB_F16, p.bias = (const float*)fake, p.rs_out = (float*)fake, p.rs_ld = 16;
+    if (gemm8_try(p, nullptr) != TB_OK) ok = 0;
+    else nslots = (int)(C / (g8_last[2] * g8_last[4] * 16));
+    if (nslots < 1 || nslots > 16) ok = 0;
+  }
+  const int64_t ns[3] = {3 * C, C, 8 * C};
+  for (int i = 0; i < 3 && ok; ++i) {
+    tb_gemm_desc c = d;
+    c.N = ns[i], c.ldc = i == 2 ? 4 * C : ns[i], c.rs_in = (const float*)fake, c.rs_ld = 16, c.rs_n = nslots, c.ln_gamma = (const float*)fake;
+    if (i == 2) c.act = TB_ACT_GEGLU, c.C2 = fake, c.ldc2 = ns[i], c.bias = (const float*)fake;
+    const int r = gemm8_try(c, nullptr);
+    if (r != TB_OK && !(r == 1 && i != 2)) ok = 0;   // (1 = the 4-wave kernel's lean epilogue takes it: plain Linear only)
+  }
+  g8_dry = false;
+  g8_last[0] = 0;
+  if (slots) *slots = ok ? nslots : 0;
+  return ok;
+}
+
 extern "C" int tb_gemm_ln_epilogue_ok(int64_t M, int64_t N, int64_t K) {
   if (N != 320 || K <= 0 || K % 64 || M <= 0) return 0;
   if (M % 128 == 0 && M / 128 >= 200) return 1;  // 128 x 320 tiles
@@ -1120,6 +1245,15 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     if (d.C2 && (d.ldc2 % 8 || ((uintptr_t)d.C2) % 16)) return 1;
     if (d.act == TB_ACT_GEGLU && (d.N % 640 || ((uintptr_t)d.C) % 16)) return 1;       // whole [h32 | g32] blocks per 320-wide tile
     if (d.act == TB_ACT_GEGLU_GRAD && (!d.C2 || d.N % 32 || d.bias)) return 1;
+  }
+  if (d.rs_out || d.rs_in) {  // folded-LayerNorm statistics (producer / consumer): the lean fp16 epilogues only -- anything else is the caller's error
+    const bool vec = d.c_dtype == TB_F16 && d.ldc % 8 == 0 && ((uintptr_t)d.C) % 16 == 0 &&
+                     (!d.R || (d.r_dtype == TB_F16 && d.ldr % 8 == 0 && ((uintptr_t)d.R) % 16 == 0));
+    if (d.a_mode != TB_A_LINEAR || d.rowbias || !vec || d.M % 128) return TB_EINVAL;
+    if (d.rs_out && (d.act != TB_ACT_NONE || d.C2 || d.rs_in || ((uintptr_t)d.rs_out) % 8)) return TB_EINVAL;
+    if (d.rs_in && ((d.act != TB_ACT_NONE && d.act != TB_ACT_GEGLU) || (d.act == TB_ACT_NONE && d.C2) || !d.ln_gamma || d.rs_n < 1 || d.rs_n > 16 ||
+                    d.rs_ld < d.rs_n || ((uintptr_t)d.rs_in) % 8 || ((uintptr_t)d.ln_stats) % 8))
+      return TB_EINVAL;
   }
   const bool ln_act = d.act == TB_ACT_LN_FWD || d.act == TB_ACT_LN_BWD;
   if (ln_act) {  // only the row-spanning Linear tiles implement these: anything else is the caller's error (tb_gemm_ln_epilogue_ok)

@@ -178,7 +178,7 @@ int tb_lin320_try(const tb_gemm_desc& d, hipStream_t s) {
   if (!g_lin320) return 1;
   if (d.a_mode != TB_A_LINEAR || d.K != L3_K || d.A2 || d.W2 || d.M % L3_BM || d.N % L3_TN || d.N < 128) return 1;
   if (d.M / L3_BM < 200) return 1;                                  // one workgroup per CU: the 64x64 maps at the metric batch
-  if (d.act != TB_ACT_NONE || d.rowbias || d.C2 || d.c_dtype != TB_F16 || (d.R && d.r_dtype != TB_F16)) return 1;
+  if (d.act != TB_ACT_NONE || d.rowbias || d.C2 || d.c_dtype != TB_F16 || (d.R && d.r_dtype != TB_F16) || d.rs_out || d.rs_in) return 1;
   if (d.lda % 8 || d.ldw % 8 || d.ldc % 4 || (d.R && d.ldr % 4)) return 1;
   if (((uintptr_t)d.A) % 16 || ((uintptr_t)d.W) % 16 || ((uintptr_t)d.C) % 8 || ((uintptr_t)d.R) % 8 || ((uintptr_t)d.bias) % 16) return 1;
   if ((d.N * d.ldw) * 2 >= ((int64_t)1 << 32)) return 1;

@@ -121,6 +121,31 @@ def gemm_ln_ok(M, N, K, dtype=None):
     return dtype in (None, L.half_dtype()) and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))
 
 
+def lnfold_slots(M, C, dtype=None):
+    """> 0 when the three LayerNorms of a transformer block of width C over M rows can be folded into the Linear layers behind them
+    (`gemm(..., rs_out=)` in the producers of the residual stream, `gemm(..., lnfold=)` in qkv / attn2.to_q / the GEGLU projection): the number of
+    statistic slots per row the producers fill."""
+    if dtype not in (None, L.half_dtype()):
+        return 0
+    import ctypes
+    n = ctypes.c_int(0)
+    return n.value if L.lib().tb_gemm_lnfold_ok(M, C, ctypes.byref(n)) else 0
+
+
+def fold_layernorm(W, gamma, beta, bias=None, dtype=None):
+    """LayerNorm folded into the Linear that consumes it (tb_gemm_desc.rs_in): LN(x) W^T + b = rstd (x W'^T - mean c1) + c2.
+    W [N, K] (any float dtype), gamma / beta [K].  Returns (W' = half(gamma (.) W), c1 = row sums of the ROUNDED W' (fp32: the algebra is then
+    exact for the operand the kernel multiplies), c2 = b + W beta (fp32))."""
+    dt = dtype or L.half_dtype()
+    Wf = W.float()
+    Wp = (Wf * gamma.float()[None, :]).to(dt)
+    c1 = Wp.float().sum(dim=1).contiguous()
+    c2 = Wf @ beta.float()
+    if bias is not None:
+        c2 = c2 + bias.float()
+    return Wp.contiguous(), c1, c2.contiguous()
+
+
 class SplitKPartials:
     """fp32 k-slices left in the GEMM workspace by `gemm(..., defer=True)` (tb_gemm_desc.split_out) together with the epilogue operands the
     consumer has to apply: handed to `groupnorm_fwd(..., partials=)` / `groupnorm_bwd(..., partials=)`.  Valid until the next gemm on the stream."""
@@ -134,14 +159,25 @@ DEFER_SPLITK = os.environ.get("TB_DEFER_SPLITK", "1") == "1"   # A/B switch: 0 =
 
 
 def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_per_group=0, R=None, act=L.ACT_NONE,
-         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None, defer=False):
+         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None, defer=False, rs_out=None, lnfold=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
     conv = dict(B,Hin,Win,Cin,Hout,Wout,stride,sign,upsample,transposed) switches A to an NHWC 3x3 gather.
     ln_fwd = (gamma, beta, stats_out, y_out, eps): LayerNorm of the output row fused into the epilogue (only where `gemm_ln_ok`): `out` gets the
     Linear's result as usual, `y_out` = LN(out), `stats_out` [M,2] = (mean, rstd).
     ln_bwd = (gamma, stats, x): `out` = tb_layernorm_bwd(dy = A @ W^T, x, gamma, stats) + R -- the LayerNorm backward applied to the dgrad
-    GEMM's accumulators (x = the LayerNorm's fp16 input)."""
+    GEMM's accumulators (x = the LayerNorm's fp16 input).
+    rs_out = fp32 [M, slots, 2]: the launch also writes per-column-tile (sum, sum of squares) of its fp16 output rows (`lnfold_slots`).
+    lnfold = (rs, n_slots, c1, stats_out_or_None, eps): W is a `fold_layernorm` weight, A the RAW LayerNorm input, bias = c2; the LayerNorm is
+    applied as two per-row scalars in the epilogue (act NONE or GEGLU); stats_out [M, 2] receives (mean, rstd) for the backward."""
     d = L.GemmDesc()
+    if rs_out is not None:
+        assert rs_out.dtype == torch.float32 and rs_out.is_contiguous() and rs_out.shape[0] == out.shape[0] and rs_out.shape[2] == 2
+        d.rs_out, d.rs_ld = L.ptr(rs_out), rs_out.shape[1]
+    if lnfold is not None:
+        rs_, n_, c1_, st_, eps_ = lnfold
+        assert rs_out is None and rs_.dtype == torch.float32 and rs_.is_contiguous() and c1_.dtype == torch.float32
+        d.rs_in, d.rs_ld, d.rs_n = L.ptr(rs_), rs_.shape[1], n_
+        d.ln_gamma, d.ln_stats, d.ln_eps = L.ptr(c1_), L.ptr(st_), eps_
     if ln_fwd is not None:
         assert act == L.ACT_NONE and C2 is None and ln_bwd is None
         g_, b_, st_, y_, eps_ = ln_fwd

@@ -36,6 +36,10 @@ MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  #
 # LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
 # residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
 FUSE_LN = _os.environ.get("TB_FUSE_LN", "1") == "1"
+# round 5: where no tile spans the row (C = 640 / 1280), the block's three LayerNorms are FOLDED into the Linear behind each of them (gamma into the
+# frozen weight, mean / rstd as per-row scalars of the consumer's epilogue, row statistics written by the producer of the residual stream):
+# no LayerNorm launch and no normalised copy in the forward (A/B switch)
+FOLD_LN = _os.environ.get("TB_FOLD_LN", "1") == "1"
 # Upsampler convolutions (nearest x2 + conv3x3) as four 2x2-tap sub-pixel convolutions with pre-summed frozen weights (round 4): 2.25x fewer FLOP in
 # the forward and in the dgrad, no materialised 4x map, no 2x2 gradient pooling pass.  The summed filter rows are rounded to fp16 once: a stated
 # divergence from the 9-tap arithmetic, bounded in tests/test_gpu_gemm.py.  TB_SUBPIXEL=0 restores the materialised-upsample path (A/B).
@@ -221,22 +225,41 @@ class HipUNet:
                 lin(prefix + ".conv_shortcut")
             self.resnets.append(prefix)
 
-        def transformer(prefix, C):
+        self.fold_slots: Dict[str, int] = {}   # transformer prefix -> statistic slots per row (> 0: its LayerNorms are folded, see FOLD_LN)
+
+        def transformer(prefix, C, level):
             norm(prefix + ".norm")
             lin(prefix + ".proj_in"); lin(prefix + ".proj_out")
             tb = prefix + ".transformer_blocks.0"
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{tb}.{n}")
             wq = torch.cat([sd[f"{tb}.attn1.to_{x}.weight"] for x in "qkv"], dim=0)
-            P[f"{tb}.attn1.qkv.w"], P[f"{tb}.attn1.qkv.wd"] = pack_linear(wq, dev, wdt)
             lin(f"{tb}.attn1.to_out.0")
-            lin(f"{tb}.attn2.to_q", bias=False)
             lin(f"{tb}.attn2.to_out.0")
             self.xattn.append((f"{tb}.attn2", C))
             wff = pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.weight"])
-            P[f"{tb}.ff1.w"], P[f"{tb}.ff1.wd"] = pack_linear(wff, dev, wdt)
-            P[f"{tb}.ff1.b"] = _f32v(pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.bias"]), dev)
+            bff = pack_geglu_rows(sd[f"{tb}.ff.net.0.proj.bias"])
             lin(f"{tb}.ff.net.2")
+            M = self.B * (self.H >> level) * (self.W >> level)
+            slots = 0
+            if FOLD_LN and wdt != torch.float32 and not (FUSE_LN and ops.gemm_ln_ok(M, C, C, wdt)):
+                slots = ops.lnfold_slots(M, C, wdt)
+            self.fold_slots[prefix] = slots
+            if slots:
+                # W' = gamma (.) W in the weight's place (forward and dgrad: d(LN input) needs gamma (.) dy = dY W'), c1 / c2 beside it
+                for key, w_, b_, ln in ((f"{tb}.attn1.qkv", wq, None, "norm1"), (f"{tb}.attn2.to_q", sd[f"{tb}.attn2.to_q.weight"], None, "norm2"),
+                                        (f"{tb}.ff1", wff, bff, "norm3")):
+                    wp, c1, c2 = ops.fold_layernorm(w_.to(dev), sd[f"{tb}.{ln}.weight"].to(dev), sd[f"{tb}.{ln}.bias"].to(dev),
+                                                    None if b_ is None else b_.to(dev), wdt)
+                    P[key + ".w"], P[key + ".wd"] = wp, wp.t().contiguous()
+                    P[key + ".c1"], P[key + ".c2"] = c1, c2
+                if "ones" not in P or P["ones"].numel() < C:
+                    P["ones"] = torch.ones(C, device=dev, dtype=torch.float32)
+                return
+            P[f"{tb}.attn1.qkv.w"], P[f"{tb}.attn1.qkv.wd"] = pack_linear(wq, dev, wdt)
+            lin(f"{tb}.attn2.to_q", bias=False)
+            P[f"{tb}.ff1.w"], P[f"{tb}.ff1.wd"] = pack_linear(wff, dev, wdt)
+            P[f"{tb}.ff1.b"] = _f32v(bff, dev)
 
         L_ = geo.layers_per_block
         prev = ch[0]
@@ -245,14 +268,14 @@ class HipUNet:
             for j in range(L_):
                 resnet(f"down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
                 if geo.cross_attn_levels[i]:
-                    transformer(f"down_blocks.{i}.attentions.{j}", c)
+                    transformer(f"down_blocks.{i}.attentions.{j}", c, i)
                 skip_chs.append(c)
             if i < len(ch) - 1:
                 conv(f"down_blocks.{i}.downsamplers.0.conv")
                 skip_chs.append(c)
             prev = c
         resnet("mid_block.resnets.0", ch[-1], ch[-1])
-        transformer("mid_block.attentions.0", ch[-1])
+        transformer("mid_block.attentions.0", ch[-1], len(ch) - 1)
         resnet("mid_block.resnets.1", ch[-1], ch[-1])
         self.skip_chs = list(skip_chs)
         rev = list(reversed(ch))
@@ -264,7 +287,7 @@ class HipUNet:
                 s = sk.pop()
                 resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else c) + s, c)
                 if geo.cross_attn_levels[level]:
-                    transformer(f"up_blocks.{i}.attentions.{j}", c)
+                    transformer(f"up_blocks.{i}.attentions.{j}", c, level)
             if i < len(ch) - 1:
                 conv(f"up_blocks.{i}.upsamplers.0.conv")
                 name = f"up_blocks.{i}.upsamplers.0.conv"
@@ -376,16 +399,27 @@ class HipUNet:
         self._gn_fwd(x, prefix + ".norm", n0, st0, HW, False, eps=1e-6, partials=x_partials)  # (x_partials: see _resnet)
         t0 = self.buf(prefix + ".t0", M, C)
         fuse_ln = FUSE_LN and ops.gemm_ln_ok(M, C, C, self.dtype)
+        # folded LayerNorms (FOLD_LN, decided in _pack): the producers of the residual stream (proj_in, attn1.to_out, attn2.to_out) write per-tile row
+        # statistics (rs), the Linear behind each LayerNorm multiplies the RAW stream by gamma-folded weights and normalises in its epilogue
+        fold = self.fold_slots.get(prefix, 0)
+        assert not (fold and fuse_ln)
+        rs = self.scratch("rs", M, 16 * 2, torch.float32).view(M, 16, 2) if fold else None
+        ln_g = (lambda n: P["ones"]) if fold else (lambda n: P[f"{tb}.{n}.g"])    # backward: the dgrad through W' already carries gamma
         # --- self attention
         ls1 = self.buf(prefix + ".ls1", M, 2, torch.float32)
-        l1 = self.scratch("a2" if fuse_ln else "a", M, C)   # (fused: written while n0 -- scratch "a" -- is still being read)
-        if fuse_ln:
-            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"], ln_fwd=(P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1, l1, 1e-5))
-        else:
-            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
-            ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
         qkv = self.buf(prefix + ".qkv", M, 3 * C)
-        ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
+        if fold:
+            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"], rs_out=rs)
+            ops.gemm(t0, P[tb + ".attn1.qkv.w"], qkv, bias=P[tb + ".attn1.qkv.c2"], lnfold=(rs, fold, P[tb + ".attn1.qkv.c1"], ls1, 1e-5))
+        else:
+            l1 = self.scratch("a2" if fuse_ln else "a", M, C)   # (fused: written while n0 -- scratch "a" -- is still being read)
+            if fuse_ln:
+                ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"],
+                         ln_fwd=(P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1, l1, 1e-5))
+            else:
+                ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
+                ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
+            ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
         o1 = self.buf(prefix + ".o1", M, C)
         lse1 = self.buf(prefix + ".lse1", B * heads, HW, torch.float32)
         fp8_ws = None
@@ -397,15 +431,19 @@ class HipUNet:
         t1 = self.buf(prefix + ".t1", M, C)
         # --- cross attention (K/V hoisted)
         ls2 = self.buf(prefix + ".ls2", M, 2, torch.float32)
-        l2 = self.scratch("a", M, C)
-        if fuse_ln:
-            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0,
-                     ln_fwd=(P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2, l2, 1e-5))
-        else:
-            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
-            ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
         q2 = self.buf(prefix + ".q2", M, C)
-        ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
+        if fold:
+            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0, rs_out=rs)
+            ops.gemm(t1, P[tb + ".attn2.to_q.w"], q2, bias=P[tb + ".attn2.to_q.c2"], lnfold=(rs, fold, P[tb + ".attn2.to_q.c1"], ls2, 1e-5))
+        else:
+            l2 = self.scratch("a", M, C)
+            if fuse_ln:
+                ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0,
+                         ln_fwd=(P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2, l2, 1e-5))
+            else:
+                ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
+                ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
+            ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
         self._ensure_kv()
         ko = self.kv_off[tb + ".attn2"]
         k2, v2 = self.kv_all[:, ko:ko + C], self.kv_all[:, ko + C:ko + 2 * C]
@@ -415,16 +453,25 @@ class HipUNet:
         t2 = self.buf(prefix + ".t2", M, C)
         # --- GEGLU feed-forward
         ls3 = self.buf(prefix + ".ls3", M, 2, torch.float32)
-        l3 = self.scratch("a", M, C)
-        if fuse_ln:
-            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1,
-                     ln_fwd=(P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3, l3, 1e-5))
+        l3 = None
+        if fold:
+            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1, rs_out=rs)
         else:
-            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
-            ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
+            l3 = self.scratch("a", M, C)
+            if fuse_ln:
+                ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1,
+                         ln_fwd=(P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3, l3, 1e-5))
+            else:
+                ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
+                ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
         raw = self.buf(prefix + ".raw", M, 8 * C)
-        fuse_ff = FUSE_FF and ops.ff_fused_ok(M, C, 4 * C, self.dtype)
-        if fuse_ff:
+        fuse_ff = FUSE_FF and not fold and ops.ff_fused_ok(M, C, 4 * C, self.dtype)
+        if fold:
+            gated = self.scratch("b", M, 4 * C)
+            ops.gemm(t2, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.c2"], act=L.ACT_GEGLU, C2=raw, lnfold=(rs, fold, P[tb + ".ff1.c1"], ls3, 1e-5))
+            t3 = self.scratch("a", M, C)
+            ops.gemm(gated, P[tb + ".ff.net.2.w"], t3, bias=P[tb + ".ff.net.2.b"], R=t2)
+        elif fuse_ff:
             t3 = self.scratch("a2" if fuse_ln else "b", M, C)   # (not scratch "a": l3 is being read)
             ops.ff_fwd(l3, P[tb + ".ff1.w"], P[tb + ".ff1.b"], P[tb + ".ff.net.2.w"], P[tb + ".ff.net.2.b"], raw, t3, R=t2)
         else:
@@ -442,7 +489,7 @@ class HipUNet:
             if fuse_ff:   # ff.net.2 dgrad, GEGLU backward and ff.net.0 dgrad in one launch; the LayerNorm backward behind it
                 dl3 = self.scratch("g2", M, C)
                 ops.ff_bwd(dt3, P[tb + ".ff.net.2.wd"], P[tb + ".ff1.wd"], raw, dl3)
-                ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
+                ops.layernorm_bwd(dl3, t2, ln_g("norm3"), ls3, dt2, add=dt3)
             else:
                 dproj = self.scratch("gc", M, 8 * C)
                 if FUSE_GEGLU_BWD or self.dtype == torch.float32:   # ff.net.2 dgrad with the GEGLU backward fused into its epilogue
@@ -456,7 +503,7 @@ class HipUNet:
                 else:
                     dl3 = self.scratch("g2", M, C)
                     ops.gemm(dproj, P[tb + ".ff1.wd"], dl3)
-                    ops.layernorm_bwd(dl3, t2, P[tb + ".norm3.g"], ls3, dt2, add=dt3)
+                    ops.layernorm_bwd(dl3, t2, ln_g("norm3"), ls3, dt2, add=dt3)
             do2 = self.scratch("g1", M, C)
             ops.gemm(dt2, P[tb + ".attn2.to_out.0.wd"], do2)
             dq2 = self.scratch("g2", M, C)
@@ -472,7 +519,7 @@ class HipUNet:
             else:
                 dl2 = self.scratch("g1", M, C)
                 ops.gemm(dq2, P[tb + ".attn2.to_q.wd"], dl2)
-                ops.layernorm_bwd(dl2, t1, P[tb + ".norm2.g"], ls2, dt1, add=dt2)
+                ops.layernorm_bwd(dl2, t1, ln_g("norm2"), ls2, dt1, add=dt2)
             do1 = self.scratch("g1", M, C)
             ops.gemm(dt1, P[tb + ".attn1.to_out.0.wd"], do1)
             dqkv = self.scratch("gq", M, 3 * C)
@@ -487,7 +534,7 @@ class HipUNet:
             else:
                 dl1 = self.scratch("g2", M, C)
                 ops.gemm(dqkv, P[tb + ".attn1.qkv.wd"], dl1)
-                ops.layernorm_bwd(dl1, t0, P[tb + ".norm1.g"], ls1, dt0, add=dt1)
+                ops.layernorm_bwd(dl1, t0, ln_g("norm1"), ls1, dt0, add=dt1)
             dn0 = self.scratch("g1", M, C)
             ops.gemm(dt0, P[prefix + ".proj_in.wd"], dn0)
             self._gn_bwd(dn0, x, prefix + ".norm", st0, dx, HW, False, add=dout)
