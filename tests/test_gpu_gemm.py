@@ -651,8 +651,10 @@ def test_linear_k320_activation_stationary_kernel(M, N, bias, res):
 @pytest.mark.parametrize("M,N,K,bias,res,act", [(2048, 1280, 1280, True, True, 0), (2048, 1280, 640, False, False, 0), (2048, 1280, 2560, True, False, 0),
                                                 (2048, 1280, 1344, True, True, 1)])
 def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
-    """gemm8_kernel<8, 1, 1, 5, false, 4> (round 4): the 16x16-map Linear layers as ONE 128 x 80 tile per CU on a 4-stage ring (two stages in flight across
-    the barrier), against torch and against the kernels that took these shapes before (tb_gemm8_set bit 2048 turns the tile off); strided views."""
+    """the 16x16-map Linear layers as ONE 128 x 80 tile per CU on a 4-stage ring (two stages in flight across the barrier): round 5's
+    gemm8_kernel<4, 1, 2, 5, false, 4, 0, 2> (4 x 1 x 2 waves: the two waves of a SIMD split every k-step, accumulators added through the LDS),
+    against torch, against round 4's 8 x 1 waves (tb_gemm8_set bit 16384) and against the 4-wave kernels that took these shapes before (bit 2048);
+    strided views."""
     ops, L = _ops()
     import ctypes
     torch.manual_seed(17)
@@ -663,14 +665,14 @@ def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
     prev = L.lib().tb_gemm8_set(39)
     outs = []
     try:
-        for bits in (39, 39 | 2048):
+        for bits, tile in ((39, [4, 1, 2, 5]), (39 | 16384, [8, 1, 1, 5]), (39 | 2048, None)):
             L.lib().tb_gemm8_set(bits)
             Cbuf = torch.full((M, N + 16), 3.0, device="cuda", dtype=torch.float16)
             out = Cbuf[:, 8:8 + N]
             ops.gemm(A, W, out, bias=b, R=R, act=L.ACT_SILU if act else L.ACT_NONE)
             last = (ctypes.c_int * 6)()
             took = bool(L.lib().tb_gemm8_last(last))
-            assert (took and list(last)[:4] == [8, 1, 1, 5]) == (bits == 39), list(last)
+            assert (took and list(last)[:4] == tile) if tile else not (took and list(last)[:4] in ([4, 1, 2, 5], [8, 1, 1, 5])), list(last)
             assert (Cbuf[:, :8] == 3).all() and (Cbuf[:, 8 + N:] == 3).all()
             outs.append(out)
     finally:
@@ -678,8 +680,9 @@ def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
     ref = A.float() @ W.float().T + (b if bias else 0) + (R.float() if res else 0)
     if act:
         ref = F.silu(ref)      # (tb_gemm: the activation acts on acc + bias + residual)
-    parity("128 x 80 one-per-CU Linear tile", outs[0], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
-    assert rel_err(outs[0], outs[1]) < 3e-4
+    parity("128 x 80 one-per-CU Linear tile, k-halves", outs[0], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
+    parity("128 x 80 one-per-CU Linear tile, 8 x 1 waves", outs[1], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
+    assert rel_err(outs[0], outs[1]) < 3e-4 and rel_err(outs[0], outs[2]) < 3e-4
 
 
 @pytest.mark.parametrize("K,bias,res", [(5120, True, True), (10240, False, False)])

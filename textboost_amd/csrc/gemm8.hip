@@ -19,6 +19,9 @@
 #ifndef G8_PROF
 #define G8_PROF 0  // profiling build: per-phase s_memtime sums of waves 0 and 4 of workgroup 0 into dbg[16..]
 #endif
+#ifndef G8_DMAC
+#define G8_DMAC 1  // A/B build switch (TB_CFLAGS=-DG8_DMAC=0): the Linear tiles' global -> LDS pieces in the LOAD phase, as in round 4
+#endif
 #ifndef G8_ABL
 #define G8_ABL 0  // profiling builds (TB_CFLAGS=-DG8_ABL=bits): 1 = no MFMAs, 2 = no in-loop global->LDS loads, 4 = no fragment reads
 #endif
@@ -58,6 +61,12 @@ __device__ __forceinline__ f16x8 lds_read16_off(uint32_t addr, int j) {  // addr
     default: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(5 * STRIDE)); break;
   }
   return v;
+}
+// global -> LDS DMA of 64 x 16 bytes as ONE asm statement (destination = the wave-uniform LDS byte address in M0 + 16 * lane).  Unlike the builtin it
+// may sit between MFMAs: there the builtin gets an `s_waitcnt vmcnt(0)` and a VGPR round trip of its M0 value in front (ff_fused.hip / lin320.hip)
+__device__ __forceinline__ void glds16_asm(const void* src, uint32_t lds_byte_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(src) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt_c() {
@@ -111,10 +120,15 @@ __device__ __forceinline__ int64_t m0p_of(int tm, int bm) { return (int64_t)tm *
 //           the tile is stored to the fine pixel (2 y + py, 2 x + px);  W = [4 classes][N][4 taps][Cin].
 //   SUB = 2 (dgrad, upsample == 3): A = the fine gradient read as four strided VIEWS (py, px), the k-loop walks (view, channel chunk) pairs with
 //           four taps each, the output is the coarse map; W = [N][4 views][4 taps][Cin]; split-K over the (view, chunk) list as usual.
-template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0>
+// KH = 2 (round 5, Linear tiles with MT < 4): the 8 waves are WM x WN x 2 -- the two waves of a SIMD (w, w + 4) own the SAME (16 MT) x (16 NT)
+// outputs and split every 64-wide k-step between them (32 k each), their accumulators are added through the LDS in front of the epilogue.  A wave
+// tile twice as tall for the same register tile per wave: the 128 x 80 one-per-CU tile read (16 + 80) fragment rows per 5 MFMAs (LDS-read bound,
+// 0.65 us per k-step at one tile per CU), as 4 x 1 x 2 waves it reads (32 + 80) rows per 10.
+template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0, int KH = 1>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int a_rows8,
                                                           unsigned long long* dbg, int S, float* __restrict__ ws, int64_t npad, int xn) {
-  static_assert(WM * WN == 8, "8 waves");
+  static_assert(WM * WN * KH == 8, "8 waves");
+  static_assert(KH == 1 || (KH == 2 && !CONV && MT < 4), "k-halves: Linear tiles whose step is one phase pair");
 #define G8_STAMP(k)                                                                                  \
   if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                  \
     dbg[(blockIdx.x ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime();
@@ -128,7 +142,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   constexpr int MAXHI = CONV ? 7 : (BM / 64 > 0 ? BM / 64 : 1);  // A-panel load instructions per wave per chunk
   const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
+  const int kh = KH == 2 ? wave / (WM * WN) : 0, wv = KH == 2 ? wave - kh * (WM * WN) : wave;   // (KH == 2: kh == the phase group, wave >> 2)
+  const int wm = wv / WN, wn = wv - wm * WN;
+  const bool stager = KH == 1 || kh == 0;   // the waves that hold the k-summed accumulators in the epilogue
   // LDS: [A panels | W stages]: conv 2 halo panels (a_rows8 pixels x 128 B), Linear NS tile-row panels; NS weight stages of BN rows x 128 B
   constexpr int NA = CONV ? 2 : NS;
   f16* const As = reinterpret_cast<f16*>(smem_raw);
@@ -396,6 +412,23 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
     return n;
   };
+  // DMAC (round 5; Linear tiles whose step is one phase pair, rings of >= 4 stages): the step's global -> LDS pieces are issued in the COMPUTE phase,
+  // between the MFMAs, not in the LOAD phase.  Measured on the 128 x 80 tile (scratch/kh_time.py with -DG8_ABL builds): a k-step took 0.625 us =
+  // 0.26 (MFMAs + the two barriers) + 0.10 .. 0.17 (fragment reads) + 0.20 (the pieces) -- the phases ADDED: a LOAD phase carrying 12 fragment reads and
+  // 3.25 pieces per wave ran ~600 cycles beside a COMPUTE phase of 160, and a piece costs 100 .. 185 issue cycles inside such a phase against ~60 among
+  // bare MFMAs (microarch guide).  The counted wait stays at the end of the LOAD phase (so the second wave group's pieces have landed one interval
+  // before the first group reads them): what must have landed is the next step's stage, issued two steps ago; the previous step's pieces stay in flight.
+  constexpr bool DMAC = G8_DMAC && !CONV && MT < 4 && NS >= 4 && !(G8_ABL & 2);
+  const uint32_t as_addr0 = lds_addr(As), ws_addr0 = lds_addr(Ws);
+  auto issue_slot_asm = [&](int k, int lc, int lslot) {   // (Linear only) piece k of stage lc into ring slot lslot
+    if (k < WI) {
+      const int j = wave + 8 * k;
+      if (lc < nchunk && j < NI_W) glds16_asm((const char*)p.W + (int64_t)lc * BK * 2 + w_off[k], ws_addr0 + (uint32_t)(lslot * (BN * BK) + j * 8 * BK) * 2);
+    } else if (lc < nchunk) {
+      const int i = k - WI, j = wave + 8 * i;
+      if (j < NI_H) glds16_asm(h_ptr[i] + (int64_t)lc * h_step[i], as_addr0 + (uint32_t)(lslot * a_elems + j * 8 * BK) * 2);
+    }
+  };
   int cnt_prev = 0;
   if (CONV) {
 #pragma unroll
@@ -507,6 +540,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll
           for (int i = 0; i < MT; ++i) a0[i] = ab_addr + arow128[i] + ((lq ^ ((arow0[i] + shift) & 7)) << 4);
         }
+        if constexpr (KH == 2) {   // this wave's half of the k-step only: sub-step kh
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            if (!(G8_ABL & 4)) bf[0][j] = lds_read16_off<2048>(kh ? b1 : b0, j);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            if (!(G8_ABL & 4)) af[0][i] = lds_read16(kh ? (a0[i] ^ 64) : a0[i]);
+        } else {
 #pragma unroll
         for (int q = 0; q < SPH; ++q) {
           const int s = h * SPH + q;
@@ -517,16 +558,23 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           for (int i = 0; i < MT; ++i)
             if (!(G8_ABL & 4)) af[s][i] = lds_read16(s ? (a0[i] ^ 64) : a0[i]);
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!DMAC) {
 #pragma unroll
-        for (int k = 0; k < NSLOT; ++k)
-          if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
+          for (int k = 0; k < NSLOT; ++k)
+            if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // after the step's last issue: everything except THIS step's loads has landed (this wave's part), i.e. the next step's stage
         if (h == HALVES - 1) {
           // (NS >= 4, Linear: the stage two steps ahead may stay in flight as well -- what must have landed is the NEXT step's stage)
-          wait_vmcnt(!CONV && NS >= 4 ? cnt_step + cnt_hist : cnt_step);
-          cnt_hist = cnt_step;
+          if constexpr (DMAC) {
+            wait_vmcnt(cnt_hist);      // (this step's pieces go out in the COMPUTE phase below; in flight: the previous step's)
+          } else {
+            wait_vmcnt(!CONV && NS >= 4 ? cnt_step + cnt_hist : cnt_step);
+            cnt_hist = cnt_step;
+          }
         }
 #if G8_PROF
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -538,16 +586,29 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- COMPUTE phase
+        constexpr int NMF = (KH == 2 ? 1 : SPH) * MT * NT;   // MFMAs of the phase; DMAC: piece k goes out behind MFMA (k + 1) NMF / (NSLOT + 1)
 #pragma unroll
-        for (int q = 0; q < SPH; ++q) {
-          const int s = h * SPH + q;
+        for (int q = 0; q < (KH == 2 ? 1 : SPH); ++q) {
+          const int s = KH == 2 ? 0 : h * SPH + q;
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)  // transposed: rows of D = output columns (from W), columns of D = output rows (from A)
+            for (int j = 0; j < NT; ++j) {  // transposed: rows of D = output columns (from W), columns of D = output rows (from A)
               if (!(G8_ABL & 1)) acc[i][j] = TB_MFMA_16x16x32(bf[s][j], af[s][i], acc[i][j]);
               else asm volatile("" ::"v"(bf[s][j]), "v"(af[s][i]));
+              if constexpr (DMAC) {
+                const int mi = (q * MT + i) * NT + j + 1;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k)
+                  if (mi == ((k + 1) * NMF) / (NSLOT + 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_slot_asm(k, lc, lslot);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+              }
+            }
         }
+        if constexpr (DMAC) cnt_hist = cnt_step;
         __builtin_amdgcn_sched_barrier(0);
         G8_PF(2)
         asm volatile("s_barrier" ::: "memory");
@@ -576,13 +637,34 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // ---- epilogue: accumulators -> padded fp32 tile in LDS -> (row, 8 columns) units with 16-byte global accesses.  A thread keeps ONE
   // column group (bias loaded once) and walks rows; all residual / auxiliary loads of its units are issued before the arithmetic.
   float* Cs = reinterpret_cast<float*>(smem_raw);
+  if constexpr (KH == 2) {   // the upper k-half's accumulators go through the staging tile into the lower half's waves (host: one staging pass)
+    static_assert(G8Epi<BM, BN>::PASSES == 1, "k-halves are added through a whole-tile staging pass");
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          *(f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15) * G8Epi<BM, BN>::LDC + (wn * NT + j) * 16 + 4 * lq) = acc[i][j];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4_t o = *(const f32x4_t*)(Cs + ((wm * MT + i) * 16 + l15) * G8Epi<BM, BN>::LDC + (wn * NT + j) * 16 + 4 * lq);
+          acc[i][j] += o;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   if (Ssplit > 1) {  // raw fp32 partial of this k-slice (Linear tiles: wshift = 30, so the row of tile row r is m0 + r)
     float* const dst0 = ws + (int64_t)slice * p.M * npad + n;
     const int64_t Mtot = p.M;
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rp = pass * PR;
-      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+      if (stager && (PASSES == 1 || (wm * MT * 16) / PR == pass)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -646,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rp = pass * PR;
-      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+      if (stager && (PASSES == 1 || (wm * MT * 16) / PR == pass)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -696,7 +778,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rp = pass * PR;
-      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+      if (stager && (PASSES == 1 || (wm * MT * 16) / PR == pass)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -786,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll
       for (int pass = 0; pass < PASSES; ++pass) {
         const int rp = pass * PR;
-        if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+        if (stager && (PASSES == 1 || (wm * MT * 16) / PR == pass)) {
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -960,7 +1042,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rp = pass * PR;
-      if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+      if (stager && (PASSES == 1 || (wm * MT * 16) / PR == pass)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1046,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #pragma unroll 1
   for (int pass = 0; pass < PASSES; ++pass) {
     const int rp = pass * PR;
-    if (PASSES == 1 || (wm * MT * 16) / PR == pass) {
+    if (stager && (PASSES == 1 || (wm * MT * 16) / PR == pass)) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1088,7 +1170,7 @@ thread_local int g8_split = 1;  // k-slices of the launch tb_gemm8_try is making
 thread_local bool g8_dry = false;   // tb_gemm_lnfold_ok: walk the dispatch rules without launching
 int g8_last[7] = {0, 0, 0, 0, 0, 0, 0};  // [0] = 1 when the most recent tb_gemm went through gemm8_kernel<[1], [2], [3], [4], [5]>
 
-template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0>
+template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0, int KH = 1>
 int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
   // SUB == 1: the tile grid walks the COARSE map (a quarter of the output rows) once per output class: S = 4 is the class count, not a k-split
@@ -1117,7 +1199,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   if (lds > 160 * 1024) return 1;
   static bool attr_done = false;
   if (!attr_done && !g8_dry) {
-    if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return TB_ELAUNCH;
     attr_done = true;
@@ -1137,7 +1219,7 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
     g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
     return TB_OK;
   }
-  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
+  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
                      wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn);
   TB_CHECK_LAUNCH();
   g8_split = SUB == 1 ? 1 : S;
@@ -1322,7 +1404,8 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   // 2.5 resident 64x64 tiles of the four-wave kernel move 820 KB per CU at K = 1280, this tile 532 KB
   if (!(g8_enable & 2048) && !ln_act && (d.act == TB_ACT_NONE || d.act == TB_ACT_SILU) && d.N % 80 == 0 && d.M % 128 == 0 && d.K >= 640 && d.K <= 2560) {
     const int64_t tiles = (d.M / 128) * (d.N / 80);
-    if (tiles >= 200 && tiles <= 256) return launch8<8, 1, 1, 5, false, 4>(d, s, 30);
+    if (tiles >= 200 && tiles <= 256)   // (16384: the 8 x 1 waves of round 4 instead of 4 x 1 x 2 k-halves)
+      return (g8_enable & 16384) ? launch8<8, 1, 1, 5, false, 4>(d, s, 30) : launch8<4, 1, 2, 5, false, 4, 0, 2>(d, s, 30);
     // ... and 128 x 160 for the 32x32-map layers (M = 8192, N = 640: 64 x 4 tiles; 369 KB per CU at K = 640 against 491 KB for the 64 x 320 tile)
     const int64_t tiles160 = d.N % 160 == 0 ? (d.M / 128) * (d.N / 160) : 0;
     if (!(g8_enable & 4096) && tiles160 >= 200 && tiles160 <= 256) return launch8<4, 2, 2, 5, false, 4>(d, s, 30);
