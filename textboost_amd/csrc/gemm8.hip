@@ -20,7 +20,7 @@
 #define G8_PROF 0  // profiling build: per-phase s_memtime sums of waves 0 and 4 of workgroup 0 into dbg[16..]
 #endif
 #ifndef G8_DMAC
-#define G8_DMAC 1  // A/B build switch (TB_CFLAGS=-DG8_DMAC=0): the Linear tiles' global -> LDS pieces in the LOAD phase, as in round 4
+#define G8_DMAC 1  // bit 0: DMAC, bit 1: DMACC (measured SLOWER, off), bit 2: DMAC2 (measured neutral, off); A/B build switch (TB_CFLAGS=-DG8_DMAC=n) (TB_CFLAGS=-DG8_DMAC=0): the Linear tiles' global -> LDS pieces in the LOAD phase, as in round 4
 #endif
 #ifndef G8_ABL
 #define G8_ABL 0  // profiling builds (TB_CFLAGS=-DG8_ABL=bits): 1 = no MFMAs, 2 = no in-loop global->LDS loads, 4 = no fragment reads
@@ -67,6 +67,14 @@ __device__ __forceinline__ f16x8 lds_read16_off(uint32_t addr, int j) {  // addr
 __device__ __forceinline__ void glds16_asm(const void* src, uint32_t lds_byte_addr) {
   const uint32_t m = __builtin_amdgcn_readfirstlane(lds_byte_addr);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(src) : "memory", "m0");
+}
+// ... with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit VGPR address (the 256 x 160 convolution tile has none to spare)
+__device__ __forceinline__ void glds16_asm_so(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t bs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);   // (the builtin returns int: no sign extension into the high dword)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(voff), "s"(bs) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt_c() {
@@ -419,14 +427,48 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // bare MFMAs (microarch guide).  The counted wait stays at the end of the LOAD phase (so the second wave group's pieces have landed one interval
   // before the first group reads them): what must have landed is the next step's stage, issued two steps ago; the previous step's pieces stay in flight.
   constexpr bool DMAC = G8_DMAC && !CONV && MT < 4 && NS >= 4 && !(G8_ABL & 2);
+  // DMACC: the same for the 9-tap convolution tiles whose step is TWO phase pairs (MT >= 4: 256 pixels x 160 / 128 channels, 3-slot weight ring): the
+  // pieces of a step go out in its two COMPUTE phases; at the end of the second LOAD phase everything but this step's first-half pieces has landed,
+  // i.e. the next step's weight stage (issued during the previous step) and every halo piece issued before this step
+  // (DMACC measured, one MI355X, scratch/g8_time.py: 320 -> 320 @ 64x64 57.7 -> 65.5 us, 960 -> 320 171 -> 184 us, the step 28.9 -> 30.0 ms: the conv
+  // tile's COMPUTE phase (20 MFMAs) is its critical phase already; off)
+  // DMAC2: Linear tiles with TWO phase pairs per step on a 2-stage ring (the 128 x 128 GEGLU tile, 128 x 320): all pieces of the next stage go out in
+  // the FIRST compute phase; the wait for them stays at the end of the second LOAD phase (vmcnt(0)), one interval before the other wave group reads them
+  // (DMAC2 measured, scratch/geglu_time.py: GEGLU 8192x5120x640 126 -> 119..125 us, 32768x320x1280 46.7 -> 47.8 us, the step 29.00 = 29.00 ms: neutral; off)
+  constexpr bool DMAC2 = (G8_DMAC & 4) && !CONV && MT >= 4 && NS == 2 && !(G8_ABL & 2);
+  constexpr bool DMACC = (G8_DMAC & 2) && CONV && SUB == 0 && MT >= 4 && NS == 3 && !(G8_ABL & 2);
   const uint32_t as_addr0 = lds_addr(As), ws_addr0 = lds_addr(Ws);
+  auto conv_slot_issues = [&](int k, int lc, int c, int tap) -> int {   // DMACC: does this wave issue a piece for slot k in step (c, tap)?
+    if (k < WI) return (lc < nchunk && wave + 8 * k < NI_W) ? 1 : 0;
+    return (tap < MAXHI && c + 1 < nchunk && wave + 8 * tap < NI_H) ? 1 : 0;
+  };
+  auto issue_conv_slot_asm = [&](int k, int lc, int ltap, int lslot, int c, int tap) {   // DMACC: issue_slot's SUB == 0 convolution case as asm pieces
+    if (k < WI) {
+      const int j = wave + 8 * k;
+      if (lc < nchunk && j < NI_W)
+        glds16_asm_so((const char*)p.W + (int64_t)((wtap0 + wtapd * ltap) * kpt + lc) * BK * 2, w_off[k], ws_addr0 + (uint32_t)(lslot * (BN * BK) + j * 8 * BK) * 2);
+    } else {
+      const int j = wave + 8 * tap;
+      if (tap < MAXHI && c + 1 < nchunk && j < NI_H)
+        glds16_asm(h_ptr[tap] + (int64_t)(c + 1) * h_step[tap], as_addr0 + (uint32_t)(((c + 1) & 1) * a_elems + j * 8 * BK) * 2);
+    }
+  };
+  uint32_t a_off[CONV ? 1 : MAXHI];   // Linear: 32-bit byte offsets of this lane's A-panel rows from p.A (rows past M: row 0 -- never stored)
+  if constexpr (!CONV) {
+#pragma unroll
+    for (int i = 0; i < MAXHI; ++i) {
+      const int hr = (wave + 8 * i) * 8 + rl;
+      const int64_t grow = m0 + hr < p.M ? m0 + hr : 0;
+      a_off[i] = (uint32_t)((grow * p.lda + ((cp ^ (hr & 7)) << 3)) * 2);
+    }
+  }
   auto issue_slot_asm = [&](int k, int lc, int lslot) {   // (Linear only) piece k of stage lc into ring slot lslot
     if (k < WI) {
       const int j = wave + 8 * k;
-      if (lc < nchunk && j < NI_W) glds16_asm((const char*)p.W + (int64_t)lc * BK * 2 + w_off[k], ws_addr0 + (uint32_t)(lslot * (BN * BK) + j * 8 * BK) * 2);
+      if (lc < nchunk && j < NI_W) glds16_asm_so((const char*)p.W + (int64_t)lc * BK * 2, w_off[k], ws_addr0 + (uint32_t)(lslot * (BN * BK) + j * 8 * BK) * 2);
     } else if (lc < nchunk) {
       const int i = k - WI, j = wave + 8 * i;
-      if (j < NI_H) glds16_asm(h_ptr[i] + (int64_t)lc * h_step[i], as_addr0 + (uint32_t)(lslot * a_elems + j * 8 * BK) * 2);
+      if (j < NI_H) glds16_asm_so((const char*)p.A + (int64_t)lc * BK * 2, a_off[CONV ? 0 : i], as_addr0 + (uint32_t)(lslot * a_elems + j * 8 * BK) * 2);
     }
   };
   int cnt_prev = 0;
@@ -560,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!DMAC) {
+        if constexpr (!DMAC && !DMACC && !DMAC2) {
 #pragma unroll
           for (int k = 0; k < NSLOT; ++k)
             if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
@@ -571,6 +613,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
           // (NS >= 4, Linear: the stage two steps ahead may stay in flight as well -- what must have landed is the NEXT step's stage)
           if constexpr (DMAC) {
             wait_vmcnt(cnt_hist);      // (this step's pieces go out in the COMPUTE phase below; in flight: the previous step's)
+          } else if constexpr (DMACC) {
+            int n0 = 0;                // in flight: the pieces of this step's FIRST compute phase
+#pragma unroll
+            for (int k = 0; k < SLOTS0; ++k) n0 += conv_slot_issues(k, lc, c, tap);
+            wait_vmcnt(n0);
           } else {
             wait_vmcnt(!CONV && NS >= 4 ? cnt_step + cnt_hist : cnt_step);
             cnt_hist = cnt_step;
@@ -596,6 +643,29 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
             for (int j = 0; j < NT; ++j) {  // transposed: rows of D = output columns (from W), columns of D = output rows (from A)
               if (!(G8_ABL & 1)) acc[i][j] = TB_MFMA_16x16x32(bf[s][j], af[s][i], acc[i][j]);
               else asm volatile("" ::"v"(bf[s][j]), "v"(af[s][i]));
+              if constexpr (DMACC) {   // this half's slots ((h == 0) == (k < SLOTS0)), spread over the phase's MT NT SPH MFMAs
+                constexpr int NMFc = SPH * MT * NT;
+                const int mi = (q * MT + i) * NT + j + 1;
+                const int kf = h == 0 ? 0 : SLOTS0, kn = h == 0 ? SLOTS0 : NSLOT - SLOTS0;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k)
+                  if (k >= kf && k < kf + kn && mi == ((k - kf + 1) * NMFc) / (kn + 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_conv_slot_asm(k, lc, ltap, lslot, c, tap);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+              }
+              if constexpr (DMAC2) {   // first compute phase: every piece of the next stage
+                constexpr int NMF2 = SPH * MT * NT;
+                const int mi = (q * MT + i) * NT + j + 1;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k)
+                  if (h == 0 && mi == ((k + 1) * NMF2) / (NSLOT + 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_slot_asm(k, lc, lslot);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+              }
               if constexpr (DMAC) {
                 const int mi = (q * MT + i) * NT + j + 1;
 #pragma unroll
