@@ -22,6 +22,23 @@
 #ifndef G8_DMAC
 #define G8_DMAC 1  // bit 0: DMAC, bit 1: DMACC (measured SLOWER, off), bit 2: DMAC2 (measured neutral, off); A/B build switch (TB_CFLAGS=-DG8_DMAC=n) (TB_CFLAGS=-DG8_DMAC=0): the Linear tiles' global -> LDS pieces in the LOAD phase, as in round 4
 #endif
+#ifndef G8_DMACC_MASK
+#define G8_DMACC_MASK 0xA  // DMACC: bit k = load slot k of a convolution step goes out in the COMPUTE phase of its half (slots 0 .. WI - 1 weight pieces, WI the halo piece)
+#endif
+#ifndef G8_DMAC_L
+#define G8_DMAC_L 0  // DMAC tiles: load slots of a step that stay in the LOAD phase (experiment: balancing the two phases of the 128 x 160 tile)
+#endif
+#ifndef G8_PSTAMP
+#define G8_PSTAMP 0  // profiling build: extra prologue stamps in dbg[3] (setup done), dbg[4] (prologue stages issued), dbg[5] (their wait done)
+#endif
+#ifndef G8_NT
+#define G8_NT 0  // experiment (TB_CFLAGS=-DG8_NT=1): non-temporal stores in the lean / GEGLU epilogues
+#endif
+#if G8_NT
+#define G8_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define G8_ST(ptr, val) (*(ptr) = (val))
+#endif
 #ifndef G8_ABL
 #define G8_ABL 0  // profiling builds (TB_CFLAGS=-DG8_ABL=bits): 1 = no MFMAs, 2 = no in-loop global->LDS loads, 4 = no fragment reads
 #endif
@@ -285,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
   }
 
+#if G8_PSTAMP
+  G8_STAMP(7)
+#endif
   const int cp = lane & 7, rl = lane >> 3;
   // ---- A-panel sources of this lane (fixed across chunks, + 64 halfs per chunk)
   const f16* h_ptr[MAXHI];
@@ -430,8 +450,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // DMACC: the same for the 9-tap convolution tiles whose step is TWO phase pairs (MT >= 4: 256 pixels x 160 / 128 channels, 3-slot weight ring): the
   // pieces of a step go out in its two COMPUTE phases; at the end of the second LOAD phase everything but this step's first-half pieces has landed,
   // i.e. the next step's weight stage (issued during the previous step) and every halo piece issued before this step
-  // (DMACC measured, one MI355X, scratch/g8_time.py: 320 -> 320 @ 64x64 57.7 -> 65.5 us, 960 -> 320 171 -> 184 us, the step 28.9 -> 30.0 ms: the conv
-  // tile's COMPUTE phase (20 MFMAs) is its critical phase already; off)
+  // (DMACC measured, one MI355X, scratch/g8_time.py: every piece in the COMPUTE phases (G8_DMACC_MASK = 0xF) 320 -> 320 @ 64x64 57.7 -> 65.5 us, 960 -> 320
+  // 171 -> 184 us, the step 28.9 -> 30.0 ms; one piece per half (0xA) 57.1 -> 55.7 / 166 -> 160 us but 29.12 = 29.15 ms in the step: the phase stamps
+  // (-DG8_PROF) say LOAD 527 cycles against COMPUTE 365 per half-step, and the LOAD phase is its 36 KB of fragment reads (288 cycles of LDS transfer at
+  // 128 B/clk), not the two pieces; off)
   // DMAC2: Linear tiles with TWO phase pairs per step on a 2-stage ring (the 128 x 128 GEGLU tile, 128 x 320): all pieces of the next stage go out in
   // the FIRST compute phase; the wait for them stays at the end of the second LOAD phase (vmcnt(0)), one interval before the other wave group reads them
   // (DMAC2 measured, scratch/geglu_time.py: GEGLU 8192x5120x640 126 -> 119..125 us, 32768x320x1280 46.7 -> 47.8 us, the step 29.00 = 29.00 ms: neutral; off)
@@ -471,6 +493,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       if (j < NI_H) glds16_asm_so((const char*)p.A + (int64_t)lc * BK * 2, a_off[CONV ? 0 : i], as_addr0 + (uint32_t)(lslot * a_elems + j * 8 * BK) * 2);
     }
   };
+#if G8_PSTAMP
+  G8_STAMP(3)
+#endif
   int cnt_prev = 0;
   if (CONV) {
 #pragma unroll
@@ -486,7 +511,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   }
   if (NS == 2) cnt_prev = 0;
   int cnt_hist = cnt_prev;   // loads this wave issued in the previous step (prologue: the youngest stage)
+#if G8_PSTAMP
+  G8_STAMP(4)
+#endif
   wait_vmcnt(cnt_prev);                                              // stage 0 (and the first halo) have landed ...
+#if G8_PSTAMP
+  G8_STAMP(5)
+#endif
   if (!CONV && t < BN) {
     bias_s[t] = bias_v;
     if (ln_epi || lnf) bias_s[BN + t] = gam_v, bias_s[2 * BN + t] = bet_v;
@@ -602,21 +633,30 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!DMAC && !DMACC && !DMAC2) {
+        if constexpr (!DMAC && !DMAC2) {
 #pragma unroll
           for (int k = 0; k < NSLOT; ++k)
-            if ((h == 0) == (k < SLOTS0)) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
+            if ((h == 0) == (k < SLOTS0) && !(DMACC && ((G8_DMACC_MASK >> k) & 1))) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
+        }
+        int n_ld = 0;   // DMAC: pieces of this step issued here, in the LOAD phase (G8_DMAC_L slots)
+        if constexpr (DMAC && G8_DMAC_L > 0 && MT * NT >= 10 && WN == 2) {
+#pragma unroll
+          for (int k = 0; k < NSLOT && k < G8_DMAC_L; ++k) {
+            issue_slot(k, lc, ltap, lslot, c, tap, 0);
+            n_ld += (lc < nchunk && (k < WI ? wave + 8 * k < NI_W : wave + 8 * (k - WI) < NI_H)) ? 1 : 0;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         // after the step's last issue: everything except THIS step's loads has landed (this wave's part), i.e. the next step's stage
         if (h == HALVES - 1) {
           // (NS >= 4, Linear: the stage two steps ahead may stay in flight as well -- what must have landed is the NEXT step's stage)
           if constexpr (DMAC) {
-            wait_vmcnt(cnt_hist);      // (this step's pieces go out in the COMPUTE phase below; in flight: the previous step's)
+            wait_vmcnt(cnt_hist + n_ld);      // (this step's pieces go out in the COMPUTE phase below; in flight: the previous step's)
           } else if constexpr (DMACC) {
-            int n0 = 0;                // in flight: the pieces of this step's FIRST compute phase
+            int n0 = 0;                // in flight: this step's pieces issued so far (all but the second compute phase's)
 #pragma unroll
-            for (int k = 0; k < SLOTS0; ++k) n0 += conv_slot_issues(k, lc, c, tap);
+            for (int k = 0; k < NSLOT; ++k)
+              if (k < SLOTS0 || !((G8_DMACC_MASK >> k) & 1)) n0 += conv_slot_issues(k, lc, c, tap);
             wait_vmcnt(n0);
           } else {
             wait_vmcnt(!CONV && NS >= 4 ? cnt_step + cnt_hist : cnt_step);
@@ -649,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
                 const int kf = h == 0 ? 0 : SLOTS0, kn = h == 0 ? SLOTS0 : NSLOT - SLOTS0;
 #pragma unroll
                 for (int k = 0; k < NSLOT; ++k)
-                  if (k >= kf && k < kf + kn && mi == ((k - kf + 1) * NMFc) / (kn + 1)) {
+                  if (k >= kf && k < kf + kn && ((G8_DMACC_MASK >> k) & 1) && mi == ((k - kf + 1) * NMFc) / (kn + 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_conv_slot_asm(k, lc, ltap, lslot, c, tap);
                     __builtin_amdgcn_sched_barrier(0);
@@ -668,9 +708,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
               }
               if constexpr (DMAC) {
                 const int mi = (q * MT + i) * NT + j + 1;
+                constexpr int KF = (G8_DMAC_L > 0 && MT * NT >= 10 && WN == 2) ? (G8_DMAC_L < NSLOT ? G8_DMAC_L : NSLOT) : 0;   // slots already issued in the LOAD phase
 #pragma unroll
-                for (int k = 0; k < NSLOT; ++k)
-                  if (mi == ((k + 1) * NMF) / (NSLOT + 1)) {
+                for (int k = KF; k < NSLOT; ++k)
+                  if (mi == ((k - KF + 1) * NMF) / (NSLOT - KF + 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_slot_asm(k, lc, lslot);
                     __builtin_amdgcn_sched_barrier(0);
@@ -826,10 +867,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
             }
             if ((G8_ABL & 8) && alpha != 12345.f) continue;  // profiling: no global stores
             if (C2g) {
-              *(f16x8*)(C2g + m * ldc2) = oh;
-              *(f16x8*)(C2g + m * ldc2 + 32) = og8;
+              G8_ST((f16x8*)(C2g + m * ldc2), oh);
+              G8_ST((f16x8*)(C2g + m * ldc2 + 32), og8);
             }
-            *(f16x8*)(Cg + m * ldc) = oo;
+            G8_ST((f16x8*)(Cg + m * ldc), oo);
           }
         }
       }
@@ -882,8 +923,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
               dh[e] = (f16)(v * ge);
               dg[e] = (f16)(v * (float)hv[it][e] * dge);
             }
-            *(f16x8*)(Cg + m * ldc) = dh;
-            *(f16x8*)(Cg + m * ldc + 32) = dg;
+            G8_ST((f16x8*)(Cg + m * ldc), dh);
+            G8_ST((f16x8*)(Cg + m * ldc + 32), dg);
           }
         }
       }
@@ -1167,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
                 if (RS_OK) ssum += (float)o[e], ssq += (float)o[e] * (float)o[e];
               }
             }
-            if (!(G8_ABL & 8) || alpha == 12345.f) *(f16x8*)(Cg + m * ldc) = o;
+            if (!(G8_ABL & 8) || alpha == 12345.f) G8_ST((f16x8*)(Cg + m * ldc), o);
             if (rs_prod) red[row * UPR + cg] = f32x2r_t{ssum, ssq};
           }
         }
