@@ -237,7 +237,7 @@ def test_attention_bwd_short_key_dq_kernel(B, H, Sq, Skv, hd):
     res = []
     prev = L.lib().tb_attention_set_variant(1)
     try:
-        for variant in (1, 1 | 16384):
+        for variant in (1 | 65536, 1 | 65536 | 16384):     # (65536: not round 5's one-launch backward, tested below)
             L.lib().tb_attention_set_variant(variant)
             o = torch.empty(B * Sq, C, device="cuda", dtype=torch.float16)
             lse = torch.empty(B, H, Sq, device="cuda")
@@ -256,6 +256,50 @@ def test_attention_bwd_short_key_dq_kernel(B, H, Sq, Skv, hd):
     finally:
         L.lib().tb_attention_set_variant(prev)
     assert rel_err(res[0], res[1]) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,hd", [(2, 8, 4096, 77, 40), (8, 8, 4096, 77, 40), (8, 8, 1024, 77, 80), (2, 8, 1024, 77, 40), (1, 5, 1152, 77, 64),
+                                           (2, 4, 1024, 50, 40), (1, 3, 2048, 96, 24), (2, 5, 2304, 77, 64)])
+def test_attention_bwd_cross_attention_in_one_launch(B, H, Sq, Skv, hd):
+    """attn_xs_bwd_kernel (round 5; diffusers attn2 backward, train_textboost.py:1108): dQ, dK and dV of the cross-attention on the prompt tokens in
+    ONE launch over query slices (+ the finalize of the dK / dV slices) -- Q and dO staged once per tile, delta = rowsum(P * dP) so the attention
+    output is not read -- against autograd and against the three launches it replaces (tb_attention_set_variant bit 65536).  `delta` is not an
+    output of this path (nothing downstream reads it)."""
+    from textboost_amd import _lib as L
+    ops = _ops()
+    torch.manual_seed(14)
+    C = H * hd
+    q = torch.randn(B * Sq, C, device="cuda").half()
+    kv = torch.randn(B * Skv, 2 * C, device="cuda").half()
+    k, v = kv[:, :C], kv[:, C:]
+    do = torch.randn(B * Sq, C, device="cuda").half()
+    qr, kr, vr = [t.float().reshape(B, -1, C).requires_grad_(True) for t in (q, k, v)]
+    oref, _ = ref_attention(qr, kr, vr, H, False)
+    oref.backward(do.float().view(B, Sq, C))
+    res = []
+    prev = L.lib().tb_attention_set_variant(1)
+    try:
+        for variant in (1 | 131072, 1 | 65536):     # (131072: the one-launch kernel also for hd = 80, where the default keeps the three launches)
+            L.lib().tb_attention_set_variant(variant)
+            o = torch.empty(B * Sq, C, device="cuda", dtype=torch.float16)
+            lse = torch.empty(B, H, Sq, device="cuda")
+            ops.attention_fwd(q, k, v, o, lse, B, H, Sq, Skv, hd)
+            delta = torch.full((B, H, Sq), 7.0, device="cuda")
+            dqb = torch.full((B * Sq, C + 8), 5.0, device="cuda", dtype=torch.float16)
+            dq = dqb[:, :C]
+            dkv = torch.empty(B * Skv, 2 * C, device="cuda", dtype=torch.float16)
+            ws = torch.empty(16 * 2 * B * Skv * C, device="cuda")
+            if variant == (1 | 131072) and hd in (40, 64, 80):
+                o.fill_(float("nan"))     # the one-launch path must not read the attention output
+            ops.attention_bwd(q, k, v, o, lse, do, delta, dq, dkv[:, :C], dkv[:, C:], B, H, Sq, Skv, hd, ws=ws)
+            assert (dqb[:, C:] == 5.0).all()
+            parity(f"cross-attention dQ variant {variant}", dq.reshape(B, Sq, C), qr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+            parity(f"cross-attention dK variant {variant}", dkv[:, :C].reshape(B, Skv, C), kr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+            parity(f"cross-attention dV variant {variant}", dkv[:, C:].reshape(B, Skv, C), vr.grad, rel=4e-3, maxabs=6e-3, ch_dim=2, ch_rel=6e-3)
+            res.append((dq.clone(), dkv.clone()))
+    finally:
+        L.lib().tb_attention_set_variant(prev)
+    assert rel_err(res[0][0], res[1][0]) < 1.5e-3 and rel_err(res[0][1], res[1][1]) < 1.5e-3
 
 
 def test_attention_online_softmax_rescale_branch():

@@ -1780,6 +1780,316 @@ __global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_bwd_dkv_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ, dK, dV in ONE launch, short key sequences
+// Round 5 (diffusers BasicTransformerBlock.attn2 backward, train_textboost.py:1108): the cross-attention backward on the 77 prompt tokens was three
+// launches -- attn_xs_bwd_dq_kernel (reads Q, dO, O; publishes delta), attn_bwd_dkv_kernel over query slices (reads Q, dO again) and the finalize of its
+// fp32 slices -- 72 / 51 us per layer on the 64x64 / 32x32 maps for work that is bounded by reading Q and dO once and writing dQ once.  Here a
+// workgroup owns a query slice, stages each 64-query tile of Q and dO ONCE (row-major + transposed images, as attn_bwd_dkv_kernel) beside resident
+// images of all <= 96 keys (K scaled by scale * log2 e, V, K transposed), and computes
+//   * delta = rowsum(P * dP) instead of rowsum(dO * O)  (O = P V, so dO . O = sum_k P_k (dO . V_k) = sum_k P_k dP_k): the attention OUTPUT is not read;
+//   * dQ in the lane-owns-a-query orientation (S^T = K Q^T, dQ^T = K^T dS^T): waves 0 / 1 make delta for query groups 0 / 1, waves 2 / 3 then dQ;
+//   * dK / dV in the lane-owns-a-key orientation (waves 0 .. 2 = keys 0 .. 95), accumulated over the slice's tiles and left as fp32 partials
+//     [slice][{K, V}][B * Skv][H * hd] for attn_dkv_finalize_kernel (same layout and order as attn_bwd_dkv_kernel's: deterministic).
+// The scores are recomputed per orientation (77 keys: the matrix work is small beside the traffic).  Host: no causal mask, 32 < Skv <= 96, Sq % 64 == 0.
+template <int DT, int KS, int PC, int NST>
+__global__ __launch_bounds__(256, (DT <= 2 ? 2 : 1)) void attn_xs_bwd_kernel(const tb_attn_desc p, int q_chunk, float* ws32, int remap) {
+  // Staging as attn_bwd_dkv_dma_kernel: the 64-query Q / dO tiles (and their LSE values) go HBM -> LDS by global_load_lds, row-major only, through
+  // an NST-slot ring with counted vmcnt; row-major fragments by ds_read_b128, the transposed Q^T / dO^T operands of dK / dV by ds_read_b64_tr_b16
+  // from the same rows.  (The first version staged through registers one tile ahead, like attn_bwd_dkv_kernel: 56 us at the 64x64 maps, the sum of
+  // the two launches it replaced -- 10 KB per workgroup in flight is a quarter of what the memory latency needs.)
+  constexpr int PCB = PC * 16, TILE_B = KVT * PCB;
+  constexpr int STAGE_B = 2 * TILE_B + KVT * 4 + 64;   // Q tile, dO tile, lse[64], slack for the tr reads past the last pad chunk
+  constexpr int NI = 2 * PC + 1, WI = (NI + 3) / 4;
+  constexpr int TP = 100;                               // row pitch (halfs) of the transposed K image [32 DT][96 keys]
+  static_assert(NST >= 3, "loads run two tiles ahead");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* const Kc = smem_raw + NST * STAGE_B;   // [96][PCB]  K * scale * log2(e), zero outside Skv x hd
+  unsigned char* const Vr = Kc + 96 * PCB;              // [96][PCB]
+  f16* const Tk = reinterpret_cast<f16*>(Vr + 96 * PCB);   // [32 DT][TP]  K^T (unscaled)
+  float* const del_s = reinterpret_cast<float*>(Tk + 32 * DT * TP);   // [64]  -delta of the current tile
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Roles by a ROTATED wave index: two workgroups share a CU and wave w of each sits on SIMD w -- with the same roles in both, the delta phase
+  // (two waves) ran on SIMDs 0 / 1 of both while SIMDs 2 / 3 idled.  Workgroups 256 apart in launch order (the likely CU mates) rotate by two.
+  const int wave = (wave_hw + 2 * (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1)) & 3;
+  AttnBlk blk;   // (query slice, batch) pairs per XCD, heads back to back (as attn_xs_bwd_dq_kernel)
+  {
+    const int gx = gridDim.x, H = gridDim.y, B = gridDim.z;
+    if (remap && ((gx * B) & 7) == 0) {
+      const int lin = blockIdx.x + gx * (blockIdx.y + H * blockIdx.z);
+      const int xcd = lin & 7, k = lin >> 3;
+      const int xb = (k / H) * 8 + xcd;
+      blk.h = k - (k / H) * H;
+      blk.x = xb % gx;
+      blk.b = xb / gx;
+    } else {
+      blk.x = blockIdx.x, blk.h = blockIdx.y, blk.b = blockIdx.z;
+    }
+  }
+  const int b = blk.b, h = blk.h, qslice = blk.x, hd = p.hd;
+  const int q_begin = qslice * q_chunk;
+  const int q_end = min(p.Sq, q_begin + q_chunk);
+  const int ntiles = (q_end - q_begin) / KVT;
+  const int64_t ldq = p.ldq, lddo = p.lddo;
+  const char* Qg = (const char*)((const f16*)p.Q + ((int64_t)b * p.Sq + q_begin) * ldq + h * hd);
+  const char* dOg = (const char*)((const f16*)p.dO + ((int64_t)b * p.Sq + q_begin) * lddo + h * hd);
+  const f16* Kg = (const f16*)p.K + (int64_t)b * p.Skv * p.ldk + h * hd;
+  const f16* Vg = (const f16*)p.V + (int64_t)b * p.Skv * p.ldv + h * hd;
+  const char* LSEg = (const char*)(p.LSE + ((int64_t)b * p.H + h) * p.Sq + q_begin);
+  const float c = p.scale * LOG2E;
+  // ---- this lane's part of a stage's loads: instruction t = wave + 4 i; t < PC: Q rows, t < 2 PC: dO rows, t == 2 PC: the 64 LSE values
+  uint32_t g_off[WI];
+  bool g_on[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int t = wave_hw + 4 * i;
+    const int tensor = t >= PC ? 1 : 0;
+    const int f = (t - tensor * PC) * 64 + lane;
+    const int row = f / PC, cc = f - row * PC;
+    g_on[i] = t < 2 * PC && cc < PC - 1;
+    g_off[i] = (uint32_t)((int64_t)row * (tensor ? lddo : ldq) * 2 + cc * 16);
+  }
+  int n_issued = 0;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) n_issued += (wave_hw + 4 * i < NI) ? 1 : 0;
+  auto stage_loads = [&](int tile, int slot) {
+    unsigned char* dst = smem_raw + slot * STAGE_B;
+    const char* qb = Qg + (int64_t)tile * KVT * ldq * 2;
+    const char* ob = dOg + (int64_t)tile * KVT * lddo * 2;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int t = wave_hw + 4 * i;
+      if (t < 2 * PC) {
+        const char* src = (t >= PC ? ob : qb) + g_off[i];
+        if (g_on[i]) __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + t * 1024), 16, 0, 0);
+      } else if (t < NI) {  // 64 floats = one dword per lane
+        const char* src = LSEg + ((int64_t)tile * KVT + lane) * 4;
+        __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(dst + 2 * TILE_B), 4, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < ntiles) stage_loads(st, st);
+  // pad chunks of every row of every stage: zeros (they meet the zero padding of the key images, but must be finite)
+  for (int u = threadIdx.x; u < 2 * KVT * NST; u += 256) {
+    const int st = u / (2 * KVT), r = u - st * 2 * KVT;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(smem_raw + st * STAGE_B + (r >= KVT ? TILE_B : 0) + (r & (KVT - 1)) * PCB + (PC - 1) * 16) = z;
+  }
+  // ---- resident key images: unit = (key, 16-byte chunk); zero outside Skv x hd (plain loads: older than nothing the counted waits protect)
+  for (int u = threadIdx.x; u < 96 * PC; u += 256) {
+    const int key = u / PC, ch = u - key * PC;
+    const bool ok = key < p.Skv && ch * 8 < hd;
+    const f16x8 kv = *(ok ? (gvec8_t)(Kg + (int64_t)key * p.ldk + ch * 8) : (gvec8_t)g_zero8);
+    const f16x8 vv = *(ok ? (gvec8_t)(Vg + (int64_t)key * p.ldv + ch * 8) : (gvec8_t)g_zero8);
+    f16x8 ks;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ks[e] = (f16)((float)kv[e] * c);
+      if (ch * 8 + e < 32 * DT) Tk[(ch * 8 + e) * TP + key] = kv[e];
+    }
+    *(f16x8*)(Kc + key * PCB + ch * 16) = ks;
+    *(f16x8*)(Vr + key * PCB + ch * 16) = vv;
+  }
+  if (PC * 8 < 32 * DT) {   // rows of the transposed image behind the last chunk (hd = 40: rows 48 .. 63): finite
+    for (int u = threadIdx.x; u < (32 * DT - PC * 8) * 96; u += 256) Tk[(PC * 8 + u / 96) * TP + (u % 96)] = (f16)0.f;
+  }
+  const int key_b = wave * 32 + l31;          // this lane's key in the dK / dV orientation (waves 0 .. 2)
+  const bool kok = wave < 3 && key_b < p.Skv;
+  f32x16 dk[DT], dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    ZERO16(dk[d]);
+    ZERO16(dv[d]);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lptr_t)smem_raw;
+  const uint32_t rm_lane = l31 * PCB + hi * 16;   // row-major fragment: row l31 (+ 32 g), chunk 2 j + hi
+  const int g4l = lane >> 4, j16 = lane & 15;
+  const uint32_t tr_lane = (4 * (g4l >> 1) + (j16 >> 2)) * PCB + ((g4l & 1) * 16 + 4 * (j16 & 3)) * 2;  // as attn_bwd_dkv_dma_kernel's Q^T / dO^T reads
+  int slot = 0, lslot = NST - 1;
+  for (int t = 0; t < ntiles; ++t) {
+    {
+      int later = ntiles - 1 - t;
+      later = later > NST - 2 ? NST - 2 : later;
+      attn_wait_vmcnt(later * n_issued);   // (waves 2 / 3 also have dQ stores in flight: the count then waits for a little more than it must)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t has landed; every wave has left tile t - 1 (first pass: the key images)
+    if (t + NST - 1 < ntiles) stage_loads(t + NST - 1, lslot);
+    const unsigned char* Qs = smem_raw + slot * STAGE_B;
+    const float* lse_s = (const float*)(Qs + 2 * TILE_B);
+    // ---- delta of query group g = wave (waves 0, 1): rowsum over the keys of P * dP, lane = query
+    if (wave < 2) {
+      const int g = wave;
+      const float nl = -lse_s[g * 32 + l31] * LOG2E;
+      float acc = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        f32x16 sc, dp;
+        FILL16(sc, nl);
+        ZERO16(dp);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          sc = TB_MFMA_32x32x16(*(const f16x8*)(Kc + (kt * 32 + l31) * PCB + (2 * j + hi) * 16), *(const f16x8*)(Qs + rm_lane + g * 32 * PCB + j * 32), sc);
+          dp = TB_MFMA_32x32x16(*(const f16x8*)(Vr + (kt * 32 + l31) * PCB + (2 * j + hi) * 16), *(const f16x8*)(Qs + TILE_B + rm_lane + g * 32 * PCB + j * 32), dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + mfma32_row(r, hi);
+          if (key < p.Skv) acc += fast_exp2(sc[r]) * dp[r];
+        }
+      }
+      const float delta = acc + __shfl_xor(acc, 32, 64);
+      if (hi == 0) del_s[g * 32 + l31] = -delta;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- dQ of query group g = wave - 2 (waves 2, 3): dS^T = P (dP - delta), dQ^T = K^T dS^T
+    if (wave >= 2) {
+      const int g = wave - 2;
+      const float nl = -lse_s[g * 32 + l31] * LOG2E, nd = del_s[g * 32 + l31];
+      f32x16 dq[DT];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) ZERO16(dq[d]);
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        f32x16 sc, dp;
+        FILL16(sc, nl);
+        FILL16(dp, nd);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          sc = TB_MFMA_32x32x16(*(const f16x8*)(Kc + (kt * 32 + l31) * PCB + (2 * j + hi) * 16), *(const f16x8*)(Qs + rm_lane + g * 32 * PCB + j * 32), sc);
+          dp = TB_MFMA_32x32x16(*(const f16x8*)(Vr + (kt * 32 + l31) * PCB + (2 * j + hi) * 16), *(const f16x8*)(Qs + TILE_B + rm_lane + g * 32 * PCB + j * 32), dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + mfma32_row(r, hi);
+          sc[r] = key < p.Skv ? fast_exp2(sc[r]) * dp[r] : 0.f;   // dS^T / scale
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const f16x8 dsf = pack8(sc, 8 * jj);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const f16* row = Tk + (d * 32 + l31) * TP + kt * 32 + 16 * jj + 4 * hi;   // contraction indices {k0 + 4 hi .. + 3, k0 + 8 + 4 hi .. + 3}
+            const f16x4 a0 = *(const f16x4*)row, a1 = *(const f16x4*)(row + 8);
+            f16x8 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = a0[e], a[4 + e] = a1[e];
+            dq[d] = TB_MFMA_32x32x16(a, dsf, dq[d]);
+          }
+        }
+      }
+      f16* dQg = (f16*)p.dQ + ((int64_t)b * p.Sq + q_begin + t * KVT + g * 32 + l31) * p.lddq + h * hd;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int col = d * 32 + 8 * r4 + 4 * hi;
+          if (col < hd) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(dq[d][4 * r4 + e] * p.scale);
+            *(f16x4*)(dQg + col) = v;
+          }
+        }
+    }
+    // ---- dK / dV of keys 32 wave .. + 31 (waves 0 .. 2), both 32-query halves: the inner loop of attn_bwd_dkv_dma_kernel
+    if (wave < 3) {
+      f16x8 kf[KS], vf[KS];
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        kf[j] = *(const f16x8*)(Kc + (wave * 32 + l31) * PCB + (2 * j + hi) * 16);
+        vf[j] = *(const f16x8*)(Vr + (wave * 32 + l31) * PCB + (2 * j + hi) * 16);
+      }
+      const uint32_t qa = lds0 + slot * STAGE_B + tr_lane;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 s, dp;  // start from -lse2 / -delta of the tile's queries: rows of register quad g are 8 g + 4 hi + {0..3}
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 lq = *(const f32x4*)(lse_s + qt * 32 + 8 * q4 + 4 * hi);
+          const f32x4 dq4 = *(const f32x4*)(del_s + qt * 32 + 8 * q4 + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s[4 * q4 + e] = -lq[e] * LOG2E;
+            dp[4 * q4 + e] = dq4[e];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const f16x8 qfr = *(const f16x8*)(Qs + rm_lane + qt * 32 * PCB + j * 32);
+          const f16x8 dofr = *(const f16x8*)(Qs + TILE_B + rm_lane + qt * 32 * PCB + j * 32);
+          s = TB_MFMA_32x32x16(qfr, kf[j], s);
+          dp = TB_MFMA_32x32x16(dofr, vf[j], dp);
+        }
+        f16x4 qtf[2][DT][2], dotf[2][DT][2];
+        __builtin_amdgcn_sched_barrier(0);
+#define TB_TR(ARR, BASE, QT, JJ, D, HH) ARR[JJ][D][HH] = lds_tr_read_off<(BASE) + ((QT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(qa);
+#define TB_TR_D(ARR, BASE, QT, D) TB_TR(ARR, BASE, QT, 0, D, 0) TB_TR(ARR, BASE, QT, 0, D, 1) TB_TR(ARR, BASE, QT, 1, D, 0) TB_TR(ARR, BASE, QT, 1, D, 1)
+#define TB_TR_ALL(QT)                                                                   \
+  TB_TR_D(qtf, 0, QT, 0) TB_TR_D(qtf, 0, QT, 1)                                         \
+  if (DT > 2) { TB_TR_D(qtf, 0, QT, (DT > 2 ? 2 : 0)) }                                 \
+  TB_TR_D(dotf, TILE_B, QT, 0) TB_TR_D(dotf, TILE_B, QT, 1)                             \
+  if (DT > 2) { TB_TR_D(dotf, TILE_B, QT, (DT > 2 ? 2 : 0)) }
+        static_assert(DT == 2 || DT == 3, "hd = 40 / 64 / 80 instantiations");
+        if (qt == 0) { TB_TR_ALL(0) } else { TB_TR_ALL(1) }
+#undef TB_TR_D
+#undef TB_TR_ALL
+#undef TB_TR
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = kok ? fast_exp2(s[r]) : 0.f;
+          s[r] = pv;            // P
+          dp[r] = pv * dp[r];   // dS / scale
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed fragments (inline-asm reads: not counted by the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const f16x8 pf = pack8(s, 8 * jj);
+          const f16x8 dsf = pack8(dp, 8 * jj);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            f16x8 a, cq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a[e] = dotf[jj][d][0][e], a[4 + e] = dotf[jj][d][1][e];
+              cq[e] = qtf[jj][d][0][e], cq[4 + e] = qtf[jj][d][1][e];
+            }
+            dv[d] = TB_MFMA_32x32x16(a, pf, dv[d]);
+            dk[d] = TB_MFMA_32x32x16(cq, dsf, dk[d]);
+          }
+        }
+      }
+    }
+    slot = slot == NST - 1 ? 0 : slot + 1;
+    lslot = lslot == NST - 1 ? 0 : lslot + 1;
+  }
+  if (kok) {
+    const int64_t C = (int64_t)p.H * hd;
+    const int64_t plane = (int64_t)p.B * p.Skv * C;
+    float* dK32 = ws32 + (int64_t)qslice * 2 * plane + ((int64_t)b * p.Skv + key_b) * C + h * hd;
+    float* dV32 = dK32 + plane;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int col = d * 32 + 8 * r4 + 4 * hi;
+        if (col < hd) {
+          f32x4 a, bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = dk[d][4 * r4 + e] * p.scale;
+            bb[e] = dv[d][4 * r4 + e];
+          }
+          *(f32x4*)(dK32 + col) = a;
+          *(f32x4*)(dV32 + col) = bb;
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_dkv_finalize_kernel(const float* __restrict__ ws32, f16* __restrict__ dK, int64_t lddk,
                                                                 f16* __restrict__ dV, int64_t lddv, int64_t rows, int C, int qsplit) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1878,6 +2188,39 @@ int launch_fwd(const tb_attn_desc& d, hipStream_t s) {
 template <int DT, int KS>
 int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
   constexpr int WD = DT * 32;
+  if constexpr ((DT == 2 && KS == 3) || (DT == 2 && KS == 4) || (DT == 3 && KS == 5)) {
+    // cross-attention on the prompt (32 < Skv <= 96; hd = 40 / 64 / 80): dQ, dK, dV in one launch over query slices + the finalize of the dK / dV
+    // slices (tb_attention_set_variant bit 65536 = the three-launch path of round 4)
+    constexpr int PC = KS == 3 ? 6 : (KS == 4 ? 9 : 11), NST = 3;
+    const int64_t C = (int64_t)d.H * d.hd, plane2 = 2 * (int64_t)d.B * d.Skv * C;
+    // measured (scratch/xbwd_time.py, B = 8, 77 keys): hd = 40 at 64x64 maps 66 -> 59 us per layer, hd = 80 at 32x32 maps 48 -> 53 us (three staged
+    // images and three score products per tile on one workgroup per CU): the wide heads keep the three launches unless bit 131072 asks
+    const bool wide_ok = KS <= 4 || (g_attn_dma & 131072);
+    if (!(g_attn_dma & 65536) && wide_ok && d.hd == (KS == 3 ? 40 : (KS == 4 ? 64 : 80)) && !d.causal && d.Skv <= 96 && d.Skv > 32 && d.Sq % KVT == 0 && d.Sq >= 256 &&
+        d.ws && d.ws_floats >= 2 * plane2 && d.ldq % 8 == 0 && d.lddo % 8 == 0 && (int64_t)KVT * (d.ldq > d.lddo ? d.ldq : d.lddo) * 2 < ((int64_t)1 << 31)) {
+      const int64_t bh = (int64_t)d.H * d.B;
+      int nsl = (int)((512 + bh - 1) / bh);                     // ~512 workgroups
+      const int max_sl = d.Sq / (2 * KVT);                      // >= 2 tiles per slice
+      if (nsl > max_sl) nsl = max_sl;
+      if ((int64_t)nsl * plane2 > d.ws_floats) nsl = (int)(d.ws_floats / plane2);
+      if (nsl < 1) nsl = 1;
+      int q_chunk = ((d.Sq + nsl - 1) / nsl + KVT - 1) / KVT * KVT;
+      nsl = (d.Sq + q_chunk - 1) / q_chunk;
+      const size_t lds = (size_t)NST * (2 * KVT * PC * 16 + KVT * 4 + 64) + 2 * 96 * PC * 16 + (size_t)32 * DT * 100 * 2 + KVT * 4;
+      static bool attr_x = false;
+      if (!attr_x && lds > 65536) {
+        if (hipFuncSetAttribute((const void*)attn_xs_bwd_kernel<DT, KS, PC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return TB_ELAUNCH;
+        attr_x = true;
+      }
+      hipLaunchKernelGGL((attn_xs_bwd_kernel<DT, KS, PC, NST>), dim3(nsl, d.H, d.B), dim3(256), lds, s, d, q_chunk, d.ws, ((g_attn_dma >> 2) & 1) ^ 1);
+      const int64_t rows = (int64_t)d.B * d.Skv;
+      hipLaunchKernelGGL(attn_dkv_finalize_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, s, d.ws, (f16*)d.dK, d.lddk,
+                         (f16*)d.dV, d.lddv, rows, (int)C, nsl);
+      TB_CHECK_LAUNCH();
+      return TB_OK;
+    }
+  }
   // LDS-DMA staged dK/dV kernel: the SD1.x 64x64-map self-attention shape; needs 2 * B * H * Sq floats of ws for the statistics the dQ
   // kernel publishes for it (else, and for every other shape, the register-staged kernel runs)
   const bool dkv_dma = ((DT == 2 && KS == 3 && d.hd == 40) || (DT == 2 && KS == 4 && d.hd == 64 && !(g_attn_dma & 512)) ||
