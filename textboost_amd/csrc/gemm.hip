@@ -92,13 +92,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const tb_gemm_desc p
   splitk_reduce_unit<false>(p, f, ws, S, npad, m, n);
 }
 
+// conv_halo_kernel on 8-wide maps (round 5): lane l31 of a 32-column MFMA tile owns output pixel halo_perm32(l31) of the tile's 32-pixel block, not
+// pixel l31.  A ds_read_b128 is served in 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) and, with 128-byte LDS rows and the
+// (row >> 1) & 7 chunk swizzle, is conflict-free iff a group's 16 rows are distinct mod 16.  With the pixels in lane order and the 10-pixel halo pitch
+// the rows of a group are {R..R+3, R+14..R+17, R+24..R+27, R+30..R+33}: 3-way conflicts (PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.47, the
+// worst of the step).  With a 12-pixel halo pitch the four image rows of a block sit at 0, 12, 24, 36 (mod 16: 0, 12, 8, 4) and giving group 0 the
+// image rows 0 / 2 and group 1 the rows 1 / 3 makes every group's rows {R..R+7, R+24..R+31}: all residues once.
+__device__ __forceinline__ int halo_perm32(int l) {
+  return l < 4 ? l : (l < 12 ? l + 4 : (l < 16 ? l - 8 : (l < 20 ? l + 8 : (l < 28 ? l - 4 : l))));
+}
+
 // Shared epilogue of the MFMA kernels (gemm_kernel, conv_halo_kernel): accumulators -> LDS -> coalesced global writes.
 // PASSES = 2 stages the tile in two halves of BM/2 rows (the rows of the waves with wm == pass), which halves the LDS the epilogue
 // needs: with 32-wide k-tiles the operand stages then bound the block's LDS and a third / fourth block fits on the CU.
 template <int BM, int BN, int TM, int TN, int PASSES>
 __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, int64_t m0, int64_t n0,
                                               int wm, int wn, int S, int slice, float* __restrict__ ws, int64_t npad, int mshift = 30,
-                                              int mstride = 0, bool lean_ok = true, int tile_id = 0) {
+                                              int mstride = 0, bool lean_ok = true, int tile_id = 0, bool perm32 = false) {
   // tile row r (0..BM-1) is output row  m0 + (r >> mshift) * mstride + (r & (2^mshift - 1)):  contiguous rows for the GEMMs (defaults),
   // a 2^mshift-pixel-wide block of image rows (mstride = image width) for the LDS-halo conv
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -167,7 +177,8 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
     __syncthreads();
     const int rp = pass * PR;  // first tile row of this pass
     auto m_of = [&](int row) -> int64_t {
-      const int r = rp + row;
+      const int r0_ = rp + row;
+      const int r = perm32 ? ((r0_ & ~31) | halo_perm32(r0_ & 31)) : r0_;   // (conv_halo_kernel on 8-wide maps: the pixel a tile row's lane owns)
       const int64_t m = m0 + (int64_t)(r >> mshift) * mstride + (r & ((1 << mshift) - 1));
       if (p.a_mode == TB_A_CONV3X3 && p.transposed == 2) {  // phase-ordered tile rows (gemm_kernel) back to map order
         const int64_t mq = p.M >> 2;
@@ -387,7 +398,8 @@ __device__ __forceinline__ void tile_epilogue(const tb_gemm_desc& p, f32x16 (&ac
     if (!last_slice) return;
     constexpr int UPRT = BN / 8;
     for (int u = t; u < BM * UPRT; u += 256) {
-      const int r = u / UPRT, cgu = u - r * UPRT;
+      const int r0_ = u / UPRT, cgu = u - r0_ * UPRT;
+      const int r = perm32 ? ((r0_ & ~31) | halo_perm32(r0_ & 31)) : r0_;
       int64_t m = m0 + (int64_t)(r >> mshift) * mstride + (r & ((1 << mshift) - 1));
       const int64_t n = n0 + cgu * 8;
       if (m >= p.M || n >= p.N) continue;
@@ -753,8 +765,8 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
 // rows or, for wider / non-power-of-two maps, a (128/TW) x TW block with TW the largest power of two <= 64 dividing W): for each 64-channel chunk the (R+2) x (W+2) input pixels the tile needs are fetched ONCE and all 9 taps read their A
 // fragments from that halo at shifted row addresses; only the weight tiles stream per tap.  Compared with gemm_kernel's
 // per-tap gather this moves 4.4x fewer activation bytes through the L2->LDS path that bounds the kernel.
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int S,
+template <int BN, int NSW = 2>
+__global__ __launch_bounds__(256, (NSW > 2 ? 1 : 2)) void conv_halo_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int S,
                                                              float* __restrict__ ws, int64_t npad) {
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   f16* smem = reinterpret_cast<f16*>(smem_raw);
@@ -774,10 +786,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   const int TW = 1 << wshift, W = p.Wout, H = p.Hout, R = BM >> wshift;
   const int hw_img = H * W;
   const bool multi = hw_img < BM;                       // host: then W == TW and BM % hw_img == 0
-  const int HC = TW + 2, HIMG = (H + 2) * HC;           // halo pixels per image (multi)
+  const bool perm = multi && TW == 8 && (p.shift == 0x100);   // 8-wide maps: 12-pixel halo pitch + permuted lanes (halo_perm32)
+  const int HC = perm ? 12 : TW + 2, HIMG = (H + 2) * HC;           // halo pixels per image (multi)
   const int NH = multi ? (BM / hw_img) * HIMG : (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
+  // NSW > 2 (round 5, the 8x8-map launches): TWO halo panels and an NSW-slot weight ring with counted vmcnt, one workgroup per CU -- see the
+  // flattened step loop below
+  constexpr int NHB = NSW > 2 ? 2 : 1;
   f16* Hs = smem;
-  f16* Wst = smem + NH8 * BK;  // two weight stages of BN x 64 halfs
+  f16* Wst = smem + NHB * NH8 * BK;  // NSW weight stages of BN x 64 halfs
 
   const int nwg = tiles_m * tiles_n * S;
   int tile, slice;
@@ -831,12 +847,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   }
   const int kpt = p.Cin / BK;
   const int c_begin = (int)((int64_t)kpt * slice / S), c_end = (int)((int64_t)kpt * (slice + 1) / S);
+  uint32_t w_voff[BI];   // (NSW > 2) byte offsets of this lane's weight rows from p.W; rows past N read row 0: those output columns are never stored
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = wave * (BN / 4) + i * 8 + rl;
+    w_voff[i] = (uint32_t)(((w_ok[i] ? n0 + row : 0) * p.ldw + ((cp ^ SWZ(row)) << 3)) * 2);
+  }
 
-  auto stage_halo = [&](int c) {
+  auto stage_halo = [&](int c, int hb = 0) {
 #pragma unroll
     for (int i = 0; i < MAXHI; ++i) {
       const int j = wave + 4 * i;
-      if (j < NI) glds16(h_ptr[i] + (int64_t)c * h_step[i], Hs + j * 8 * BK);
+      if (j < NI) glds16(h_ptr[i] + (int64_t)c * h_step[i], Hs + hb * NH8 * BK + j * 8 * BK);
     }
   };
   auto stage_w = [&](int tap, int c, int buf) {
@@ -858,11 +880,78 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
   int hrow0[TM];  // halo row of this lane's output pixel for tap offset (0, 0)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int ml = wm * WTM + i * 32 + l31;
+    const int ml = wm * WTM + i * 32 + (perm ? halo_perm32(l31) : l31);
     const int img = multi ? ml / hw_img : 0, ml1 = ml - img * hw_img;
     hrow0[i] = img * HIMG + (ml1 >> wshift) * HC + (ml1 & (TW - 1));
   }
 
+  if constexpr (NSW > 2) {
+    // One workgroup per CU streams its (channel chunk, tap) steps through an NSW-slot weight ring: NSW - 2 weight tiles (and the next chunk's halo)
+    // stay in flight across every barrier.  The 2-slot loop below exposes one memory round trip per tap -- at the 8x8 maps every weight byte is
+    // HBM-cold and read once: 18 taps x ~1.3 us per workgroup for 0.3 us of matrix work each (30 us for 1280 -> 1280, 1 TB/s of weights).
+    const int nstep = (c_end - c_begin) * 9;
+    stage_halo(c_begin, 0);
+#pragma unroll
+    for (int i = 0; i < NSW - 1; ++i)
+      if (i < nstep) stage_w(i % 9, c_begin + i / 9, i);
+    int slot = 0, tap = 0, c = c_begin, ltap = (NSW - 1) % 9, lc = c_begin + (NSW - 1) / 9, lslot = NSW - 1;
+    for (int st = 0; st < nstep; ++st) {
+      {   // stage st (issued NSW - 1 steps ago) has landed: at most the NSW - 2 younger weight stages stay in flight (a halo issued among them
+          // makes the count wait for a little more than it must -- never less)
+        int later = nstep - 1 - st;
+        later = later > NSW - 2 ? NSW - 2 : later;
+        switch (later) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BI) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BI) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * BI) : "memory"); break;
+        }
+        static_assert(NSW <= 5, "counted waits up to three stages in flight");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... for every wave, and every wave has left step st - 1
+      if (tap == 0 && c + 1 < c_end) stage_halo(c + 1, (c + 1 - c_begin) & 1);   // (that panel was last read in chunk c - 1)
+      // the BI weight pieces of stage st + NSW - 1 (its slot was read in step st - 1) go out BETWEEN the MFMAs below, as asm (a builtin piece in front
+      // of the MFMAs blocks its wave for 100+ cycles; with one wave per SIMD nothing else runs meanwhile: 42 us against the 2-slot kernel's 38)
+      const bool w_on = st + NSW - 1 < nstep;
+      const char* w_base = (const char*)p.W + (int64_t)(ltap * kpt + lc) * BK * 2;
+      const uint32_t w_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(Wst + lslot * (BN * BK) + (wave * (BN / 4)) * BK);
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int dy = p.sign > 0 ? ky : 2 - ky, dx = p.sign > 0 ? kx : 2 - kx;
+      const int shift = dy * HC + dx;
+      const f16* Hb = Hs + ((c - c_begin) & 1) * NH8 * BK;
+      const f16* Bb = Wst + slot * (BN * BK) + (wn * WTN) * BK;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        f16x8 af[TM], bf[TN];
+        const int ch = kk * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = hrow0[i] + shift;
+          af[i] = *(const f16x8*)(Hb + row * BK + ((ch ^ SWZ(row)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 32 + l31;
+          bf[j] = *(const f16x8*)(Bb + row * BK + ((ch ^ SWZ(row)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = TB_MFMA_32x32x16(bf[j], af[i], acc[i][j]);
+        static_assert(BI == BK / 16, "one weight piece per 16-wide k-step");
+        if (w_on) {
+          __builtin_amdgcn_sched_barrier(0);
+          glds16_asm_so(w_base, w_voff[kk], w_dst + kk * 8 * BK * 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      slot = slot + 1 == NSW ? 0 : slot + 1;
+      lslot = lslot + 1 == NSW ? 0 : lslot + 1;
+      if (++tap == 9) tap = 0, ++c;
+      if (++ltap == 9) ltap = 0, ++lc;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the epilogue reuses the LDS
+  } else
   for (int c = c_begin; c < c_end; ++c) {
     // every wave has left the previous chunk's last tap (barrier there), so the halo and weight stage 0 may be overwritten
     stage_halo(c);
@@ -903,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const tb_gemm_desc p,
     }
   }
 #undef SWZ
-  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, wshift, W, true, tm * tiles_n + tn);
+  tile_epilogue<BM, BN, TM, TN, 1>(p, acc, smem_raw, m0, n0, wm, wn, S, slice, ws, npad, wshift, W, true, tm * tiles_n + tn, perm);
 }
 
 
@@ -917,7 +1006,8 @@ int g_inkernel_reduce = 0;  // split-K launches with tb_gemm_desc.sync reduce in
                             // reducer launch, but the agent-scope partial stores / loads it needs make the step 35.1 ms against 31.3 (scratch/ab_step.py)
 int g_last_cfg[5] = {0, 0, 0, 0, 0};  // BM, BN, MODE, k-tile, split of the most recent launch (bench.py names kernels by it)
 int g_order = 0;    // tile order: 0 = 8-row groups (default), 1 = n-fastest, 2 = m-fastest (tb_gemm_set_variant(3000 + v))
-int g_halo = 3;     // 3x3 stride-1 convs use conv_halo_kernel: bit 0 = tiles of whole image rows, bit 1 = tiles of whole small images (8x8 maps) (tb_gemm_set_variant(7000 + bits))
+int g_halo = 11;    // (bit 3 = 8-wide maps on the 12-pixel halo pitch with permuted lanes: conflict-free fragment reads; bit 2, the 5-slot ring, measured slower: off)
+                    // 3x3 stride-1 convs use conv_halo_kernel: bit 0 = tiles of whole image rows, bit 1 = tiles of whole small images (8x8 maps), bit 2 = the 8x8-map launches on the 5-slot weight ring (one workgroup per CU) (tb_gemm_set_variant(7000 + bits))
 int g_ablate = 0;   // profiling only (tb_gemm_set_variant(2000 + bits)): 1 = skip k-loop loads, 2 = skip k-loop MFMAs
 int g_variant = 0;  // tuning knob (tb_gemm_set_variant): 0 = BK64 x 2 stages, 1 = BK32 x 3 stages, 2 = BK32 x 2 stages
 
@@ -993,27 +1083,30 @@ int g_split_minnk = 32;      // ... and at least this many k-tiles (6000 + n)
 int g_nosplit64 = 1;         // see dispatch_tile (tb_gemm_set_variant(9600 + {0,1}))
 int g_split_target = 384;  // split K until about this many blocks exist (A/B: 256 22.7, 384 23.05, 512 22.6, 768 22.6, off 20.2 steps/s)  (tb_gemm_set_variant(1000 + n))
 
-template <int BN>
+template <int BN, int NSW = 2>
 int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
   const int tiles_m = (int)(d.M / 128), tiles_n = (int)((d.N + BN - 1) / BN);
   const int TW = 1 << wshift, R = 128 >> wshift;
   const int hw_img = d.Hout * d.Wout;
-  const int nh8 = ((hw_img < 128 ? (128 / hw_img) * (d.Hout + 2) * (TW + 2) : (R + 2) * (TW + 2)) + 7) & ~7;
-  size_t lds = (size_t)nh8 * 128 + 2 * (size_t)BN * 128;
+  const bool perm8 = hw_img < 128 && TW == 8 && (g_halo & 8);
+  const int nh8 = ((hw_img < 128 ? (128 / hw_img) * (d.Hout + 2) * (perm8 ? 12 : TW + 2) : (R + 2) * (TW + 2)) + 7) & ~7;
+  size_t lds = (size_t)(NSW > 2 ? 2 : 1) * nh8 * 128 + (size_t)NSW * BN * 128;
   if (lds < (size_t)128 * BN * sizeof(float)) lds = (size_t)128 * BN * sizeof(float);
-  g_last_cfg[0] = 128, g_last_cfg[1] = BN, g_last_cfg[2] = 2, g_last_cfg[3] = 642, g_last_cfg[4] = S;
+  if (lds > 160 * 1024) return 1;
+  g_last_cfg[0] = 128, g_last_cfg[1] = BN, g_last_cfg[2] = 2, g_last_cfg[3] = 640 + NSW, g_last_cfg[4] = S;
   const int64_t npad = (d.N + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done && lds > 65536) {
-    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TB_ELAUNCH;
     attr_done = true;
   }
   tb_gemm_desc dk = d;
+  if (perm8) dk.shift = 0x100;   // (the kernel's switch for the 12-pixel halo pitch + permuted lanes; `shift` itself is 0 for every launch that gets here)
   const bool defer = defer_reduce(d, S);
   const bool inkernel = S > 1 && !defer && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
   if (!inkernel) dk.sync = nullptr;
-  hipLaunchKernelGGL((conv_halo_kernel<BN>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m, tiles_n, wshift, S,
+  hipLaunchKernelGGL((conv_halo_kernel<BN, NSW>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m, tiles_n, wshift, S,
                      (float*)d.ws, npad);
   if (defer) *d.split_out = S;
   else if (S > 1 && !inkernel)
@@ -1067,8 +1160,19 @@ int dispatch_tile(const tb_gemm_desc& d, hipStream_t s) {
       if (want > fit) want = fit;
       if (want > 1) Sh = (int)want;
     }
+    const int wshift = halo_wshift(d.Wout, d.Hout);
+    if ((int64_t)d.Hout * d.Wout < 128 && !narrow && !(g_conv_narrow & 1) && (g_halo & 4) && d.ws && blocks < 256) {
+      // 8x8 maps (round 5): one workgroup per CU on a 5-slot weight ring -- as few k-slices as still give ~200 workgroups (half the fp32 partials)
+      int Sd = (int)((220 + blocks - 1) / blocks);
+      if (Sd > kpt / 2) Sd = kpt / 2;
+      const int64_t fit = d.ws_bytes / (int64_t)(d.M * ((d.N + 7) / 8 * 8) * sizeof(float));
+      if (Sd > fit) Sd = (int)fit;
+      if (Sd >= 1 && blocks * Sd >= 128) {
+        const int r = launch_halo<128, 5>(d, s, wshift, Sd);
+        if (r != 1) return r;
+      }
+    }
     if (blocks * Sh >= 200) {
-      const int wshift = halo_wshift(d.Wout, d.Hout);
       return (narrow || (g_conv_narrow & 1)) ? launch_halo<64>(d, s, wshift, Sh) : launch_halo<128>(d, s, wshift, Sh);
     }
   }

@@ -17,6 +17,21 @@ __device__ __forceinline__ void glds16(const f16* src, f16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// global -> LDS DMA of 64 x 16 bytes as ONE asm statement (destination = the wave-uniform LDS byte address in M0 + 16 * lane).  Unlike the builtin it
+// may sit between MFMAs: there the builtin gets an `s_waitcnt vmcnt(0)` and a VGPR round trip of its M0 value in front (ff_fused.hip / lin320.hip)
+__device__ __forceinline__ void glds16_asm(const void* src, uint32_t lds_byte_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(src) : "memory", "m0");
+}
+// ... with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit VGPR address (the 256 x 160 convolution tile has none to spare)
+__device__ __forceinline__ void glds16_asm_so(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t bs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);   // (the builtin returns int: no sign extension into the high dword)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(voff), "s"(bs) : "memory", "m0");
+}
+
 // Epilogue for 8 consecutive output columns n..n+7 of row m (shared by the MFMA kernel and the split-K reducer):
 // v = alpha*acc + bias + rowbias + R ; activation ; store C (fp16 | fp32), optionally C2 (pre-activation).
 // All global accesses are 16-byte vectors when the row pitch / base alignment allow (EpiFlags), else scalar.
