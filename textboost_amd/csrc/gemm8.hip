@@ -20,7 +20,7 @@
 #define G8_PROF 0  // profiling build: per-phase s_memtime sums of waves 0 and 4 of workgroup 0 into dbg[16..]
 #endif
 #ifndef G8_DMAC
-#define G8_DMAC 1  // bit 0: DMAC, bit 1: DMACC (measured SLOWER, off), bit 2: DMAC2 (measured neutral, off); A/B build switch (TB_CFLAGS=-DG8_DMAC=n) (TB_CFLAGS=-DG8_DMAC=0): the Linear tiles' global -> LDS pieces in the LOAD phase, as in round 4
+#define G8_DMAC 9  // bit 3: DMACH (the 256 x 80 convolution tile on a 4-slot ring), bit 0: DMAC, bit 1: DMACC (measured SLOWER, off), bit 2: DMAC2 (measured neutral, off); A/B build switch (TB_CFLAGS=-DG8_DMAC=n) (TB_CFLAGS=-DG8_DMAC=0): the Linear tiles' global -> LDS pieces in the LOAD phase, as in round 4
 #endif
 #ifndef G8_DMACC_MASK
 #define G8_DMACC_MASK 0xA  // DMACC: bit k = load slot k of a convolution step goes out in the COMPUTE phase of its half (slots 0 .. WI - 1 weight pieces, WI the halo piece)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // ---- software pipeline: NS weight stages (and, for Linear, NS activation stages); the loads of step s + NS - 1 are issued in step s,
   // so NS - 2 steps of loads stay in flight across each barrier (counted vmcnt, raw s_barrier: cdna guide T3/T4).  An L2 round trip under
   // load is ~1 us, as long as one step of MFMAs: with NS = 2 every step waited for it.
-  static_assert(!CONV || SUB || TAPS % NS == 0, "the weight ring slot of a conv step is tap % NS (SUB: run-time ring counters, like the Linear path)");
+  static_assert(!CONV || SUB || TAPS % NS == 0 || NS == 4, "the weight ring slot of a conv step is tap % NS (SUB and the 4-slot ring: run-time ring counters, like the Linear path)");
   // The stage loaded during step (c, tap) is the one NS - 1 steps ahead: (lc, ltap).  The tap loop is fully unrolled, so tap, ltap, the
   // ring slots and the tap's halo offset are compile-time; only the chunk index is a loop variable.  (With a rolled tap loop the LOAD
   // phase was ~100 instructions, half of them scalar index arithmetic, and took 420 cycles against 340 for the 20 MFMAs of the partner.)
@@ -444,6 +444,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // the FIRST compute phase; the wait for them stays at the end of the second LOAD phase (vmcnt(0)), one interval before the other wave group reads them
   // (DMAC2 measured, scratch/geglu_time.py: GEGLU 8192x5120x640 126 -> 119..125 us, 32768x320x1280 46.7 -> 47.8 us, the step 29.00 = 29.00 ms: neutral; off)
   constexpr bool DMAC2 = (G8_DMAC & 4) && !CONV && MT >= 4 && NS == 2 && !(G8_ABL & 2);
+  // DMACH (bit 3): the 256-pixel x 80-channel convolution tile (MT = 2: ONE phase pair per step) on a 4-slot weight ring, as DMAC: every piece of a step
+  // between the MFMAs of its COMPUTE phase, the wait at the end of the LOAD phase leaves the previous step's pieces in flight.  Phase stamps of the
+  // 3-slot version (-DG8_PROF, 640 -> 640 @ 32x32): LOAD 709 cycles against 355 for the 20 MFMAs -- the imbalance DMAC removed from the Linear tiles.
+  constexpr bool DMACH = (G8_DMAC & 8) && CONV && SUB == 0 && MT < 4 && NS == 4 && !(G8_ABL & 2);
   constexpr bool DMACC = (G8_DMAC & 2) && CONV && SUB == 0 && MT >= 4 && NS == 3 && !(G8_ABL & 2);
   const uint32_t as_addr0 = lds_addr(As), ws_addr0 = lds_addr(Ws);
   auto conv_slot_issues = [&](int k, int lc, int c, int tap) -> int {   // DMACC: does this wave issue a piece for slot k in step (c, tap)?
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       constexpr int dummy_ = 0;
       (void)dummy_;
       const int ltap = (tap + NS - 1) % TAPS, lc = c + (tap + NS - 1) / TAPS;
-      constexpr bool RT_RING = !CONV || SUB != 0;   // run-time ring counters
+      constexpr bool RT_RING = !CONV || SUB != 0 || NS == 4;   // run-time ring counters
       const int wslot = RT_RING ? lin_slot : tap % NS, lslot = RT_RING ? lin_lslot : (tap + NS - 1) % NS;
       const int cnt_step = NS == 2 ? 0 : stage_count(lc, c, tap);
       int shift = CONV ? (tap / 3) * HC + (tap % 3) : 0;
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!DMAC && !DMAC2) {
+        if constexpr (!DMAC && !DMAC2 && !DMACH) {
 #pragma unroll
           for (int k = 0; k < NSLOT; ++k)
             if ((h == 0) == (k < SLOTS0) && !(DMACC && ((G8_DMACC_MASK >> k) & 1))) issue_slot(k, lc, ltap, lslot, c, tap, (tap + NS - 1) / TAPS);
@@ -636,7 +640,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         // after the step's last issue: everything except THIS step's loads has landed (this wave's part), i.e. the next step's stage
         if (h == HALVES - 1) {
           // (NS >= 4, Linear: the stage two steps ahead may stay in flight as well -- what must have landed is the NEXT step's stage)
-          if constexpr (DMAC) {
+          if constexpr (DMACH) {
+            wait_vmcnt(cnt_hist);
+          } else if constexpr (DMAC) {
             wait_vmcnt(cnt_hist + n_ld);      // (this step's pieces go out in the COMPUTE phase below; in flight: the previous step's)
           } else if constexpr (DMACC) {
             int n0 = 0;                // in flight: this step's pieces issued so far (all but the second compute phase's)
@@ -681,6 +687,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
                     __builtin_amdgcn_sched_barrier(0);
                   }
               }
+              if constexpr (DMACH) {
+                constexpr int NMFh = SPH * MT * NT;
+                const int mi = (q * MT + i) * NT + j + 1;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k)
+                  if (mi == ((k + 1) * NMFh) / (NSLOT + 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_conv_slot_asm(k, lc, ltap, lslot, c, tap);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+              }
               if constexpr (DMAC2) {   // first compute phase: every piece of the next stage
                 constexpr int NMF2 = SPH * MT * NT;
                 const int mi = (q * MT + i) * NT + j + 1;
@@ -705,14 +722,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
               }
             }
         }
-        if constexpr (DMAC) cnt_hist = cnt_step;
+        if constexpr (DMAC || DMACH) cnt_hist = cnt_step;
         __builtin_amdgcn_sched_barrier(0);
         G8_PF(2)
         asm volatile("s_barrier" ::: "memory");
         G8_PF(3)
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!CONV || SUB) {
+      if (!CONV || SUB || NS == 4) {
         lin_slot = lin_slot + 1 == NS ? 0 : lin_slot + 1;
         lin_lslot = lin_lslot + 1 == NS ? 0 : lin_lslot + 1;
       }
@@ -1470,7 +1487,13 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     // 256 pixels x 160 channels (one round of >= 200 blocks), else 256 x 80
     if (256 % TW == 0 && d.Hout % (256 / TW) == 0 && d.M % 256 == 0) {
       if (d.N % 160 == 0 && (d.M / 256) * (d.N / 160) >= 200) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift);
-      if (d.N % 80 == 0 && (d.M / 256) * (d.N / 80) >= 200) return launch8<8, 1, 2, 5, true, 3>(d, s, wshift);
+      if (d.N % 80 == 0 && (d.M / 256) * (d.N / 80) >= 200) {
+        if (!(g8_enable & 32768)) {   // 4-slot weight ring with the pieces between the MFMAs (DMACH) where the LDS holds it (maps up to 32 wide)
+          const int r = launch8<8, 1, 2, 5, true, 4>(d, s, wshift);
+          if (r != 1) return r;
+        }
+        return launch8<8, 1, 2, 5, true, 3>(d, s, wshift);
+      }
       // 256 pixels x 128 channels (wave tiles 64 x 64): the VAE's 128 / 256 / 512-channel convolutions (AutoencoderKL encoder / decoder,
       // train_textboost.py:1036-1037 and log_validation), which the 80-wide wave tiles do not divide
       if (d.N % 128 == 0 && (d.M / 256) * (d.N / 128) >= 200 && !(g8_enable & 1024)) return launch8<4, 2, 4, 4, true, 3>(d, s, wshift);
