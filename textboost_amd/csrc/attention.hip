@@ -921,6 +921,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const tb_attn_desc
 // lane-owned Q / dO fragments -- it only has to be FINITE: the next row's first chunk, or for the last row of the V tile the zeroed 64-byte slack
 // behind the stage.  80-byte rows put the 16 rows of a ds_read_b128 lane group on 16 distinct 16-byte bank slots (the 96-byte rows were a
 // 2-way conflict on every such read: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, profiles/r03_pmc_sq.txt) and the DMA moves 1/6 fewer bytes.
+#ifndef TB_DQ_ASMDMA
+#define TB_DQ_ASMDMA 0   // attn_bwd_dq_dma_kernel: 1 = the next tile's global -> LDS pieces go out as asm statements BETWEEN the tile's MFMAs (round 5 experiment:
+                         // 913 -> 911 us for the 64x64-map backward pair, 110.6 = 110.6 us at 32x32 -- neutral, the kernel is not piece-issue bound); 0 = the
+                         // builtin pieces in front of the tile's compute
+#endif
+// one global -> LDS piece (64 x 16 bytes, destination = wave-uniform LDS byte address + 16 lane) as an asm statement: may sit between MFMAs, where
+// the builtin gets a vmcnt(0) and a VGPR round trip of M0 in front (csrc/gemm_epi.h glds16_asm)
+__device__ __forceinline__ void attn_glds16_asm(const void* src, uint32_t lds_byte_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(src) : "memory", "m0");
+}
 template <int DT, int KS, int PC, int NST, bool PAD = true>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_desc p, int remap, int publish) {
   constexpr int PCB = PC * 16, TILE_B = KVT * PCB;
@@ -1025,7 +1036,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
       attn_wait_vmcnt(later * n_issued);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + NST - 1 < ntiles) stage_loads(t + NST - 1, lslot);
+    const bool ld_on = t + NST - 1 < ntiles;
+    if (!TB_DQ_ASMDMA && ld_on) stage_loads(t + NST - 1, lslot);
+    // TB_DQ_ASMDMA: piece i of the next stage behind MFMA group i of this tile (three groups: scores of the first half, its dQ products, scores of the second half)
+    auto piece = [&](int i) {
+      const int tt = wave + 4 * i;
+      if (TB_DQ_ASMDMA && i < WI && ld_on && tt < NI && g_on[i]) {
+        const char* src = (tt >= PC ? Vg + (int64_t)(t + NST - 1) * KVT * ldv * 2 : Kg + (int64_t)(t + NST - 1) * KVT * ldk * 2) + g_off[i];
+        __builtin_amdgcn_sched_barrier(0);
+        attn_glds16_asm(src, lds0 + lslot * STAGE_B + tt * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     const unsigned char* Ks = smem_raw + slot * STAGE_B;
     const uint32_t ka = lds0 + slot * STAGE_B + tr_lane;
 #pragma unroll
@@ -1038,6 +1060,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
         s = TB_MFMA_32x32x16(kfr, qf[j], s);
         dp = TB_MFMA_32x32x16(vfr, dof[j], dp);
       }
+      piece(kt == 0 ? 0 : 2);
       f16x4 ktf[2][DT][2];  // K^T fragments of this 32-key half: issued behind the score products, they arrive under the exponentials
       __builtin_amdgcn_sched_barrier(0);
 #define TB_TR(KT, JJ, D, HH) ktf[JJ][D][HH] = lds_tr_read_off<((KT) * 32 + 16 * (JJ) + 8 * (HH)) * PCB + (D) * 64>(ka);
@@ -1066,6 +1089,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const tb_attn_d
           dq[d] = TB_MFMA_32x32x16(a, dsf, dq[d]);
         }
       }
+      if (kt == 0) piece(1);
+    }
+    static_assert(!TB_DQ_ASMDMA || WI <= 3 || PAD, "three piece slots per tile");
+    if (WI > 3) {
+#pragma unroll
+      for (int i = 3; i < WI; ++i) piece(i);
     }
     slot = slot == NST - 1 ? 0 : slot + 1;
     lslot = lslot == NST - 1 ? 0 : lslot + 1;
