@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textboost_amd import ops, _lib as L
 dev = "cuda"
 dbg = torch.zeros(32, dtype=torch.int64, device=dev)
-NR = 8
+NR = int(os.environ.get("NR", "8"))
 for M, N, K, res in [(8192, 640, 640, True), (8192, 640, 640, False), (2048, 1280, 1280, True), (8192, 640, 2560, True)]:
     A = [torch.randn(M, K, device=dev).half() for _ in range(NR)]
     W = [(torch.randn(N, K, device=dev) / K ** 0.5).half() for _ in range(NR)]

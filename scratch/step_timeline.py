@@ -7,16 +7,13 @@ gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols e
 wx = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else None)
 sel = "name, start, end" + (f", {gx}" if gx else ", 0") + (f", {wx}" if wx else ", 1")
 rows = cur.execute(f"select {sel} from kernels order by start").fetchall()
-groups, g = [], [rows[0]]
-for prev, r in zip(rows, rows[1:]):
-    if r[1] - prev[2] > 100_000: groups.append(g); g = []
-    g.append(r)
-groups.append(g)
-big = [x for x in groups if len(x) > 600]
-tight = [x for x in big if (x[-1][2] - x[0][1]) < 1.08 * sum(r[2] - r[1] for r in x)]   # graph replays (kernels abut), not the eager roofline leg
-g = (tight or big)[-1]
-ends = [i for i, r in enumerate(g) if 'renorm_rows_kernel' in r[0]]   # (consecutive replays less than 100 us apart land in one group: keep the last whole step)
-if len(ends) >= 2: g = g[ends[-2] + 1:ends[-1] + 1]
+# a step = the launches between two consecutive renorm_rows_kernel launches (the step's last kernel); graph replays are the steps whose kernels abut
+# (span close to the sum of the durations) -- the last such step is printed whole (round 5: independent of the > 100 us gaps inside a replay)
+ends = [i for i, r in enumerate(rows) if 'renorm_rows_kernel' in r[0]]
+steps = [rows[a + 1:b + 1] for a, b in zip(ends, ends[1:])]
+steps = [x for x in steps if len(x) > 300 and not any('spin_kernel' in r[0] or 'mfma_peak' in r[0] for r in x)]   # (not the eager roofline leg)
+tight = [x for x in steps if (x[-1][2] - x[0][1]) < 1.10 * sum(r[2] - r[1] for r in x)]
+g = (tight or steps)[-1]
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 t0 = g[0][1]
 def short(n):

@@ -118,6 +118,15 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 }
 
 __device__ __forceinline__ int64_t m0p_of(int tm, int bm) { return (int64_t)tm * bm; }  // first row of Linear row panel tm
+// The workgroup -> tile arithmetic ran 9 integer divisions (~25 scalar instructions each, one dependent chain per wave) in front of the first load of
+// EVERY launch: of the ~970 instructions in front of the first barrier (5 500 cycles = 2.9 us of a 20 us K = 640 launch, warm or cold operands alike --
+// s_memtime stamps, scratch/lin_stamps.py) a quarter was division.  The divisors are launch constants: the host passes ceil(2^32 / d) and the kernel
+// multiplies (exact for n, d < 2^16).
+struct G8Magic {
+  uint32_t S, tiles_n, rn, xn, tiles_img, tiles_x, hc;
+};
+__device__ __forceinline__ int mg_div(int n, uint32_t magic) { return (int)__umulhi((uint32_t)n, magic); }
+inline uint32_t mg_of(int d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint32_t)d - 1) / (uint32_t)d) : 0u; }   // (d == 1: callers skip the divide)
 
 // WM x WN waves (WM * WN == 8), each wave (16 MT) x (16 NT) outputs; CONV: 3x3 stride-1 halo convolution, else A rows linear
 //
@@ -137,7 +146,7 @@ __device__ __forceinline__ int64_t m0p_of(int tm, int bm) { return (int64_t)tm *
 // 0.65 us per k-step at one tile per CU), as 4 x 1 x 2 waves it reads (32 + 80) rows per 10.
 template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0, int KH = 1>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int a_rows8,
-                                                          unsigned long long* dbg, int S, float* __restrict__ ws, int64_t npad, int xn) {
+                                                          unsigned long long* dbg, int S, float* __restrict__ ws, int64_t npad, int xn, G8Magic mg) {
   static_assert(WM * WN * KH == 8, "8 waves");
   static_assert(KH == 1 || (KH == 2 && !CONV && MT < 4), "k-halves: Linear tiles whose step is one phase pair");
 #define G8_STAMP(k)                                                                                  \
@@ -173,22 +182,25 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     const int bid = blockIdx.x, xcd = bid & 7;
     int j = bid >> 3;
     if (S > 1) {
-      slice = j % S;
-      j /= S;
+      const int jq = mg_div(j, mg.S);
+      slice = j - jq * S;
+      j = jq;
     }
-    const int rn = tiles_n / xn, rm = tiles_m / (8 / xn);
-    const int jm = j / rn;
-    tm = (xcd / xn) * rm + jm;
-    tn = (xcd % xn) * rn + (j - jm * rn);
+    const int xs = xn == 8 ? 3 : (xn == 4 ? 2 : (xn == 2 ? 1 : 0));   // (xn is a power of two: launch8)
+    const int rn = tiles_n >> xs, rm = (tiles_m << xs) >> 3;
+    const int jm = rn > 1 ? mg_div(j, mg.rn) : j;
+    tm = (xcd >> xs) * rm + jm;
+    tn = (xcd & (xn - 1)) * rn + (j - jm * rn);
   } else {
     const int nwg = tiles_m * tiles_n * S;
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     if (S > 1) {
-      slice = tile % S;
-      tile /= S;
+      const int tq = mg_div(tile, mg.S);
+      slice = tile - tq * S;
+      tile = tq;
     }
-    tm = tile / tiles_n, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
+    tm = tiles_n > 1 ? mg_div(tile, mg.tiles_n) : tile, tn = tile - tm * tiles_n;  // the tiles_n column tiles of one row panel are adjacent (same XCD)
   }
   const int cls = SUB == 1 ? slice : 0;   // SUB == 1: the `slice` index is the output class 2 py + px, not a k-range
   if constexpr (SUB == 1) slice = 0;
@@ -243,15 +255,23 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   int y0 = 0, x0 = 0, bimg = 0;
   const int hw = H * W;
   if (CONV) {
-    const int tiles_x = W >> wshift, tiles_img = (H / R) * tiles_x;
-    bimg = tm / tiles_img;
+    const int rshift = (BM == 256 ? 8 : 7) - wshift;                        // R = BM >> wshift rows per tile, a power of two
+    const int tiles_x = W >> wshift, tiles_img = (H >> rshift) * tiles_x;   // (host: H % R == 0)
+    bimg = tiles_img > 1 ? mg_div(tm, mg.tiles_img) : tm;
     const int trem = tm - bimg * tiles_img;
-    y0 = (trem / tiles_x) * R;
-    x0 = (trem % tiles_x) << wshift;
+    const int ty = tiles_x > 1 ? mg_div(trem, mg.tiles_x) : trem;
+    y0 = ty << rshift;
+    x0 = (trem - ty * tiles_x) << wshift;
     m0 = (int64_t)bimg * hw + (int64_t)y0 * W + x0;
   } else {
     m0 = (int64_t)tm * BM;
   }
+  // time-embedding row bias (rowbias[m / rows_per_group]): a convolution tile lies inside ONE image, so with rows_per_group == H W (every ResnetBlock2D
+  // launch) the group is the tile's image index -- no 64-bit divisions (three of them, ~100 instructions each, sat in front of the first load of the
+  // 256 x 80 tile; two in the 256 x 160 tile's epilogue)
+  const bool rb_img = CONV && SUB == 0 && p.rowbias && p.rows_per_group == (int64_t)hw;
+  auto rb_group0 = [&]() -> int64_t { return rb_img ? (int64_t)bimg : m0 / p.rows_per_group; };
+  auto rb_is_uniform = [&](int64_t m_last) -> bool { return !p.rowbias || rb_img || (m0 / p.rows_per_group == m_last / p.rows_per_group); };
   // output row of tile row r: the tile's pixels in map order; SUB == 1: the class's pixels (2 y + py, 2 x + px) of the fine (2H x 2W) map
   const int64_t mo0 = SUB == 1 ? ((int64_t)bimg * 2 * H + 2 * y0 + (cls >> 1)) * (2 * W) + 2 * x0 + (cls & 1) : m0;
   const int oys = SUB == 1 ? 4 * W : W, oxs = SUB == 1 ? 2 : 1;
@@ -269,12 +289,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   bool fast = false;
   if (PRE_B) {
     const EpiFlags ef0 = epi_flags(p);
-    const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == (m0 + ((int64_t)(R - 1) * W + TW - 1)) / p.rows_per_group);
+    const bool rb_uniform = rb_is_uniform(m0 + ((int64_t)(R - 1) * W + TW - 1));
     fast = p.c_dtype == TB_F16 && ef0.c_vec && (!p.R || (ef0.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
            !p.C2 && rb_uniform;
     epi_load_bias8(p, n, b8);
     if (fast && p.rowbias) {
-      const float* rb = p.rowbias + (m0 / p.rows_per_group) * p.ldrb + n;
+      const float* rb = p.rowbias + rb_group0() * p.ldrb + n;
 #pragma unroll
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
     }
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     bool ok;
     int64_t grow;
     if (CONV) {
-      const int hy = hr / HC, hx = hr - hy * HC;
+      const int hy = mg_div(hr, mg.hc), hx = hr - hy * HC;   // (HC = TW + 2 >= 18: the multiply-high division)
       const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
       ok = j < NI_H && hr < NH && yy >= 0 && yy < H && xx >= 0 && xx < W;
       grow = SUB == 2 ? ((int64_t)bimg * 2 * H + 2 * yy) * (2 * W) + 2 * xx   // view (0, 0) of the fine gradient; other views: + a uniform offset
@@ -349,26 +369,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       if (j < NI_H) glds16(h_ptr[i] + (int64_t)c * h_step[i], As + (c & 1) * a_elems + j * 8 * BK);
     }
   };
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // fragment addressing (bytes inside a panel / stage): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 s + lq for sub-step s
-  int arow0[MT];  // panel row of this lane's output row for tap offset (0, 0)
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int ml = (wm * MT + i) * 16 + l15;
-    arow0[i] = CONV ? (ml >> wshift) * HC + (ml & (TW - 1)) : ml;
-  }
-  uint32_t arow128[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) arow128[i] = (uint32_t)arow0[i] * 128;
-  // W rows wn*NT*16 + 16 j + l15: row & 7 == l15 & 7 for every j, so one base + immediates
-  const int brow = wn * NT * 16 + l15;
-  const int boff0 = brow * 128 + ((lq ^ (brow & 7)) << 4), boff1 = boff0 ^ 64;
 
   // loads this wave issues per weight stage (wave-uniform), for the counted waits below
   int n_w = 0;
@@ -465,15 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
         glds16_asm(h_ptr[tap] + (int64_t)(c + 1) * h_step[tap], as_addr0 + (uint32_t)(((c + 1) & 1) * a_elems + j * 8 * BK) * 2);
     }
   };
-  uint32_t a_off[CONV ? 1 : MAXHI];   // Linear: 32-bit byte offsets of this lane's A-panel rows from p.A (rows past M: row 0 -- never stored)
-  if constexpr (!CONV) {
-#pragma unroll
-    for (int i = 0; i < MAXHI; ++i) {
-      const int hr = (wave + 8 * i) * 8 + rl;
-      const int64_t grow = m0 + hr < p.M ? m0 + hr : 0;
-      a_off[i] = (uint32_t)((grow * p.lda + ((cp ^ (hr & 7)) << 3)) * 2);
-    }
-  }
+  uint32_t a_off[CONV ? 1 : MAXHI];   // Linear: 32-bit byte offsets of this lane's A-panel rows from p.A (rows past M: row 0 -- never stored); filled below
   auto issue_slot_asm = [&](int k, int lc, int lslot) {   // (Linear only) piece k of stage lc into ring slot lslot
     if (k < WI) {
       const int j = wave + 8 * k;
@@ -500,6 +492,36 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
       if (!CONV || k < WI) issue_slot(k, lc, ltap, st % NS, -2, -1, 0);
   }
   if (NS == 2) cnt_prev = 0;
+  // ---- everything the first stages' loads do not need sits BEHIND their issue (it runs under their latency): accumulators, fragment addressing,
+  // the DMAC path's 32-bit A offsets
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing (bytes inside a panel / stage): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 s + lq for sub-step s
+  int arow0[MT];  // panel row of this lane's output row for tap offset (0, 0)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ml = (wm * MT + i) * 16 + l15;
+    arow0[i] = CONV ? (ml >> wshift) * HC + (ml & (TW - 1)) : ml;
+  }
+  uint32_t arow128[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) arow128[i] = (uint32_t)arow0[i] * 128;
+  // W rows wn*NT*16 + 16 j + l15: row & 7 == l15 & 7 for every j, so one base + immediates
+  const int brow = wn * NT * 16 + l15;
+  const int boff0 = brow * 128 + ((lq ^ (brow & 7)) << 4), boff1 = boff0 ^ 64;
+
+  if constexpr (!CONV) {
+#pragma unroll
+    for (int i = 0; i < MAXHI; ++i) {
+      const int hr = (wave + 8 * i) * 8 + rl;
+      const int64_t grow = m0 + hr < p.M ? m0 + hr : 0;
+      a_off[i] = (uint32_t)((grow * p.lda + ((cp ^ (hr & 7)) << 3)) * 2);
+    }
+  }
   int cnt_hist = cnt_prev;   // loads this wave issued in the previous step (prologue: the youngest stage)
 #if G8_PSTAMP
   G8_STAMP(4)
@@ -815,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   // unit) -- the generic epilogue8 path cost 8 us of a 23 us 32768x320x320 launch, against 3 us for the stores themselves.
   if (!PRE_B) {
     const int64_t m_last = CONV ? m0 + ((int64_t)(R - 1) * W + TW - 1) : m0 + BM - 1;
-    const bool rb_uniform = !p.rowbias || (m0 / p.rows_per_group == m_last / p.rows_per_group);
+    const bool rb_uniform = rb_is_uniform(m_last);
     fast = p.c_dtype == TB_F16 && ef.c_vec && (!p.R || (ef.r_vec && p.r_dtype == TB_F16)) && (p.act == TB_ACT_NONE || p.act == TB_ACT_SILU) &&
            !p.C2 && rb_uniform;
     if (CONV) epi_load_bias8(p, n, b8);
@@ -1137,7 +1159,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     const f16* const Rg = p.R ? (const f16*)p.R + n : nullptr;
     const int64_t ldc = p.ldc, ldr = p.ldr, Mtot = p.M;
     if (!PRE_B && p.rowbias) {  // (PRE_B: folded into b8 before the main loop)
-      const float* rb = p.rowbias + (m0 / p.rows_per_group) * p.ldrb + n;
+      const float* rb = p.rowbias + rb_group0() * p.ldrb + n;
 #pragma unroll
       for (int e = 0; e < 8; ++e) b8[e] += rb[e];
     }
@@ -1329,12 +1351,20 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
       if (cost < best) xn = c, best = cost;
     }
   }
+  G8Magic mg;
+  {
+    const int W_ = SUB == 1 ? d.Win : d.Wout, H_ = SUB == 1 ? d.Hin : d.Hout;
+    const int tiles_x = CONV ? (W_ >> wshift) : 1, R_ = CONV ? (BM >> wshift) : 1;
+    mg.S = mg_of(S), mg.tiles_n = mg_of(tiles_n), mg.rn = mg_of(xn > 0 ? tiles_n / xn : 1), mg.xn = mg_of(xn);
+    mg.tiles_img = mg_of(CONV ? (H_ / R_) * tiles_x : 1), mg.tiles_x = mg_of(tiles_x), mg.hc = mg_of(CONV ? (1 << wshift) + 2 : 1);
+    if ((int64_t)tiles_m * tiles_n * S >= 65536) return 1;   // (the multiply-high division is exact below 2^16)
+  }
   if (g8_dry) {
     g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
     return TB_OK;
   }
   hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
-                     wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn);
+                     wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn, mg);
   TB_CHECK_LAUNCH();
   g8_split = SUB == 1 ? 1 : S;
   g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
