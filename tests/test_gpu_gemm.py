@@ -283,6 +283,48 @@ def test_conv3x3_wide_tile_128_channels(B, Cin, Cout, H, W):
            rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,rowbias", [(8, 640, 640, 32, True), (8, 1280, 640, 32, False), (8, 320, 640, 32, True), (8, 1920, 640, 32, False)])
+def test_conv3x3_256x80_tile_on_the_four_slot_ring(B, Cin, Cout, H, rowbias):
+    """gemm8_kernel<8, 1, 2, 5, true, 4> (round 5, DMACH): the 32x32-map convolutions on a 4-slot weight ring with the global -> LDS pieces issued
+    between the MFMAs of the compute phase and run-time ring slots -- forward with bias, the time-embedding row bias (its group now comes from the tile's
+    image index) and residual, and the dgrad, against F.conv2d and BIT-equal to round 4's 3-slot loop (tb_gemm8_set bit 32768: same products, same
+    summation order)."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(21)
+    x = torch.randn(B, Cin, H, H, device="cuda").half()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    rb = torch.randn(B, Cout, device="cuda") if rowbias else None
+    res = torch.randn(B * H * H, Cout, device="cuda").half()
+    xn = nhwc(x).view(B * H * H, Cin)
+    geo = dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+    default_bits = L.lib().tb_gemm8_set(39)
+    outs, dxs = [], []
+    dy = torch.randn(B, Cout, H, H, device="cuda").half()
+    geod = dict(B=B, Hin=H, Win=H, Cin=Cout, Hout=H, Wout=H, stride=1, sign=-1, upsample=0, transposed=0)
+    try:
+        for bits, ns in ((39, 4), (39 | 32768, 3)):
+            L.lib().tb_gemm8_set(bits)
+            out = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.float16)
+            ops.gemm(xn, pack_conv_w(w), out, bias=bias, R=res, conv=geo, rowbias=rb, rows_per_group=H * H if rowbias else 0)
+            last = (ctypes.c_int * 6)()
+            assert L.lib().tb_gemm8_last(last) and list(last) == [8, 1, 2, 5, 1, ns], list(last)
+            outs.append(out)
+            dx = torch.empty(B * H * H, Cin, device="cuda", dtype=torch.float16)
+            ops.gemm(nhwc(dy).view(B * H * H, Cout), pack_conv_w_dgrad(w), dx, conv=geod)
+            dxs.append(dx)
+    finally:
+        L.lib().tb_gemm8_set(default_bits)
+    ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * H, Cout) + res.float()
+    if rowbias:
+        ref = ref + rb.repeat_interleave(H * H, dim=0)
+    parity("256 x 80 conv tile, 4-slot ring", outs[0], ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(dxs[0], dxs[1])
+    parity("256 x 80 conv tile dgrad, 4-slot ring", dxs[0], nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1)).view(B * H * H, Cin),
+           rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H", [(8, 640, 640, 16), (8, 1280, 1280, 16), (8, 2560, 1280, 16), (4, 1280, 640, 32)])
 def test_conv3x3_wide_tile_split_k(B, Cin, Cout, H):
     """16x16 / small-batch maps give too few 256 x 160 tiles for the chip: gemm8_kernel splits the channel chunks over S workgroups per tile
