@@ -11,7 +11,7 @@ def timeit(fn, reps=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); g.replay(); g.replay(); e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / (2 * reps) * 1e3
-for B, H, Sq, hd in ((8, 8, 4096, 40), (8, 8, 1024, 80), (8, 8, 256, 160)):
+for B, H, Sq, hd in ((8, 8, 4096, 40), (8, 8, 1024, 80), (8, 5, 9216, 64), (8, 10, 2304, 64), (8, 20, 576, 64)):
     Skv, C = 77, H * hd
     q = torch.randn(B * Sq, C, device="cuda").half(); kv = torch.randn(B * Skv, 2 * C, device="cuda").half(); do = torch.randn(B * Sq, C, device="cuda").half()
     o = torch.empty_like(q); lse = torch.empty(B, H, Sq, device="cuda"); delta = torch.empty(B, H, Sq, device="cuda")

@@ -2223,8 +2223,8 @@ int launch_bwd(const tb_attn_desc& d, hipStream_t s) {
     constexpr int PC = KS == 3 ? 6 : (KS == 4 ? 9 : 11), NST = 3;
     const int64_t C = (int64_t)d.H * d.hd, plane2 = 2 * (int64_t)d.B * d.Skv * C;
     // measured (scratch/xbwd_time.py, B = 8, 77 keys): hd = 40 at 64x64 maps 66 -> 59 us per layer, hd = 80 at 32x32 maps 48 -> 53 us (three staged
-    // images and three score products per tile on one workgroup per CU): the wide heads keep the three launches unless bit 131072 asks
-    const bool wide_ok = KS <= 4 || (g_attn_dma & 131072);
+    // images and three score products per tile on one workgroup per CU): the wide heads (hd = 64, 80) keep the three launches unless bit 131072 asks
+    const bool wide_ok = KS <= 3 || (g_attn_dma & 131072);   // (hd = 64, SD2.x at 96x96 latents: 107 -> 136 us, 63 -> 78, 45 -> 51 us: off as well)
     if (!(g_attn_dma & 65536) && wide_ok && d.hd == (KS == 3 ? 40 : (KS == 4 ? 64 : 80)) && !d.causal && d.Skv <= 96 && d.Skv > 32 && d.Sq % KVT == 0 && d.Sq >= 256 &&
         d.ws && d.ws_floats >= 2 * plane2 && d.ldq % 8 == 0 && d.lddo % 8 == 0 && (int64_t)KVT * (d.ldq > d.lddo ? d.ldq : d.lddo) * 2 < ((int64_t)1 << 31)) {
       const int64_t bh = (int64_t)d.H * d.B;
