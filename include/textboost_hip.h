@@ -154,6 +154,11 @@ typedef struct tb_ff_desc {
   void* HG; int64_t ldhg;          /* fp16 [M, 2 inner]: written by tb_ff_fwd, read by tb_ff_bwd */
   const void* R; int64_t ldr;      /* optional fp16 [M, C] added to Y */
   void* Y; int64_t ldy;            /* fp16 [M, C] */
+  /* tb_ff_bwd only (round 5): the LayerNorm backward of norm3 applied to the accumulators -- Y = tb_layernorm_bwd(dy = [dh | dg] W2^T, ln_x, ln_gamma,
+   * ln_stats) + R instead of Y = dy + R, i.e. the block's d(residual stream) directly (the tile spans the 320-wide row).  NULL ln_x: off. */
+  const void* ln_x; int64_t ld_lnx;   /* fp16 [M, C]: the LayerNorm's input */
+  const float* ln_stats;              /* fp32 [M, 2] (mean, rstd) */
+  const float* ln_gamma;              /* fp32 [C] */
 } tb_ff_desc;
 int tb_ff_fused_ok(int64_t M, int C, int inner);
 int tb_ff_fwd(const tb_ff_desc* d, tb_stream_t stream);

@@ -95,6 +95,43 @@ def test_ff_backward_vs_autograd_and_vs_the_two_launch_path(M, with_r):
     assert rel_err(dx, dx2) < 3e-4
 
 
+@pytest.mark.parametrize("M", [256, 4096, 32768])
+def test_ff_backward_with_the_layernorm_backward_in_its_epilogue(M):
+    """round 5 (tb_ff_desc.ln_x / ln_stats / ln_gamma): the fused feed-forward backward applies norm3's LayerNorm backward to its accumulators and
+    adds the residual gradient -- against autograd through LayerNorm -> ff and against the two launches it replaces (tb_ff_bwd + tb_layernorm_bwd)."""
+    ops, L = _ops()
+    torch.manual_seed(M + 7)
+    w1, b1, w2, b2 = _weights(3)
+    x = (torch.randn(M, C, device="cuda") * 0.8 + torch.randn(M, 1, device="cuda") * 0.5).half()     # the residual stream (LayerNorm input)
+    gamma, beta = 1 + 0.4 * torch.randn(C, device="cuda"), 0.2 * torch.randn(C, device="cuda")
+    l3 = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    st = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, l3, gamma, beta, st)
+    dy = torch.randn(M, C, device="cuda").half()
+    w1p, b1p = pack_geglu(w1).contiguous(), pack_geglu(b1).contiguous()
+    hg = torch.empty(M, 2 * INNER, device="cuda", dtype=torch.float16)
+    y = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.ff_fwd(l3, w1p, b1p, w2, b2, hg, y)
+    w2d, w1d = w2.t().contiguous(), w1p.t().contiguous()
+    dres = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.ff_bwd(dy, w2d, w1d, hg, dres, R=dy, ln=(x, st, gamma))          # d(residual stream) = LN'(d l3) + dy
+    # the launches it replaces
+    dl3 = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.ff_bwd(dy, w2d, w1d, hg, dl3)
+    dres2 = torch.empty_like(dres)
+    ops.layernorm_bwd(dl3, x, gamma, st, dres2, add=dy)
+    assert rel_err(dres, dres2) < 6e-4
+    # autograd from the stored projections on (as the test above), through the LayerNorm
+    blocks = hg.float().reshape(M, INNER // 32, 2, 32)
+    h = blocks[:, :, 0].reshape(M, INNER).requires_grad_(True)
+    g = blocks[:, :, 1].reshape(M, INNER).requires_grad_(True)
+    (h * F.gelu(g)).backward(dy.float() @ w2.float())
+    dl3_ref = h.grad.half().float() @ w1[:INNER].float() + g.grad.half().float() @ w1[INNER:].float()
+    xr = x.float().requires_grad_(True)
+    F.layer_norm(xr, (C,), gamma, beta, 1e-5).backward(dl3_ref)
+    parity("ff_bwd + LayerNorm backward", dres, xr.grad + dy.float(), 2e-3, 3e-3, ch_dim=1, ch_rel=3e-3)
+
+
 def test_ff_fused_rejects_what_it_does_not_cover():
     ops, L = _ops()
     d = L.FfDesc()

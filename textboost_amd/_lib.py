@@ -77,6 +77,7 @@ class FfDesc(C.Structure):
         ("HG", C.c_void_p), ("ldhg", C.c_int64),
         ("R", C.c_void_p), ("ldr", C.c_int64),
         ("Y", C.c_void_p), ("ldy", C.c_int64),
+        ("ln_x", C.c_void_p), ("ld_lnx", C.c_int64), ("ln_stats", C.c_void_p), ("ln_gamma", C.c_void_p),
     ]
 
 

@@ -311,6 +311,68 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
   // ---- epilogue: rows 32 wm + 16 i + l15, columns wn 160 + 16 jj + 4 lq .. + 3
   const int64_t mrow = m0 + wm * 32 + l15;
   const int ncol = wn * 160 + 4 * lq;
+  if constexpr (BWD) {
+    if (p.ln_x) {
+      // LayerNorm backward of norm3 on the accumulators (round 5; it had been a launch of its own since the feed-forward was fused): the 320-wide row of
+      // a tile row sits in 2 waves (wn) x 4 lanes (lq) x 40 accumulator values: lane partials of (sum g, sum g xhat), two cross-lane steps, one LDS
+      // exchange between the two waves of the row band (added in the fixed order wn = 0, 1), then dx = rstd (g - mean g - xhat mean(g xhat)) + R --
+      // tb_layernorm_bwd's arithmetic on the fp32 accumulators (one rounding fewer than through the fp16 dl3 tensor).
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      // (the LayerNorm input x is read twice, here and in the output pass -- the second time from the L2: held in 40 registers across the exchange
+      // the kernel spilled)
+      f32x2_t st[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) st[i] = *(const f32x2_t*)(p.ln_stats + 2 * (mrow + 16 * i));
+      float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < 10; ++jj) {
+        const f32x4_t gm = *(const f32x4_t*)(p.ln_gamma + ncol + 16 * jj);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f16x4 x4 = *(const f16x4*)((const f16*)p.ln_x + (mrow + 16 * i) * p.ld_lnx + ncol + 16 * jj);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = acc_o[i][jj][e] * gm[e];
+            acc_o[i][jj][e] = g;
+            s1[i] += g;
+            s2[i] += g * (((float)x4[e] - st[i][0]) * st[i][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        s1[i] += __shfl_xor(s1[i], 16, 64), s2[i] += __shfl_xor(s2[i], 16, 64);
+        s1[i] += __shfl_xor(s1[i], 32, 64), s2[i] += __shfl_xor(s2[i], 32, 64);
+      }
+      f32x2_t* const red = reinterpret_cast<f32x2_t*>(smem_raw);   // [8 waves][2][16] (the ring slots are free: every wave has left the main loop ...)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... after this barrier
+      if (lq == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) red[(wave * 2 + i) * 16 + l15] = f32x2_t{s1[i], s2[i]};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      constexpr float inv_c = 1.f / (float)FF_C;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x2_t a = red[((wm * 2 + 0) * 2 + i) * 16 + l15], b = red[((wm * 2 + 1) * 2 + i) * 16 + l15];
+        const float m1 = (a[0] + b[0]) * inv_c, m2 = (a[1] + b[1]) * inv_c;
+#pragma unroll
+        for (int jj = 0; jj < 10; ++jj) {
+          f16x4 o, r4 = {0, 0, 0, 0};
+          if (p.R) r4 = *(const f16x4*)((const f16*)p.R + (mrow + 16 * i) * p.ldr + ncol + 16 * jj);
+          const f16x4 x4 = *(const f16x4*)((const f16*)p.ln_x + (mrow + 16 * i) * p.ld_lnx + ncol + 16 * jj);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = ((float)x4[e] - st[i][0]) * st[i][1];
+            const float v = st[i][1] * (acc_o[i][jj][e] - m1 - xh * m2) + (float)r4[e];
+            o[e] = (f16)v;
+          }
+          *(f16x4*)((f16*)p.Y + (mrow + 16 * i) * p.ldy + ncol + 16 * jj) = o;
+        }
+      }
+      return;
+    }
+  }
   f16x4 rv[2][10];
   if (p.R) {
 #pragma unroll

@@ -555,12 +555,16 @@ def ff_fwd(x, w1p, b1p, w2, b2, hg, y, R=None):
     return y
 
 
-def ff_bwd(dy, w2d, w1d, hg, dx, R=None):
+def ff_bwd(dy, w2d, w1d, hg, dx, R=None, ln=None):
     """its backward in one launch: du = dy @ w2d^T (w2d = ff.net.2.weight^T [inner, C]); dh = du gelu(g), dg = du h gelu'(g);
-    dx = [dh | dg] @ w1d^T (w1d = packed ff.net.0.proj.weight^T [C, 2 inner]) (+ R)."""
+    dx = [dh | dg] @ w1d^T (w1d = packed ff.net.0.proj.weight^T [C, 2 inner]) (+ R).
+    ln = (x, stats, gamma): the LayerNorm backward of norm3 in the epilogue -- dx = layernorm_bwd([dh | dg] @ w1d^T, x, gamma, stats) + R."""
     M, C = dy.shape
     inner = hg.shape[1] // 2
     d = _ff_desc(dy, w2d, w1d, hg, dx, R)
+    if ln is not None:
+        x_, st_, g_ = ln
+        d.ln_x, d.ld_lnx, d.ln_stats, d.ln_gamma = L.ptr(x_), x_.stride(0), L.ptr(st_), L.ptr(g_)
     byt = 2.0 * (M * C + 3 * C * inner + M * 2 * inner + M * C * (2 if R is not None else 1))
     with _rec("ff_fused_kernel<true>", 2.0 * M * C * 3 * inner, byt):
         L.check(L.lib().tb_ff_bwd(d, L.stream()), "tb_ff_bwd")

@@ -32,6 +32,7 @@ import os as _os
 FUSE_GEGLU_BWD = _os.environ.get("TB_FUSE_GEGLU_BWD", "1") == "1"
 # the whole GEGLU feed-forward of the C = 320 blocks as one launch per direction (csrc/ff_fused.hip): the gated tensor / d(proj) never go to memory
 FUSE_FF = _os.environ.get("TB_FUSE_FF", "1") == "1"
+FUSE_FF_LN = _os.environ.get("TB_FUSE_FF_LN", "1") == "1"   # the fused feed-forward backward also applies norm3's LayerNorm backward (A/B switch)
 MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  # A/B switch (see the up-block forward)
 # LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
 # residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
@@ -486,7 +487,9 @@ class HipUNet:
             dt3 = self.scratch("g1", M, C)
             ops.gemm(dout, P[prefix + ".proj_out.wd"], dt3)
             dt2 = self.scratch("g3", M, C)
-            if fuse_ff:   # ff.net.2 dgrad, GEGLU backward and ff.net.0 dgrad in one launch; the LayerNorm backward behind it
+            if fuse_ff and FUSE_FF_LN:   # ... and the LayerNorm backward of norm3 in its epilogue (round 5): dt2 = LN'(dl3) + dt3 directly
+                ops.ff_bwd(dt3, P[tb + ".ff.net.2.wd"], P[tb + ".ff1.wd"], raw, dt2, R=dt3, ln=(t2, ls3, ln_g("norm3")))
+            elif fuse_ff:   # ff.net.2 dgrad, GEGLU backward and ff.net.0 dgrad in one launch; the LayerNorm backward behind it
                 dl3 = self.scratch("g2", M, C)
                 ops.ff_bwd(dt3, P[tb + ".ff.net.2.wd"], P[tb + ".ff1.wd"], raw, dl3)
                 ops.layernorm_bwd(dl3, t2, ln_g("norm3"), ls3, dt2, add=dt3)
