@@ -543,6 +543,29 @@ def test_encoder_forward_as_a_branch_beside_the_unet_head_is_bit_equal():
             torch.testing.assert_close(a, b, rtol=0, atol=0)
 
 
+def test_encoder_forward_issued_behind_the_unet_head_is_bit_equal():
+    """`te_fwd_late` (round 5, default): the encoder forward issued on the SAME stream where the UNet first needs the text states (in front of the
+    hoisted K/V projection) instead of in front of the UNet -- an issue-order change only, so gradients, losses and the updated parameters are
+    bit-equal to the reference's order (`train_textboost.py:1054-1067`), eagerly and replayed."""
+    B, hw, D = 2, 16, 64
+    res = []
+    for late, graph in ((False, False), (True, False), (True, True)):
+        _, step, added = build_step(B, hw, D)
+        assert step.te_fwd_late
+        step.te_fwd_late = late
+        _fill_inputs(step, added, B, hw, seed=35)
+        if graph:
+            step.capture(warmup=0)
+            step.replay()
+        else:
+            step.step_eager()
+        torch.cuda.synchronize()
+        res.append((step.flat_grad.clone(), step.state.clone(), step.te.lora_A.clone(), step.te.token_table[49408:].clone(), step.pred.clone()))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("mode", ["autocast", "fp32"])
 def test_hip_text_encoder_on_the_reference_generated_fixture(mode):
     """tests/golden/clip_textboost_tiny.pt was produced by the REFERENCE's own TextBoostModel (/root/reference/textboost/text_encoder.py:34-87,

@@ -1528,6 +1528,18 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
       // train_textboost.py:1036-1037 and log_validation), which the 80-wide wave tiles do not divide
       if (d.N % 128 == 0 && (d.M / 256) * (d.N / 128) >= 200 && !(g8_enable & 1024)) return launch8<4, 2, 4, 4, true, 3>(d, s, wshift);
       // too few tiles for the chip (16x16 maps: 8 x 8 tiles of 256 x 160): split the channel chunks over S workgroups per tile
+      // (65536, experiment: the same maps as 256 x 80 tiles -- twice the tiles, so HALF the k-slices: the GroupNorm behind the convolution reads
+      //  2 fp32 slices instead of 4 and this launch writes half the partial bytes, against 61 instead of 98 FLOP per operand byte)
+      if (d.N % 160 == 0 && (g8_enable & 32) && (g8_enable & 65536)) {
+        const int tiles = (int)((d.M / 256) * (d.N / 80)), kpt = d.Cin / 64;
+        int S = (230 + tiles - 1) / tiles;
+        while (S > 1 && kpt / S < 2) --S;
+        if (S > 1 && tiles * S >= 128) {
+          const int r = launch8<8, 1, 2, 5, true, 4>(d, s, wshift, S);
+          if (r != 1) return r;
+          return launch8<8, 1, 2, 5, true, 3>(d, s, wshift, S);
+        }
+      }
       if (d.N % 160 == 0 && (g8_enable & 32)) {
         const int tiles = (int)((d.M / 256) * (d.N / 160)), kpt = d.Cin / 64;
         int S = (230 + tiles - 1) / tiles;

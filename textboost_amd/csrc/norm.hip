@@ -385,6 +385,21 @@ __device__ __forceinline__ void gnf_block_sum2(float& a, float& b, float* red /*
   b = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
+// Workgroup -> (image, group), XCD-aware (workgroup w runs on XCD w & 7): a group's slice of a pixel row is 80 ... 320 bytes of a 128-byte-line
+// tensor, so neighbouring groups share lines; with the (G, B) grid of the first version neighbours sat on DIFFERENT XCDs and every shared line
+// was fetched into two L2s (1.8x the bytes from HBM for 40-channel groups of fp32 k-slices, 2.6x for the fp16 rows).  Here every XCD owns a
+// contiguous run of slices (a whole image at B = 8), the lines meet in one L2.  TB_GNF_XCD=0 at build time restores the plain order (A/B).
+#ifndef TB_GNF_XCD
+#define TB_GNF_XCD 1
+#endif
+__device__ __forceinline__ void gnf_slice_of_block(int G, int& b, int& g) {
+  const int n = gridDim.x, bid = blockIdx.x;
+  int sl = bid;
+  if (TB_GNF_XCD && (n & 7) == 0) sl = (bid & 7) * (n >> 3) + (bid >> 3);
+  b = sl / G;
+  g = sl - b * G;
+}
+
 // Split-K source of a fused GroupNorm (tb_groupnorm_*_splitk): the fp32 k-slices of the producing convolution and its epilogue operands.
 // gnf_splitk_load8 is splitk_reduce_unit + epilogue8 of gemm.hip for act NONE / fp16 C / alpha 1, operation for operation (slice order, then
 // + bias, + residual, + row bias, one rounding to fp16), so the fused launch is bit-identical to reducer + GroupNorm.
@@ -414,6 +429,9 @@ __device__ __forceinline__ void gnf_splitk_load_all(const GnSplitK& k, int b, in
     const int r = itc / cv, c = itc - r * cv;
     col[i] = g * gs + c * 8;
     off[i] = ((int64_t)b * HW + r) * k.npad + col[i];
+#ifdef TB_GNF_FAKE  // timing experiment only (wrong results): the slices as if laid out [b][g][HW][gs], contiguous per workgroup
+    off[i] = ((int64_t)b * (k.npad / gs) + g) * HW * gs + (int64_t)itc * 8;
+#endif
     roff[i] = ((int64_t)b * HW + r) * k.ldr + col[i];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
@@ -479,7 +497,9 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const f16* __restrict
                                                            float* __restrict__ stats, int HW, int C, int G, float eps, int silu,
                                                            const GnSplitK sk) {
   __shared__ float red[8];
-  const int g = blockIdx.x, b = blockIdx.y, gs = C / G, cv = gs >> 3;
+  int b, g;
+  gnf_slice_of_block(G, b, g);
+  const int gs = C / G, cv = gs >> 3;
   const int items = HW * cv;
   const f16* xb = X + (int64_t)b * HW * ldx + g * gs;
   f16* yb = Y + (int64_t)b * HW * ldy + g * gs;
@@ -546,7 +566,9 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const f16* __restrict
                                                            f16* __restrict__ dX, int64_t lddx, int HW, int C, int G, int silu,
                                                            const GnSplitK sk) {
   __shared__ float red[8];
-  const int g = blockIdx.x, b = blockIdx.y, gs = C / G, cv = gs >> 3;
+  int b, g;
+  gnf_slice_of_block(G, b, g);
+  const int gs = C / G, cv = gs >> 3;
   const int items = HW * cv;
   const f16* xb = X + (int64_t)b * HW * ldx + g * gs;
   const f16* dyb = SPLITK ? nullptr : dY + (int64_t)b * HW * lddy + g * gs;
@@ -1066,7 +1088,7 @@ extern "C" int tb_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
   if (gn_fused_ok(B, HW, C, G)) {
-    hipLaunchKernelGGL(gn_fused_fwd_kernel<false>, dim3(G, B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, HW, C, G,
+    hipLaunchKernelGGL(gn_fused_fwd_kernel<false>, dim3(G * B), dim3(256), 0, s, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta, stats, HW, C, G,
                        eps, silu, GnSplitK{});
     TB_CHECK_LAUNCH();
     return TB_OK;
@@ -1102,7 +1124,7 @@ extern "C" int tb_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int
   const int nch = gn_chunks(B, HW, C);
   hipStream_t s = (hipStream_t)stream;
   if (gn_fused_ok(B, HW, C, G)) {
-    hipLaunchKernelGGL(gn_fused_bwd_kernel<false>, dim3(G, B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
+    hipLaunchKernelGGL(gn_fused_bwd_kernel<false>, dim3(G * B), dim3(256), 0, s, (const f16*)dy, lddy, (const f16*)x, ldx, gamma, beta, stats,
                        (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, silu, GnSplitK{});
     TB_CHECK_LAUNCH();
     return TB_OK;
@@ -1144,7 +1166,7 @@ extern "C" int tb_groupnorm_fwd_splitk(const float* part, int S, int64_t npad, c
   if (((uintptr_t)part) % 16 || (R && (ldr % 8 || ((uintptr_t)R) % 16)) || ((uintptr_t)x) % 16 || ((uintptr_t)y) % 16) return TB_EINVAL;
   if (!gn_fused_ok(B, HW, C, G)) return TB_EINVAL;
   GnSplitK sk{part, S, npad, (int64_t)B * HW * npad, bias, rowbias, ldrb, (const f16*)R, ldr};
-  hipLaunchKernelGGL(gn_fused_fwd_kernel<true>, dim3(G, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta,
+  hipLaunchKernelGGL(gn_fused_fwd_kernel<true>, dim3(G * B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, (f16*)y, ldy, gamma, beta,
                      stats, HW, C, G, eps, silu, sk);
   TB_CHECK_LAUNCH();
   return TB_OK;
@@ -1159,7 +1181,7 @@ extern "C" int tb_groupnorm_bwd_splitk(const float* part, int S, int64_t npad, c
   if (((uintptr_t)part) % 16) return TB_EINVAL;
   if (!gn_fused_ok(B, HW, C, G)) return TB_EINVAL;
   GnSplitK sk{part, S, npad, (int64_t)B * HW * npad, nullptr, nullptr, 0, nullptr, 0};
-  hipLaunchKernelGGL(gn_fused_bwd_kernel<true>, dim3(G, B), dim3(256), 0, (hipStream_t)stream, (const f16*)nullptr, (int64_t)0, (const f16*)x,
+  hipLaunchKernelGGL(gn_fused_bwd_kernel<true>, dim3(G * B), dim3(256), 0, (hipStream_t)stream, (const f16*)nullptr, (int64_t)0, (const f16*)x,
                      ldx, gamma, beta, stats, (const f16*)add, ldadd, (f16*)dx, lddx, HW, C, G, silu, sk);
   TB_CHECK_LAUNCH();
   return TB_OK;

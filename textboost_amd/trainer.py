@@ -229,6 +229,12 @@ class TextBoostStep:
         # costs a cross-stream dependency: both schedules are net LOSSES and stay opt-in (TB_SPLIT_TE=1, TB_TE_FWD_SIDE=1) as tested A/B knobs.
         self.split_te = self.merge_teacher and os.environ.get("TB_SPLIT_TE", "0") == "1"
         self.te_fwd_side = self.merge_teacher and os.environ.get("TB_TE_FWD_SIDE", "0") == "1"
+        # Issue ORDER only, one stream: the encoder forward is issued where the UNet first needs the text states (in front of the hoisted K/V
+        # projection), behind conv_in / the first ResNet block / the first self-attention.  Every replay opens with a submission bubble
+        # (profiles/r05_step_timeline.txt: ~90 ... 250 us of gaps about 16 launches in, while the runtime is still writing the rest of the graph's
+        # packets): ~0.7 ms of chip-filling kernels at the head of the graph cover it where 16 five-microsecond launches did not.  Same kernels,
+        # same operands: bit-identical results.
+        self.te_fwd_late = os.environ.get("TB_TE_FWD_LATE", "1") == "1"
         if self.merge_teacher:  # (allocated whenever the split is possible, so that tests can toggle `split_te` on one object)
             prio = int(os.environ.get("TB_SIDE_PRIORITY", "0"))
             self.side2 = torch.cuda.Stream(device=device, priority=prio)
@@ -259,7 +265,7 @@ class TextBoostStep:
         self.timesteps.random_(0, self.hp.num_train_timesteps, generator=self.gen)
 
     # the step body in four phases; `forward_backward` runs them in the reference's order on one stream (teacher on a forked side stream)
-    def _phase_student(self, encoder_only=False):
+    def _phase_student(self, encoder_only=False, skip_encoder=False):
         hp, te, B = self.hp, self.te, self.B
         if not encoder_only:
             if self.vae is not None:
@@ -267,6 +273,8 @@ class TextBoostStep:
             ops.add_noise(self.x0, self.noise, self.timesteps, self.acp, self.noisy, self.velocity)
             te.pack_lora()
             self.unet.pack_kv_lora()
+        if skip_encoder:
+            return
         if self.merge_teacher:
             nb = self.ids_all.shape[0]
             out = te.forward(self.ids_all, slot=0, extra_ids=self.prior_ids, extra_table=self.teacher_table32)
@@ -362,12 +370,19 @@ class TextBoostStep:
             self._phase_unet_backward()
             self._phase_encoder_backward()
             return
-        self._phase_student()
+        late = self.te_fwd_late and not (self.kpl and not self.merge_teacher)
+        if late:
+            self._phase_student(encoder_only=False, skip_encoder=True)
+        else:
+            self._phase_student()
         fork = None
         if self.kpl:
             fork = torch.cuda.Event()
             fork.record(main)
-        self._phase_unet_forward()
+        if late:
+            self.pred = self.unet.forward(self.noisy, self.timesteps, self.ehs16, ehs_ready=lambda: self._phase_student(encoder_only=True))
+        else:
+            self._phase_unet_forward()
         if self.kpl and self.merge_teacher:
             self._phase_teacher()  # only the KPL loss kernel is left of it
         elif self.kpl:
