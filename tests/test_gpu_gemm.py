@@ -727,6 +727,59 @@ def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
     assert rel_err(outs[0], outs[1]) < 3e-4 and rel_err(outs[0], outs[2]) < 3e-4
 
 
+@pytest.mark.parametrize("act", ["quick_gelu", "quick_gelu_grad", "none_f32"])
+def test_linear_ragged_last_row_tile_128x128(act):
+    """the text encoder's wide layers (M = 24 x 77 = 1848 token rows: not a multiple of any tile height; N = 3072, K = 768) on the 8-wave 128 x 128
+    tile with a RAGGED last row tile (tb_gemm8_set bit 131072, an experiment: 28.3 -> 27.4 us, not worth a default): the panel loads of rows past M
+    read row 0 and nothing of them is stored (canary rows), the generic epilogue (GELU variants with the saved pre-activation, fp32 output +
+    fp32 residual) agrees with the 4-wave kernel and with torch."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(23)
+    M, N, K = 1848, 3072, 768
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda")
+    pre = torch.randn(M, N, device="cuda").half()
+    R32 = torch.randn(M, N, device="cuda")
+    prev = L.lib().tb_gemm8_set(39)
+    outs, pres = [], []
+    try:
+        for bits in (39 | 131072, 39):
+            L.lib().tb_gemm8_set(bits)
+            f32 = act == "none_f32"
+            Cbuf = torch.full((M + 128, N), 3.0, device="cuda", dtype=torch.float32 if f32 else torch.float16)
+            out = Cbuf[:M]
+            c2 = pre.clone() if act == "quick_gelu_grad" else (torch.zeros_like(pre) if act == "quick_gelu" else None)
+            if act == "quick_gelu":
+                ops.gemm(A, W, out, bias=b, act=L.ACT_QUICK_GELU, C2=c2)
+            elif act == "quick_gelu_grad":
+                ops.gemm(A, W, out, act=L.ACT_QUICK_GELU_GRAD, C2=c2)
+            else:
+                ops.gemm(A, W, out, bias=b, R=R32)
+            last = (ctypes.c_int * 6)()
+            took = bool(L.lib().tb_gemm8_last(last))
+            assert (took and list(last)[:4] == [2, 4, 4, 2]) == (bits != 39), list(last)
+            assert (Cbuf[M:] == 3).all()
+            outs.append(out)
+            pres.append(c2)
+    finally:
+        L.lib().tb_gemm8_set(prev)
+    acc = A.float() @ W.float().T
+    if act == "quick_gelu":
+        z = acc + b
+        ref = z * torch.sigmoid(1.702 * z)
+        assert rel_err(pres[0], z) < 1e-3 and torch.equal(pres[0], pres[1])
+    elif act == "quick_gelu_grad":
+        z = pre.float()
+        sg = torch.sigmoid(1.702 * z)
+        ref = acc * (sg * (1 + 1.702 * z * (1 - sg)))
+    else:
+        ref = acc + b + R32
+    parity("ragged 128 x 128 Linear tile", outs[0], ref, rel=1e-3, maxabs=6e-3, ch_dim=1, ch_rel=2e-3)
+    assert rel_err(outs[0], outs[1]) < 3e-4
+
+
 @pytest.mark.parametrize("K,bias,res", [(5120, True, True), (10240, False, False)])
 def test_linear_long_k_two_slices_of_128x160_tiles(K, bias, res):
     """the 16x16-map long-K Linear layers (M = 2048, N = 1280: ff.net.2, the GEGLU-projection dgrad) as 16 x 8 tiles of 128 x 160 in two k-slices on the

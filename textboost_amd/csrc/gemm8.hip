@@ -1310,7 +1310,8 @@ template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0, int KH
 int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
   // SUB == 1: the tile grid walks the COARSE map (a quarter of the output rows) once per output class: S = 4 is the class count, not a k-split
-  const int tiles_m = (int)((SUB == 1 ? d.M / 4 : d.M) / BM), tiles_n = (int)(d.N / BN);
+  // (Linear: a ragged last row tile is allowed -- the panel loads clamp their rows to M - 1 and every epilogue masks m < M)
+  const int tiles_m = CONV ? (int)((SUB == 1 ? d.M / 4 : d.M) / BM) : (int)((d.M + BM - 1) / BM), tiles_n = (int)(d.N / BN);
   const int64_t npad = (d.N + 7) & ~(int64_t)7;
   if (SUB == 1 && S != 4) return TB_EINVAL;
   if (SUB != 1 && S > 1 && (!d.ws || (size_t)S * (size_t)d.M * (size_t)npad * 4 > d.ws_bytes)) return 1;
@@ -1581,6 +1582,10 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
       if (r != 1) return r;
     }
   }
+  // the text encoder's wide layers (CLIP fc1 and the dgrad of fc2: M = 1848 token rows, N = 3072, K = 768): 15 x 24 tiles of 128 x 128, two
+  // workgroups per CU, the last row tile ragged -- against 720 two-stage 128 x 64 tiles of the 4-wave kernel (bit 131072)
+  if ((g8_enable & 131072) && !ln_act && d.K <= 1024 && d.N % 128 == 0 && d.M >= 1024 && d.M < 4096 && ((d.M + 127) / 128) * (d.N / 128) >= 300)
+    return launch8<2, 4, 4, 2, false, 2>(d, s, 30);
   if (d.N % 320) return 1;
   if (ln_act && (d.M / 128) * (d.N / 320) >= 200 && d.M % 128 == 0) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
   if (d.M % 128 == 0 && (d.M / 128) * (d.N / 320) >= 200 && !(g8_enable & 8)) return launch8<2, 4, 4, 5, false, 2>(d, s, 30);
