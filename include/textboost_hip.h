@@ -279,6 +279,10 @@ int tb_convin_to_nhwc(const void* in, int in_dtype, int Cin, const float* w_pack
 /* UNet conv_out forward: NHWC fp16 [B*H*W, C] -> NCHW fp16 [B,4,H,W]; w_packed fp32 [4][9][C] */
 int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, const float* bias, void* out, int B, int H, int W, int C,
                 tb_stream_t stream);
+/* the three boundary convolutions above run on the matrix cores when the map width is a multiple of 16 and the channel count of 32 (16-pixel
+ * MFMA tiles; the fp32 pack is consumed in the library's 16-bit type, exact for a model cast by unet.to(fp16), fp32 accumulation): 1 (default);
+ * 0 = the fp32 VALU kernels for every shape.  Returns the old value (A/B and test knob). */
+int tb_boundary_conv_set_variant(int v);
 /* ---- VAE encoder pieces (vae.encode(x).latent_dist.sample() * scaling_factor, train_textboost.py:1036-1037) ----
  * row softmax of fp32 scores -> fp16 probabilities (single-head 512-channel mid-block attention runs as GEMM, softmax, GEMM) */
 int tb_softmax_rows(const float* scores, int64_t lds, void* probs /* fp16 */, int64_t ldp, int64_t rows, int cols, tb_stream_t stream);

@@ -15,6 +15,7 @@ def apply(codes):
         elif c.startswith("gn:"): lib.tb_groupnorm_set_variant(int(c[3:]))
         elif c.startswith("defer:"): ops.DEFER_SPLITK = bool(int(c[6:]))
         elif c.startswith("lora:"): lib.tb_lora_set_variant(int(c[5:]))
+        elif c.startswith("bc:"): lib.tb_boundary_conv_set_variant(int(c[3:]))
         elif c.startswith("chain:"):
             import textboost_amd.text_encoder as _te; _te.CHAIN_LORA_BWD = bool(int(c[6:]))
         elif c.startswith("env:"):

@@ -63,6 +63,55 @@ def test_conv_in_out_boundary_kernels():
     assert rel_err(dh, ref) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 32, 320), (1, 8, 16, 64), (2, 5, 48, 96)])
+def test_conv_in_out_boundary_kernels_on_the_matrix_cores(B, H, W, C):
+    """round 5: conv_in / conv_out / the conv_out input gradient as 16-pixel MFMA tiles (maps whose width is a multiple of 16, channels of 32;
+    `tb_boundary_conv_set_variant`): against torch (the fp32 pack is consumed in 16 bits: inputs here are fp16-representable, as the weights of
+    a model cast by unet.to(fp16) are) and against the fp32 VALU kernels they replace; image borders, the strided NHWC output, 3-channel input."""
+    ops, L = _ops()
+    torch.manual_seed(5)
+    h16 = lambda t: t.half().float()   # noqa: E731
+    x = torch.randn(B, 4, H, W, device=dev).half()
+    w = h16(torch.randn(C, 4, 3, 3, device=dev) * 0.2); b = torch.randn(C, device=dev)
+    wp = w.permute(2, 3, 1, 0).reshape(36, C).contiguous()
+    wo = h16(torch.randn(4, C, 3, 3, device=dev) * 0.1); bo = torch.randn(4, device=dev)
+    wop = wo.permute(0, 2, 3, 1).reshape(4, 9, C).contiguous()
+    wdp = wo.permute(2, 3, 0, 1).reshape(36, C).contiguous()
+    hbuf = torch.randn(B * H * W, C + 8, device=dev).half()
+    h = hbuf[:, :C]
+    dpred = torch.randn(B, 4, H, W, device=dev)
+    x3 = torch.rand(B, 3, H, W, device=dev) * 2 - 1
+    w3 = h16(torch.randn(C, 3, 3, 3, device=dev) * 0.2)
+    w3p = w3.permute(2, 3, 1, 0).reshape(27, C).contiguous()
+    res = []
+    old = L.lib().tb_boundary_conv_set_variant(1)
+    try:
+        for variant in (1, 0):
+            L.lib().tb_boundary_conv_set_variant(variant)
+            obuf = torch.full((B * H * W, C + 16), 3.0, device=dev, dtype=torch.float16)
+            out = obuf[:, 8:8 + C]
+            ops.conv4_to_nhwc(x, wp, b, out, B, H, W, C, sign=1)
+            assert (obuf[:, :8] == 3).all() and (obuf[:, 8 + C:] == 3).all()
+            pred = torch.empty(B, 4, H, W, device=dev, dtype=torch.float16)
+            ops.conv_to4(h, wop, bo, pred, B, H, W, C)
+            dh = torch.empty(B * H * W, C, device=dev, dtype=torch.float16)
+            ops.conv4_to_nhwc(dpred, wdp, None, dh, B, H, W, C, sign=-1)
+            o3 = torch.empty(B * H * W, C, device=dev, dtype=torch.float16)
+            ops.convin_to_nhwc(x3, 3, w3p, b, o3, B, H, W, C)
+            res.append((out.clone(), pred, dh, o3))
+    finally:
+        L.lib().tb_boundary_conv_set_variant(old)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])   # noqa: E731
+    refs = (nhwc(F.conv2d(x.float(), w, b, padding=1)),
+            F.conv2d(h.float().view(B, H, W, C).permute(0, 3, 1, 2), wo, bo, padding=1),
+            nhwc(F.conv_transpose2d(dpred, wo, padding=1)),
+            nhwc(F.conv2d(x3, w3, b, padding=1)))
+    for k, (name, tol) in enumerate((("conv_in", 1e-3), ("conv_out", 1e-3), ("conv_out dgrad", 2e-3), ("conv_in rgb", 2e-3))):
+        assert rel_err(res[0][k], refs[k]) < tol, (name, rel_err(res[0][k], refs[k]))
+        assert rel_err(res[1][k], refs[k]) < tol, (name, "valu", rel_err(res[1][k], refs[k]))
+        assert rel_err(res[0][k], res[1][k]) < tol, (name, "mfma vs valu", rel_err(res[0][k], res[1][k]))
+
+
 def test_mse_and_kpl_losses():
     ops, L = _ops()
     torch.manual_seed(2)

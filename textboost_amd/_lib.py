@@ -143,6 +143,7 @@ _SIGS = {
     "tb_lora_bwd_chain": ([_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _VP, _VP, _I64, _I, _I, _I, _I, _F, _VP, _I64, _VP, _I64, _VP, _I,
                            _VP], C.c_int),
     "tb_lora_set_variant": ([_I], C.c_int),
+    "tb_boundary_conv_set_variant": ([_I], C.c_int),
     "tb_lora_bwd": ([_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _F, _VP], C.c_int),
     "tb_sumsq": ([_VP, _I64, _VP, _VP, _VP], C.c_int),
     "tb_scaler_update": ([_VP, _F, _F, _F, _F, _F, _F, _I, _F, _VP], C.c_int),

@@ -126,6 +126,197 @@ __global__ __launch_bounds__(256) void conv_to4_kernel(const f16* __restrict__ i
   }
 }
 
+// ---- the same two boundary convolutions on the matrix cores (round 5).  The kernels above are load-ISSUE bound, not memory bound: conv_to4 spends
+// 225 scalar-width load instructions per pixel and wave (74 us for 21 MB of input), conv4_to_nhwc 144 per thread (59 us for 21 MB of output).  As
+// 16 x 16 x 32 MFMA tiles over 16 consecutive pixels of an image row a wave issues one 16-byte load per lane and MFMA, the 16-bit weights wait
+// in the LDS (staged once per workgroup from the caller's fp32 pack: exact for a model cast by unet.to(fp16), train_textboost.py:937), fp32
+// accumulation as before.  Shapes outside (W % 16, C % 32) keep the kernels above.
+//
+// conv_to4: D[co, px] = sum_k W[co, k] X[px, k], k = (tap, channel).  srcA = weight rows (4 real, 12 zero), srcB = pixel rows: lane l holds
+// pixel l % 16 and its accumulator rows 4 (l / 16) .. + 3 are output channels -- lanes 0..15 own the 4 x 16 results, one 32-byte run per channel.
+constexpr int C4_GROUPS = 1;   // 16-pixel groups per wave (64 pixels per workgroup: 512 workgroups at 64 x 64 x 8, two per CU)
+// KCT = C / 32 at compile time (10: the 320-channel UNets) unrolls the whole 9 x KCT tile loop -- straight-line code, so the compiler issues the
+// 16-byte pixel loads many MFMAs ahead; 0 = run-time channel count (rolled loops)
+template <int KCT>
+__global__ __launch_bounds__(256) void conv_to4_mfma_kernel(const f16* __restrict__ in, int64_t ldi, const float* __restrict__ Wp,
+                                                            const float* __restrict__ bias, f16* __restrict__ out, int B, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
+  f16* ws = reinterpret_cast<f16*>(c4_smem);   // [tap][kc][co 4][32]
+  const int KC = KCT ? KCT : C >> 5, t = threadIdx.x;
+  {
+    constexpr int NIT = KCT ? (9 * KCT * 32 + 255) / 256 : 1;
+    const int units = 9 * KC * 4 * 8;   // units of 4 weights
+    auto put = [&](int i, const f32x4& w) {
+      const int q = i & 7, co = (i >> 3) & 3, r = i >> 5, kc = r % KC, tap = r / KC;
+      f16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (f16)w[e];
+      *(f16x4*)(ws + ((tap * KC + kc) * 4 + co) * 32 + q * 4) = h;
+    };
+    auto src_of = [&](int i) {
+      const int q = i & 7, co = (i >> 3) & 3, r = i >> 5, kc = r % KC, tap = r / KC;
+      return Wp + ((int64_t)co * 9 + tap) * C + kc * 32 + q * 4;
+    };
+    if constexpr (KCT != 0) {
+      f32x4 w[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = t + it * 256;
+        w[it] = *(const f32x4*)src_of(i < units ? i : 0);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = t + it * 256;
+        if (i < units) put(i, w[it]);
+      }
+    } else {
+      for (int i = t; i < units; i += 256) put(i, *(const f32x4*)src_of(i));
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, quad = lane >> 4;
+  const int gpr = W >> 4;   // groups per image row
+  const int64_t ngroups = (int64_t)B * H * gpr;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+  for (int g = 0; g < C4_GROUPS; ++g) {
+    const int64_t grp = ((int64_t)blockIdx.x * 4 + wave) * C4_GROUPS + g;
+    if (grp >= ngroups) break;
+    const int xg = (int)(grp % gpr);
+    const int64_t by = grp / gpr;
+    const int y = (int)(by % H), b = (int)(by / H), x = xg * 16 + p;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const f16* wt0 = ws + (p & 3) * 32 + quad * 8;
+    if constexpr (KCT != 0) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int sy = y + ky - 1, sx = x + kx - 1;
+        const bool ok = sx >= 0 && sx < W && sy >= 0 && sy < H;   // (a row outside the image costs its MFMAs on zeros: two of 64 rows)
+        const f16* src = in + (((int64_t)b * H + (ok ? sy : y)) * W + (ok ? sx : x)) * ldi + quad * 8;
+#pragma unroll
+        for (int kc = 0; kc < KCT; ++kc) {
+          f16x8 xv = *(const f16x8*)(src + kc * 32);
+          f16x8 wv = *(const f16x8*)(wt0 + (tap * KCT + kc) * 128);
+          if (!ok) xv = zero8;
+          if (p >= 4) wv = zero8;
+          if (kc & 1) acc1 = TB_MFMA_16x16x32(wv, xv, acc1);
+          else acc0 = TB_MFMA_16x16x32(wv, xv, acc0);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int sy = y + ky - 1, sx = x + kx - 1;
+        if (sy < 0 || sy >= H) continue;   // (wave-uniform)
+        const bool ok = sx >= 0 && sx < W;
+        const f16* src = in + (((int64_t)b * H + sy) * W + (ok ? sx : x)) * ldi + quad * 8;
+        const f16* wt = wt0 + tap * KC * 128;
+#pragma unroll 2
+        for (int kc = 0; kc < KC; kc += 2) {
+          f16x8 x0 = *(const f16x8*)(src + kc * 32), x1 = kc + 1 < KC ? *(const f16x8*)(src + kc * 32 + 32) : zero8;
+          f16x8 w0 = *(const f16x8*)(wt + kc * 128), w1 = kc + 1 < KC ? *(const f16x8*)(wt + kc * 128 + 128) : zero8;
+          if (!ok) x0 = zero8, x1 = zero8;
+          if (p >= 4) w0 = zero8, w1 = zero8;
+          acc0 = TB_MFMA_16x16x32(w0, x0, acc0);
+          acc1 = TB_MFMA_16x16x32(w1, x1, acc1);
+        }
+      }
+    }
+    if (quad == 0) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        out[(((int64_t)b * 4 + co) * H + y) * W + x] = (f16)(acc0[co] + acc1[co] + (bias ? bias[co] : 0.f));
+    }
+  }
+}
+
+// conv4_to_nhwc: D[co, px] = sum_{k < 9 CIN} W[k, co] P[px, k], P = the 3 x 3 x CIN patch of the NCHW side (k = tap * CIN + ci, zero-padded to 64).
+// The weight rows of a 32-channel block are permuted so that a lane's accumulators of the block's two 16-row tiles are 8 CONSECUTIVE output
+// channels of its pixel: MFMA row a of tile h is channel 32 J + 8 (a / 4) + 4 h + (a % 4) -> one 16-byte store per lane, block and pixel.
+constexpr int CI_LDW = 72;   // f16 per weight row in the LDS (64 k + pad: conflict-free 16-byte reads of 16 consecutive rows)
+template <typename TIN, int CIN>
+__global__ __launch_bounds__(256) void conv4_to_nhwc_mfma_kernel(const TIN* __restrict__ in, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bias, f16* __restrict__ out, int64_t ldo, int B, int H,
+                                                                 int W, int Cout, int sign, float in_scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
+  f16* ws = reinterpret_cast<f16*>(c4_smem);                       // [Cout][CI_LDW]: row co = the 9 CIN weights of output channel co over k, zeros behind
+  float* bs = reinterpret_cast<float*>(ws + (size_t)Cout * CI_LDW);   // [Cout] bias (zeros when absent)
+  constexpr int KR = 9 * CIN, KZ = (KR + 3) & ~3;   // real k, first k of the 8-byte zero fill
+  const int t = threadIdx.x, c4n = Cout >> 2;
+  for (int i = t; i < KR * c4n; i += 256) {   // 4 channels of one k per thread: 16-byte global loads, a row of the pack is contiguous over channels
+    const int k = i / c4n, c4 = i - k * c4n;
+    const f32x4 w = *(const f32x4*)(Wp + (int64_t)k * Cout + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ws[(c4 * 4 + e) * CI_LDW + k] = (f16)w[e];
+  }
+  for (int i = t; i < Cout * ((64 - KZ) / 4 + 1); i += 256) {   // the padding k: KR .. KZ - 1 one by one (slot 0), then 8-byte zeros
+    const int per = (64 - KZ) / 4 + 1, co = i / per, j = i - co * per;
+    if (j == 0) {
+      for (int k = KR; k < KZ; ++k) ws[co * CI_LDW + k] = (f16)0.f;
+    } else {
+      *(f16x4*)(ws + co * CI_LDW + KZ + (j - 1) * 4) = f16x4{0, 0, 0, 0};
+    }
+  }
+  for (int i = t; i < Cout; i += 256) bs[i] = bias ? bias[i] : 0.f;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, quad = lane >> 4;
+  const int gpr = W >> 4;
+  const int64_t ngroups = (int64_t)B * H * gpr;
+  // this lane's slice of its first pixel's patch is fetched before the barrier (independent of the staged weights)
+  auto patch = [&](int64_t grp, f16x8 (&pf)[2], int& b, int& y, int& x) {
+    const int xg = (int)(grp % gpr);
+    const int64_t by = grp / gpr;
+    y = (int)(by % H), b = (int)(by / H), x = xg * 16 + p;
+    float v[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = s2 * 32 + quad * 8 + e;
+        const int tap = k / CIN, ci = k - tap * CIN, ky = tap / 3, kx = tap - ky * 3;
+        const int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
+        const bool ok = k < KR && sy >= 0 && sy < H && sx >= 0 && sx < W;
+        const TIN raw = in[ok ? (((int64_t)b * CIN + ci) * H + sy) * W + sx : 0];   // (clamped address: no branch around the load)
+        v[s2][e] = ok ? (float)raw * in_scale : 0.f;
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[s2][e] = (f16)v[s2][e];
+  };
+  const int64_t grp0 = ((int64_t)blockIdx.x * 4 + wave) * C4_GROUPS;
+  f16x8 pf[2];
+  int b = 0, y = 0, x = 0;
+  if (grp0 < ngroups) patch(grp0, pf, b, y, x);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < C4_GROUPS; ++g) {
+    const int64_t grp = grp0 + g;
+    if (grp >= ngroups) break;
+    if (g > 0) patch(grp, pf, b, y, x);
+    f16* dst = out + (((int64_t)b * H + y) * W + x) * ldo + quad * 8;
+#pragma unroll 2
+    for (int J = 0; J < Cout; J += 32) {
+      f32x4 a[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = J + 8 * (p >> 2) + 4 * h + (p & 3);   // channel of MFMA row p of tile h
+        const f16* wr = ws + co * CI_LDW + quad * 8;
+        a[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        a[h] = TB_MFMA_16x16x32(*(const f16x8*)wr, pf[0], a[h]);
+        if (KR > 32) a[h] = TB_MFMA_16x16x32(*(const f16x8*)(wr + 32), pf[1], a[h]);
+      }
+      // accumulator i of tile h = channel J + 8 quad + 4 h + i of pixel p
+      const f32x4 b0 = *(const f32x4*)(bs + J + 8 * quad), b1 = *(const f32x4*)(bs + J + 8 * quad + 4);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)(a[0][e] + b0[e]), o[4 + e] = (f16)(a[1][e] + b1[e]);
+      *(f16x8*)(dst + J) = o;
+    }
+  }
+}
+
 // ---- :1085-1090 loss = mean((pred.float() - target.float())^2); also d(loss*loss_scale)/d pred.
 // Single block (N = B*4*h*w is small); loss_out[0] = mse (unscaled). dpred fp32 NCHW.
 __global__ __launch_bounds__(1024) void mse_loss_kernel(const f16* __restrict__ pred, const float* __restrict__ target,
@@ -429,6 +620,12 @@ __global__ __launch_bounds__(256) void vae_image_kernel(const float* __restrict_
 
 }  // namespace
 
+static int g_boundary_mfma = 1;   // tb_boundary_conv_set_variant: 1 = the matrix-core boundary convolutions (round 5), 0 = the VALU kernels
+extern "C" int tb_boundary_conv_set_variant(int v) {
+  const int old = g_boundary_mfma;
+  g_boundary_mfma = v;
+  return old;
+}
 #define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
 
 extern "C" int tb_add_noise(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod, void* noisy,
@@ -457,6 +654,24 @@ extern "C" int tb_convin_to_nhwc(const void* in, int in_dtype, int Cin, const fl
   if (((uintptr_t)w_packed) % 16) return TB_EINVAL;
   const int64_t n = (int64_t)B * H * ((W + 3) / 4) * (Cout / 8);
   hipStream_t s = (hipStream_t)stream;
+  if (g_boundary_mfma && W % 16 == 0 && Cout % 32 == 0 && Cout <= 416) {   // (<= 64 KB of LDS: weights + bias)   // matrix-core form (see conv4_to_nhwc_mfma_kernel)
+    const int64_t groups = (int64_t)B * H * (W / 16);
+    const dim3 grid((unsigned)((groups + 4 * C4_GROUPS - 1) / (4 * C4_GROUPS)));
+    const size_t lds = (size_t)Cout * CI_LDW * 2 + (size_t)Cout * 4;
+#define TB_CONVIN_M(T, CI)                                                                                                                     \
+  hipLaunchKernelGGL((conv4_to_nhwc_mfma_kernel<T, CI>), grid, dim3(256), lds, s, (const T*)in, w_packed, bias, (f16*)out, ldo, B, H, W, Cout, sign, \
+                     in_scale)
+    if (in_dtype == TB_F32) {
+      if (Cin == 4) TB_CONVIN_M(float, 4);
+      else TB_CONVIN_M(float, 3);
+    } else {
+      if (Cin == 4) TB_CONVIN_M(f16, 4);
+      else TB_CONVIN_M(f16, 3);
+    }
+#undef TB_CONVIN_M
+    TB_CHECK_LAUNCH();
+    return TB_OK;
+  }
 #define TB_CONVIN(T, CI) \
   hipLaunchKernelGGL((conv4_to_nhwc_kernel<T, CI, 4>), GRID1D(n), dim3(256), 0, s, (const T*)in, w_packed, bias, (f16*)out, ldo, B, H, W, Cout, sign, in_scale)
   if (in_dtype == TB_F32) {
@@ -481,6 +696,26 @@ extern "C" int tb_conv_to4(const void* in, int64_t ldi, const float* w_packed, c
   (void)hipGetLastError();  // drop any stale (non-sticky) error left by an earlier runtime call
   if (!in || !w_packed || !out || B <= 0) return TB_EINVAL;
   const int64_t M = (int64_t)B * H * W;
+  if (g_boundary_mfma && W % 16 == 0 && C % 32 == 0 && C <= 1280 && ldi % 8 == 0 && ((uintptr_t)in) % 16 == 0 && ((uintptr_t)w_packed) % 16 == 0) {
+    const int64_t groups = (int64_t)B * H * (W / 16);
+    const size_t lds = (size_t)9 * C * 4 * 2;
+    const dim3 grid((unsigned)((groups + 4 * C4_GROUPS - 1) / (4 * C4_GROUPS)));
+    if (C == 320) {
+      hipLaunchKernelGGL(conv_to4_mfma_kernel<10>, grid, dim3(256), lds, (hipStream_t)stream, (const f16*)in, ldi, w_packed, bias, (f16*)out, B, H, W, C);
+    } else {
+      if (lds > 48 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+          if (hipFuncSetAttribute((const void*)conv_to4_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+            return TB_ELAUNCH;
+          attr_done = true;
+        }
+      }
+      hipLaunchKernelGGL(conv_to4_mfma_kernel<0>, grid, dim3(256), lds, (hipStream_t)stream, (const f16*)in, ldi, w_packed, bias, (f16*)out, B, H, W, C);
+    }
+    TB_CHECK_LAUNCH();
+    return TB_OK;
+  }
   hipLaunchKernelGGL(conv_to4_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)in, ldi, w_packed,
                      bias, (f16*)out, B, H, W, C);
   TB_CHECK_LAUNCH();
