@@ -727,6 +727,38 @@ def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
     assert rel_err(outs[0], outs[1]) < 3e-4 and rel_err(outs[0], outs[2]) < 3e-4
 
 
+@pytest.mark.parametrize("B,C,Hc,res", [(8, 320, 32, True), (8, 640, 16, True), (8, 320, 32, False), (2, 320, 32, True)])
+def test_stride2_conv_dgrad_as_sub_pixel_convolution(B, C, Hc, res):
+    """round 5: the input gradient of `Downsample2D`'s stride-2 convolution written as a sub-pixel convolution of d out
+    (`ops.pack_strided_dgrad_subpixel`, `conv=dict(upsample=2)`, gemm8 SUB = 1): 9 of its 16 (class, tap) blocks carry one filter tap, 7 are zero --
+    the convolution's own weights, nothing summed.  Against conv_transpose2d and against the 4-wave transposed gather it replaces, with the skip
+    gradient riding in as the residual."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(29)
+    H = 2 * Hc
+    w = (torch.randn(C, C, 3, 3, device="cuda") / (3 * C ** 0.5)).half()
+    dy = torch.randn(B, C, Hc, Hc, device="cuda").half()
+    R = torch.randn(B * H * H, C + 8, device="cuda").half()[:, 8:] if res else None
+    if not ops.subpixel_ok(B, Hc, Hc, C, C):
+        pytest.skip("coarse map does not tile")
+    dx = torch.full((B * H * H, C + 16), 3.0, device="cuda", dtype=torch.float16)
+    out = dx[:, 8:8 + C]
+    ops.gemm(nhwc(dy).view(-1, C), ops.pack_strided_dgrad_subpixel(w), out, R=R,
+             conv=dict(B=B, Hin=Hc, Win=Hc, Cin=C, Hout=H, Wout=H, stride=1, sign=1, upsample=2, transposed=0))
+    last = (ctypes.c_int * 6)()
+    assert L.lib().tb_gemm8_last(last) and list(last)[4] == 1, list(last)
+    assert (dx[:, :8] == 3).all() and (dx[:, 8 + C:] == 3).all()
+    old = torch.zeros(B * H * H, C, device="cuda", dtype=torch.float16)
+    ops.gemm(nhwc(dy).view(-1, C), pack_conv_w_dgrad(w), old, R=R,
+             conv=dict(B=B, Hin=Hc, Win=Hc, Cin=C, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=1))
+    ref = nhwc(F.conv_transpose2d(dy.float(), w.float(), stride=2, padding=1, output_padding=1)).reshape(B * H * H, C)
+    if res:
+        ref = ref + R.float()
+    parity("stride-2 dgrad as sub-pixel convolution", out, ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+    assert rel_err(out, old) < 3e-4, rel_err(out, old)
+
+
 @pytest.mark.parametrize("act", ["quick_gelu", "quick_gelu_grad", "none_f32"])
 def test_linear_ragged_last_row_tile_128x128(act):
     """the text encoder's wide layers (M = 24 x 77 = 1848 token rows: not a multiple of any tile height; N = 3072, K = 768) on the 8-wave 128 x 128

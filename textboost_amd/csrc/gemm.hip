@@ -1267,9 +1267,12 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
     // sub-pixel form of nearest-x2 + conv3x3 (gemm8.hip): upsample == 2 forward (A coarse [B, Hin, Win, Cin], C fine [B, 2 Hin, 2 Win, N],
     // W [4 classes][N][4 taps][Cin], K = 4 Cin), upsample == 3 dgrad (A fine [B, Hin, Win, Cin], C coarse [B, Hin / 2, Win / 2, N], W [N][16 Cin])
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != (d.upsample == 2 ? 4 : 16) * (int64_t)d.Cin) return TB_EINVAL;
-    if (d.M != (int64_t)d.B * d.Hout * d.Wout || d.stride != 1 || d.transposed || d.shift || d.R || d.rowbias || d.C2 || d.act != TB_ACT_NONE ||
+    if (d.M != (int64_t)d.B * d.Hout * d.Wout || d.stride != 1 || d.transposed || d.shift || d.rowbias || d.C2 || d.act != TB_ACT_NONE ||
         d.c_dtype != TB_F16)
       return TB_EINVAL;
+    // a residual rides in the forward form only (the stride-2 convolution's dgrad written as a sub-pixel convolution adds the skip gradient), as
+    // 16-byte fp16 rows
+    if (d.R && (d.upsample != 2 || d.r_dtype != TB_F16 || d.ldr % 8 || ((uintptr_t)d.R) % 16)) return TB_EINVAL;
     if (d.upsample == 2 ? (d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) : (d.Hin != 2 * d.Hout || d.Win != 2 * d.Wout)) return TB_EINVAL;
   } else if (d.a_mode == TB_A_CONV3X3) {
     if (d.A2 || d.Cin <= 0 || d.Cin % BK || d.K != 9 * (int64_t)d.Cin) return TB_EINVAL;

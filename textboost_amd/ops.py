@@ -116,6 +116,26 @@ def pack_subpixel_weights(w):
     return fwd.reshape(4 * Co, 4 * Ci).to(hd).contiguous(), dg.reshape(Ci, 16 * Co).to(hd).contiguous()
 
 
+def pack_strided_dgrad_subpixel(w):
+    """[Co, Ci, 3, 3] weight of a stride-2, padding-1 convolution (`Downsample2D`) -> the [4*Ci, 4*Co] operand that computes its INPUT GRADIENT as a
+    sub-pixel convolution (`gemm(..., conv=dict(upsample=2))`: A = d out [B, Hc, Wc, Co], C = d in [B, 2Hc, 2Wc, Ci]).  Fine pixel u = 2Y + py
+    receives filter row ky from coarse row y with u = 2y + ky - 1: py = 0 -> (ky 1, y = Y); py = 1 -> (ky 2, y = Y), (ky 0, y = Y + 1).  In the
+    window of class py (coarse rows Y - 1 + py + a, a in {0, 1}) that is KY[py][a] = (None, 1) for py = 0 and (2, 0) for py = 1: 9 of the 16
+    (class, tap) blocks carry one filter tap each, the other 7 are zero (16 / 9 of the products, on the halo-resident 8-wave tile instead of
+    the 4-wave transposed gather).  No taps are summed: the values are the convolution's own 16-bit weights."""
+    Co, Ci = w.shape[0], w.shape[1]
+    KY = ((None, 1), (2, 0))
+    out = torch.zeros(4, Ci, 4, Co, dtype=w.dtype, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for c in range(2):
+                    ky, kx = KY[py][a], KY[px][c]
+                    if ky is not None and kx is not None:
+                        out[2 * py + px, :, 2 * a + c, :] = w[:, :, ky, kx].t()
+    return out.reshape(4 * Ci, 4 * Co).to(L.half_dtype()).contiguous()
+
+
 def gemm_ln_ok(M, N, K, dtype=None):
     """can a fp16 Linear of this shape carry a fused LayerNorm epilogue (`gemm(..., ln_fwd=... / ln_bwd=...)`)?"""
     return dtype in (None, L.half_dtype()) and bool(L.lib().tb_gemm_ln_epilogue_ok(M, N, K))

@@ -45,6 +45,8 @@ FOLD_LN = _os.environ.get("TB_FOLD_LN", "1") == "1"
 # the forward and in the dgrad, no materialised 4x map, no 2x2 gradient pooling pass.  The summed filter rows are rounded to fp16 once: a stated
 # divergence from the 9-tap arithmetic, bounded in tests/test_gpu_gemm.py.  TB_SUBPIXEL=0 restores the materialised-upsample path (A/B).
 SUBPIXEL = _os.environ.get("TB_SUBPIXEL", "1") == "1"
+# the downsamplers' input gradient as a sub-pixel convolution of d out (ops.pack_strided_dgrad_subpixel); 0 = the 4-wave transposed gather
+DOWN_DGRAD_SUBPIXEL = _os.environ.get("TB_DOWN_DGRAD_SUBPIXEL", "1") == "1"
 
 
 @dataclass
@@ -273,6 +275,10 @@ class HipUNet:
                 skip_chs.append(c)
             if i < len(ch) - 1:
                 conv(f"down_blocks.{i}.downsamplers.0.conv")
+                name = f"down_blocks.{i}.downsamplers.0.conv"
+                # the stride-2 convolution's input gradient as a sub-pixel convolution over d out (csrc/gemm8.hip SUB = 1) where the coarse map tiles
+                if DOWN_DGRAD_SUBPIXEL and wdt != torch.float32 and ops.subpixel_ok(self.B, self.H >> (i + 1), self.W >> (i + 1), c, c, wdt):
+                    P[name + ".wdsub2"] = ops.pack_strided_dgrad_subpixel(sd[name + ".weight"].to(dev).to(wdt))
                 skip_chs.append(c)
             prev = c
         resnet("mid_block.resnets.0", ch[-1], ch[-1])
@@ -782,7 +788,12 @@ class HipUNet:
                 gx = self.buf(f"grad.down.{lvl}", xin.shape[0], xin.shape[1])
                 nxt = recs[ri + 1][4] if ri + 1 < len(recs) else None   # the layer in front of the downsampler wrote a skip tensor: its
                 R = skip_grad[nxt] if nxt is not None else None         # gradient rides in as the dgrad GEMM's residual (no add launch)
-                self._conv(g, name, gx, B, hw[lvl + 1][0], hw[lvl + 1][1], hw[lvl][0], hw[lvl][1], dgrad=True, transposed=1, R=R)
+                if (name + ".wdsub2") in P:
+                    ops.gemm(g, P[name + ".wdsub2"], gx, R=R,
+                             conv=dict(B=B, Hin=hw[lvl + 1][0], Win=hw[lvl + 1][1], Cin=g.shape[1], Hout=hw[lvl][0], Wout=hw[lvl][1], stride=1, sign=1,
+                                       upsample=2, transposed=0))
+                else:
+                    self._conv(g, name, gx, B, hw[lvl + 1][0], hw[lvl + 1][1], hw[lvl][0], hw[lvl][1], dgrad=True, transposed=1, R=R)
                 premerged = R is not None
                 g = gx
         # hoisted K/V dgrad -> d encoder_hidden_states (fp32)
