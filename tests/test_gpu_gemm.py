@@ -691,7 +691,7 @@ def test_linear_k320_activation_stationary_kernel(M, N, bias, res):
 
 
 @pytest.mark.parametrize("M,N,K,bias,res,act", [(2048, 1280, 1280, True, True, 0), (2048, 1280, 640, False, False, 0), (2048, 1280, 2560, True, False, 0),
-                                                (2048, 1280, 1344, True, True, 1)])
+                                                (2048, 1280, 1344, True, True, 1), (2048, 1280, 3840, False, False, 0)])   # (K = 3840: the qkv dgrad)
 def test_linear_one_tile_per_cu_128x80(M, N, K, bias, res, act):
     """the 16x16-map Linear layers as ONE 128 x 80 tile per CU on a 4-stage ring (two stages in flight across the barrier): round 5's
     gemm8_kernel<4, 1, 2, 5, false, 4, 0, 2> (4 x 1 x 2 waves: the two waves of a SIMD split every k-step, accumulators added through the LDS),
