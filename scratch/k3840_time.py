@@ -11,7 +11,7 @@ def timeit(fn, reps=24):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); g.replay(); g.replay(); e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / (2 * reps) * 1e3
-for M, N, K in [(2048, 1280, 3840), (8192, 640, 1920), (2048, 1280, 3200)]:
+for M, N, K in [(2048, 1280, 3840), (8192, 640, 5120), (8192, 640, 3840)]:
     A = [torch.randn(M, K, device="cuda").half() for _ in range(NR)]
     W = [(torch.randn(N, K, device="cuda") / K ** 0.5).half() for _ in range(NR)]
     out = [torch.empty(M, N, device="cuda", dtype=torch.float16) for _ in range(NR)]

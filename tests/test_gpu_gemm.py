@@ -812,6 +812,40 @@ def test_linear_ragged_last_row_tile_128x128(act):
     assert rel_err(outs[0], outs[1]) < 3e-4
 
 
+@pytest.mark.parametrize("K,bias,res", [(640, True, True), (2560, True, True), (3840, False, False), (5120, False, True)])
+def test_linear_one_tile_per_cu_128x160(K, bias, res):
+    """the 32x32-map Linear layers (M = 8192, N = 640: 64 x 4 tiles of 128 x 160, one per CU, 4-stage ring) up to K = 5120 (round 5: the
+    GEGLU-projection dgrad, K = 8 C, used to fall onto 64 x 320 tiles of the 3-stage ring -- 85 -> 66 us): against torch and against the route the
+    shape took before (tb_gemm8_set bit 262144 = the old K <= 2560 limit; bit 4096 = no 128 x 160 one-per-CU tile at all)."""
+    ops, L = _ops()
+    import ctypes
+    torch.manual_seed(31)
+    M, N = 8192, 640
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda") if bias else None
+    R = torch.randn(M, N + 8, device="cuda").half()[:, 8:] if res else None
+    prev = L.lib().tb_gemm8_set(39)
+    outs = []
+    try:
+        for bits in (39, 39 | 262144 | 4096):
+            L.lib().tb_gemm8_set(bits)
+            Cbuf = torch.full((M, N + 16), 3.0, device="cuda", dtype=torch.float16)
+            out = Cbuf[:, 8:8 + N]
+            ops.gemm(A, W, out, bias=b, R=R)
+            last = (ctypes.c_int * 6)()
+            took = bool(L.lib().tb_gemm8_last(last))
+            if bits == 39:
+                assert took and list(last)[:4] == [4, 2, 2, 5] and list(last)[5] == 4, list(last)
+            assert (Cbuf[:, :8] == 3).all() and (Cbuf[:, 8 + N:] == 3).all()
+            outs.append(out)
+    finally:
+        L.lib().tb_gemm8_set(prev)
+    ref = A.float() @ W.float().T + (b if bias else 0) + (R.float() if res else 0)
+    parity("128 x 160 one-per-CU Linear tile", outs[0], ref, rel=1e-3, maxabs=4e-3, ch_dim=1, ch_rel=2e-3)
+    assert rel_err(outs[0], outs[1]) < 3e-4
+
+
 @pytest.mark.parametrize("K,bias,res", [(5120, True, True), (10240, False, False)])
 def test_linear_long_k_two_slices_of_128x160_tiles(K, bias, res):
     """the 16x16-map long-K Linear layers (M = 2048, N = 1280: ff.net.2, the GEGLU-projection dgrad) as 16 x 8 tiles of 128 x 160 in two k-slices on the

@@ -1565,9 +1565,12 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
   // One 128 x 80 tile per CU with a 4-stage ring for the 16x16-map Linear layers (M = 2048, N = 1280: 16 x 16 tiles): their launches are bound by
   // the bytes that go through the L2 -> LDS path (scratch/lin_ablate.py, scratch/ubench/ldsdma_bw.hip: ~100 GB/s per CU whatever is in flight) --
   // 2.5 resident 64x64 tiles of the four-wave kernel move 820 KB per CU at K = 1280, this tile 532 KB
-  if (!(g8_enable & 2048) && !ln_act && (d.act == TB_ACT_NONE || d.act == TB_ACT_SILU) && d.N % 80 == 0 && d.M % 128 == 0 && d.K >= 640 && d.K <= ((g8_enable & 262144) ? 2560 : 3840)) {   // (3840: the 16x16-map qkv dgrad, K = 3 C; bit 262144 = 2560 as until round 5)
+  if (!(g8_enable & 2048) && !ln_act && (d.act == TB_ACT_NONE || d.act == TB_ACT_SILU) && d.N % 80 == 0 && d.M % 128 == 0 && d.K >= 640 && d.K <= ((g8_enable & 262144) ? 2560 : 5120)) {
+    // K limits (bit 262144 = 2560 for both, as until round 5): 3840 for the 128 x 80 tile (the 16x16-map qkv dgrad, K = 3 C: 50 -> 34 us; at
+    // K = 5120 the two-slice route below is the faster one there), 5120 for the 128 x 160 tile (the 32x32-map GEGLU-projection dgrad, 8192 x 640 x
+    // 5120, sat on 64 x 320 tiles of the 3-stage ring)
     const int64_t tiles = (d.M / 128) * (d.N / 80);
-    if (tiles >= 200 && tiles <= 256)   // (16384: the 8 x 1 waves of round 4 instead of 4 x 1 x 2 k-halves)
+    if (tiles >= 200 && tiles <= 256 && d.K <= 3840)   // (16384: the 8 x 1 waves of round 4 instead of 4 x 1 x 2 k-halves)
       return (g8_enable & 16384) ? launch8<8, 1, 1, 5, false, 4>(d, s, 30) : launch8<4, 1, 2, 5, false, 4, 0, 2>(d, s, 30);
     // ... and 128 x 160 for the 32x32-map layers (M = 8192, N = 640: 64 x 4 tiles; 369 KB per CU at K = 640 against 491 KB for the 64 x 320 tile)
     const int64_t tiles160 = d.N % 160 == 0 ? (d.M / 128) * (d.N / 160) : 0;
