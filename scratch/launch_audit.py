@@ -27,5 +27,5 @@ for ex, t, floor, fl, by, name in rows:
     k = (name, round(fl / 1e9, 1), round(by / 1e6, 1))
     agg[k][0] += 1; agg[k][1] += t; agg[k][2] += ex
 print(f"recorded launches {len(rows)}, total {sum(r[1] for r in rows)/1e3:.2f} ms, total excess {sum(r[0] for r in rows)/1e3:.2f} ms")
-for (name, gf, mb), (n, t, ex) in sorted(agg.items(), key=lambda kv: -kv[1][2])[:60]:
+for (name, gf, mb), (n, t, ex) in sorted(agg.items(), key=lambda kv: -kv[1][2])[:90]:
     print(f"{n:3d} x {t/n:7.1f} us  excess {ex:8.1f} us total  {gf:8.1f} GF {mb:7.1f} MB  ({gf/ (t/n) /1e3 if gf else 0:5.2f} PF/s, {mb/(t/n)/1e3:5.2f} TB/s)  {name}")

@@ -60,6 +60,9 @@ __device__ __forceinline__ void ff_wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef FF_DMAC
+#define FF_DMAC 1   // 0 (TB_CFLAGS=-DFF_DMAC=0): the tile's LDS-DMA pieces in front of phase A, as in round 4
+#endif
 #ifndef FF_PROF
 #define FF_PROF 0   // profiling build (TB_CFLAGS=-DFF_PROF=1): per-phase s_memtime sums of waves 0 and 4 of workgroup 0 -> tb_ff_debug buffer
 #endif
@@ -178,7 +181,14 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
         asm volatile("global_load_dwordx2 %0, %1, off offset:64" : "=v"(gin[i]) : "v"(src) : "memory");
       }
     }
-    issue_tile(tile + 1 < FF_NT ? tile + 1 : tile, slot ^ 1);   // (the last tile re-fetches itself into the free slot: never read, keeps the count at 8)
+    // (the last tile re-fetches itself into the free slot: never read, keeps the count at 8)
+    const int ntile = tile + 1 < FF_NT ? tile + 1 : tile;
+    const char* const wa_n = (const char*)p.W1 + ntile * a_tile_stride;
+    const char* const wb_n = (const char*)p.W2 + (int64_t)ntile * b_tile_stride;
+    const uint32_t dst_n = lds0 + (slot ^ 1) * FF_SLOT;
+    // FF_DMAC (round 5, as DMAC in gemm8.hip): the next tile's eight 1 KB LDS-DMA pieces go out as asm statements BETWEEN the MFMAs of phase A (one
+    // behind each of the first eight k-steps) instead of back to back in front of it, where every piece cost the wave 100 ... 185 issue cycles
+    if (!FF_DMAC) issue_tile(ntile, slot ^ 1);
     FF_SB();
 
     // ---------------------------------------------------------------- phase A
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
         for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc_a[a][i] = TB_MFMA_16x16x32(wf[ks % 3][a], xf[i][ks], acc_a[a][i]);
+        if constexpr (FF_DMAC && ks < 8) glds16_asm((d_isb[ks] ? wb_n : wa_n) + d_off[ks], dst_n + d_dst[ks]);
         FF_SB();
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});

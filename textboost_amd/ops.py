@@ -19,6 +19,7 @@ def _dt(t):
 # ---- optional per-launch timing (bench.py roofline leg): HIP events on torch's current stream, which is the stream every
 # kernel here is launched on.  Off by default; never active inside graph capture.
 _REC = None
+REC_SHAPES = os.environ.get("TB_REC_SHAPES", "0") == "1"   # launch records carry the GEMM shape (diagnostics)
 
 
 def start_recording():
@@ -280,6 +281,8 @@ def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_p
                 r.name = f"lin320_kernel<{'true' if R is not None else 'false'}>"
             else:
                 r.name = f"gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3] // 10}, {cfg[3] % 10}>"  # split-K launches: + its reducer
+            if REC_SHAPES:   # (scratch/launch_audit.py: which shape sat on which kernel)
+                r.name += f" [{M}x{N}x{d.K}{' conv' if conv is not None else ''} act {act}{' +R' if R is not None else ''}]"
     if split is not None and split.value > 1:
         return SplitKPartials(ws, split.value, (N + 7) // 8 * 8, bias, rowbias, R, out)
     return out
