@@ -96,7 +96,8 @@ typedef struct tb_gemm_desc {
    * normalised copy in memory.  The row statistics come from the launch that PRODUCES x:
    *   rs_out (producer): fp32 [M][rs_ld][2]; the launch writes, for its column tile tn, slot tn of row m = (sum, sum of squares) of the fp16-ROUNDED
    *          output row over the tile's columns.  8-wave Linear tiles only (act NONE, fp16 C; tb_gemm8_last tells the tile width = N / slots in use);
-   *          tb_gemm returns -22 when the launch would take another kernel.
+   *          tb_gemm returns -22 when the launch would take another kernel, when its column tiles do not fit a row of rs_out (> rs_ld), or
+   *          when rs_n > 0 and the launch would fill another number of slots than the rs_n its consumer is going to sum.
    *   rs_in  (consumer): the producer's rs_out with rs_n slots per row in use (row stride rs_ld slots).  Per row: mean = S / K, var = Q / K - mean^2
    *          (K = the LayerNorm width), rstd = rsqrt(var + ln_eps); epilogue v = rstd (alpha acc - mean ln_gamma[n]) + bias[n] (+ R) for act NONE,
    *          the same in front of the gate for GEGLU; ln_gamma = c1 (fp32 [N], in W's row order), bias = c2.  When ln_stats != NULL the column

@@ -146,28 +146,60 @@ class TrainState:
         with torch.no_grad():  # :1017 -- mean row norm over ALL rows, after token addition
             self.mean_norm = self.te.token_embedding.weight.norm(dim=-1).mean().item()
 
-    def step(self, x0, noise, timesteps, input_ids, prior_input_ids):
-        """One optimizer step on already-drawn noise/timesteps. Returns dict of scalars."""
+    def step(self, x0, noise, timesteps, input_ids, prior_input_ids, chunk=None):
+        """One optimizer step on already-drawn noise/timesteps. Returns dict of scalars.
+        chunk: evaluate the batch `chunk` samples at a time (samples are independent and both losses are means over the batch, so the
+        gradient is the sum of the chunks' gradients of `(n_chunk / B) * loss_chunk`): bounds host memory to a `chunk`-sample autograd
+        graph at the full-size shapes; the result then also carries `d_ehs`, the gradient w.r.t. the encoder hidden states (:1108)."""
         cfg, te = self.cfg, self.te
         noisy = add_noise(x0, noise, timesteps, self.acp)                          # :1052
-        ehs = te(input_ids)                                                         # :1054-1059
-        pred = self.unet(noisy, timesteps, ehs)                                     # :1063-1067
         target = noise if cfg.prediction_type == "epsilon" else get_velocity(x0, noise, timesteps, self.acp)
-        loss_mse = F.mse_loss(pred.float(), target.float(), reduction="none").mean()  # :1085-1090
-        loss = loss_mse
-        kp = torch.zeros(())
-        if cfg.kpl_weight > 0:                                                      # :1096-1106
-            h = te(prior_input_ids).float()
-            with torch.no_grad():
-                h0 = self.teacher(prior_input_ids).float()
-            if cfg.kpl_type == "cos":
-                kp = (1 - F.cosine_similarity(h, h0, dim=-1)).mean()
-            else:
-                kp = F.mse_loss(h, h0, reduction="mean")
-            loss = loss + cfg.kpl_weight * kp
         params = [te.token_embedding.weight] + self.lora + self.unet_lora
-        grads = list(torch.autograd.grad(loss, params, allow_unused=True))         # :1108
-        grads = [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
+        B = x0.shape[0]
+        d_ehs = None
+        if chunk:
+            grads = [torch.zeros_like(p) for p in params]
+            loss_mse, kp = torch.zeros(()), torch.zeros(())
+            ehs_l, pred_l, dehs_l = [], [], []
+            for b in range(0, B, chunk):
+                sl = slice(b, min(B, b + chunk))
+                w = (sl.stop - sl.start) / B
+                e_c = te(input_ids[sl])                                             # :1054-1059
+                p_c = self.unet(noisy[sl], timesteps[sl], e_c)                      # :1063-1067
+                m_c = F.mse_loss(p_c.float(), target[sl].float(), reduction="none").mean() * w
+                l_c = m_c
+                if cfg.kpl_weight > 0:                                              # :1096-1106
+                    h = te(prior_input_ids[sl]).float()
+                    with torch.no_grad():
+                        h0 = self.teacher(prior_input_ids[sl]).float()
+                    k_c = ((1 - F.cosine_similarity(h, h0, dim=-1)).mean() if cfg.kpl_type == "cos" else F.mse_loss(h, h0, reduction="mean")) * w
+                    l_c = l_c + cfg.kpl_weight * k_c
+                    kp = kp + k_c.detach()
+                gs = torch.autograd.grad(l_c, params + [e_c], allow_unused=True)    # :1108
+                for acc, g in zip(grads, gs[:-1]):
+                    if g is not None:
+                        acc.add_(g)
+                loss_mse = loss_mse + m_c.detach()
+                ehs_l.append(e_c.detach()); pred_l.append(p_c.detach()); dehs_l.append(gs[-1].detach())
+            ehs, pred, d_ehs = torch.cat(ehs_l), torch.cat(pred_l), torch.cat(dehs_l)
+            loss = loss_mse + cfg.kpl_weight * kp
+        else:
+            ehs = te(input_ids)                                                     # :1054-1059
+            pred = self.unet(noisy, timesteps, ehs)                                 # :1063-1067
+            loss_mse = F.mse_loss(pred.float(), target.float(), reduction="none").mean()  # :1085-1090
+            loss = loss_mse
+            kp = torch.zeros(())
+            if cfg.kpl_weight > 0:                                                  # :1096-1106
+                h = te(prior_input_ids).float()
+                with torch.no_grad():
+                    h0 = self.teacher(prior_input_ids).float()
+                if cfg.kpl_type == "cos":
+                    kp = (1 - F.cosine_similarity(h, h0, dim=-1)).mean()
+                else:
+                    kp = F.mse_loss(h, h0, reduction="mean")
+                loss = loss + cfg.kpl_weight * kp
+            grads = list(torch.autograd.grad(loss, params, allow_unused=True))     # :1108
+            grads = [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
         g_emb, g_lora, g_unet = grads[0], grads[1:1 + len(self.lora)], grads[1 + len(self.lora):]
         g_emb[: min(self.added)] = 0                                                # :1109-1117
         if cfg.mixing is not None:                                                  # :1119-1126
@@ -190,7 +222,7 @@ class TrainState:
             w[self.added] = (scale / vn) * rows
         return {"loss": loss.item(), "mse": loss_mse.item(), "kpl": float(kp.detach()), "lora_grad_norm": gnorm.item(),
                 "added_embedding_norm": vn.mean().item(), "ehs": ehs.detach(), "pred": pred.detach(),
-                "g_emb_added": g_emb[self.added].clone(), "g_lora": [g.clone() for g in g_lora], "g_unet": [g.clone() for g in g_unet]}
+                "g_emb_added": g_emb[self.added].clone(), "g_lora": [g.clone() for g in g_lora], "g_unet": [g.clone() for g in g_unet], "d_ehs": d_ehs}
 
 
 def make_teacher(te_before_tokens: TextBoostEncoder) -> TextBoostEncoder:

@@ -236,6 +236,49 @@ def test_bf16_full_step_runs_without_a_grad_scaler_and_matches_oracle():
         torch.testing.assert_close(a, b, rtol=0, atol=0)
 
 
+def test_vae_encoder_stays_on_the_fp16_build_in_a_bf16_run():
+    """train_textboost.py:938 keeps the VAE in fp32 in every --mixed_precision mode.  The device encoder multiplies 16-bit operands with fp32
+    accumulation; in a bf16 run it must not drop to 8 significand bits: HipVAEEncoder packs and runs on the fp16 library whatever the process's
+    active build is.  Latents against the fp32 oracle at the fp16 test's own bound (tests/test_gpu_vae.py: 5e-3 on this config), bit-equal to an
+    fp16-process encoder, and measurably better than what bf16 operands give (the same encoder forced onto the bf16 build)."""
+    from oracle.vae_encoder import VAEConfig, VAEEncoder
+    from textboost_amd import _lib as L
+    from textboost_amd import models
+    from textboost_amd.vae import HipVAEEncoder, VAEGeometry, vae_encoder_shapes
+    assert L.half_kind() == "bf16"
+    geo = VAEGeometry(block_out_channels=(64, 64, 128, 128), layers_per_block=1)
+    B, H, W = 2, 64, 64
+    sd = models.random_state_dict(vae_encoder_shapes(geo), 5, device="cpu")
+    sd = {k: v.half().float() for k, v in sd.items()}
+    with torch.device("meta"):
+        ref = VAEEncoder(VAEConfig.tiny())
+    ref = ref.to_empty(device="cpu")
+    ref.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    eps = torch.randn(B, 4, H // 8, W // 8, generator=g)
+    with torch.no_grad():
+        z_ref = ref.encode_sample(x, noise=eps)
+    dsd = {k: v.to(dev) for k, v in sd.items()}
+    enc = HipVAEEncoder(geo, dsd, B, H, W, device=dev)
+    assert enc.half == "fp16" and all(t.dtype != BF for t in enc.P.values())
+    z = enc.encode(x.to(dev), noise=eps.to(dev)).clone()
+    assert L.half_kind() == "bf16"                       # the switch is scoped to the encoder's own calls
+    e16 = rel_err(z, z_ref)
+    with L.use_half("fp16"):
+        z16 = HipVAEEncoder(geo, dsd, B, H, W, device=dev).encode(x.to(dev), noise=eps.to(dev)).clone()
+    assert torch.equal(z, z16)
+    forced = HipVAEEncoder.__new__(HipVAEEncoder)        # the bf16-operand encoder this replaces (round 5's behaviour), for the comparison only
+    forced.half = None
+    nd = len(geo.block_out_channels) - 1
+    forced.geo, forced.B, forced.H, forced.W, forced.dev, forced.dtype, forced._bufs, forced.generator = geo, B, H, W, dev, torch.float32, {}, None
+    forced._pack(dsd)
+    forced.gn_ws = torch.empty((2048 + 2 * B) * geo.norm_num_groups * 2, device=dev, dtype=torch.float32)
+    ebf = rel_err(forced.encode(x.to(dev), noise=eps.to(dev)), z_ref)
+    print(f"[parity] VAE latents in a bf16 run: fp16-build encoder {e16:.3e} vs the fp32 oracle (bf16 operands would give {ebf:.3e})")
+    assert e16 < 5e-3 and ebf > 2 * e16
+
+
 def test_bf16_cli_end_to_end(tmp_path):
     """`--mixed_precision bf16` through the CLI (synthetic latents, the full SD1.5 shapes at 16x16 latents): the reference output layout, no loss
     scaling, finite weights."""

@@ -543,6 +543,14 @@ def test_unet_crossattn_kv_lora_step_matches_oracle(tmp_path):
     hip_unet.kv_lora_A.zero_(); hip_unet.kv_lora_B.zero_()
     ckpt.load_unet_peft_adapter_state_dict(hip_unet, {k: v.cuda() for k, v in sd.items()})
     assert torch.equal(hip_unet.kv_lora_A, A0) and torch.equal(hip_unet.kv_lora_B, B0)
+    #  the in-model layout of earlier rounds' files still loads; a mangled / foreign layout is refused by name, not by a later KeyError
+    old_layout = {k[len("base_model.model."):].replace(".weight", ".default.weight"): v.cuda() for k, v in sd.items()}
+    hip_unet.kv_lora_A.zero_(); hip_unet.kv_lora_B.zero_()
+    ckpt.load_unet_peft_adapter_state_dict(hip_unet, old_layout)
+    assert torch.equal(hip_unet.kv_lora_A, A0) and torch.equal(hip_unet.kv_lora_B, B0)
+    for bad in ({"unet." + k: v for k, v in sd.items()}, {k.replace(".weight", ".default.weight"): v for k, v in sd.items()}):
+        with pytest.raises(KeyError, match="adapter"):
+            ckpt.load_unet_peft_adapter_state_dict(hip_unet, bad)
     import json
     cfg = json.load(open(tmp_path / "unet" / "adapter_config.json"))
     assert set(cfg) == set(ckpt.adapter_config(r, "base"))   # a pure LoraConfig: no extra keys

@@ -269,22 +269,27 @@ def test_step_invariants_at_batch_16():
 
 def test_sd15_full_step_at_the_metric_batch_vs_oracle():
     """BASELINE.json configs[1], the benchmarked launches themselves (B=8 tiles, split-K factors, XCD remaps, the hd = 40 attention
-    backward): ONE full-size forward + backward of the step's differentiable chain -- trainable CLIP-L (LoRA r=4, added rows) -> fp16
-    hidden states -> SD1.5 UNet forward -> UNet dgrad backward -> d(ehs) -> CLIP-L backward -> LoRA A / B and added-row gradients
-    (train_textboost.py:1054-1067, :1108) -- against the fp32 oracle, plus the frozen KPL teacher rows that ride in the student's launches
-    (:1096-1100).  The oracle runs the 8 samples one at a time (samples are independent; parameter gradients accumulate), which bounds
-    its memory to a B=1 autograd graph.  Tolerances: the existing full-size ones for pred / d_ehs; gradients that went through BOTH
-    networks 4e-3 / 6e-3 / 1e-2 (the small-config whole-step bound)."""
+    backward) driven by the REAL step object: TWO optimizer steps of `TextBoostStep` (train_textboost.py:1040-1149) at full size -- trainable
+    CLIP-L (LoRA r=4, added rows) + the KPL prior / teacher rows -> fp16 hidden states -> SD1.5 UNet -> MSE -> dgrad backward -> d(ehs) ->
+    CLIP-L backward -> masks, GradScaler, clip, AdamW (both groups), row decay, renorm -- against the fp32 oracle's `TrainState`.
+    Step 1 checks every intermediate (prediction and d(ehs) per sample, losses, gradients); after BOTH steps the updated parameters are compared
+    ELEMENTWISE: LoRA A / B, the added token rows, the decay-only rows (north_star: "token-embedding/LoRA weight updates are compared
+    elementwise"; tolerances of the small-config test, tests/test_gpu_model.py::test_full_step_matches_oracle_elementwise).
+    The oracle evaluates the batch two samples at a time (TrainState.step(chunk=2): samples are independent, the losses are batch means),
+    which bounds its memory to a B=2 autograd graph -- TB_TEST_ORACLE_CHUNK to change.
+    Then the two KPL teachers at full size (:939, :1096-1100): the default one (teacher rows riding in the student's launches, autocast
+    arithmetic) and the reference's plain fp16 module (TB_SEPARATE_TEACHER=1) against the fp32 oracle and against each other, hidden states
+    and KPL loss."""
     from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
     from oracle import train_step as ts
     from oracle.unet_sd import UNetConfig
-    from textboost_amd import models
+    from textboost_amd import _lib as L
+    from textboost_amd import models, ops
     from textboost_amd.text_encoder import HipTextEncoder
+    from textboost_amd.trainer import StepHyper, TextBoostStep
     torch.manual_seed(0)
     B, T, D = 8, 77, 768
     ref_unet, hip_unet = _full_unet_pair(models.SD15_UNET, UNetConfig.sd15(), 83, B, 64)
-    for p in ref_unet.parameters():
-        p.requires_grad_(False)                      # frozen (:696): dgrad only, like the product
     csd = models.random_state_dict(models.clip_shapes(models.SD15_CLIP), 84, device="cpu")
     base = TextBoostEncoder(CLIPTextCfg.sd15(), r=0)
     base.load_hf_state_dict(csd)
@@ -293,10 +298,11 @@ def test_sd15_full_step_at_the_metric_batch_vs_oracle():
     with torch.no_grad():
         for n, p in ref.named_parameters():
             if "lora_B" in n:
-                p.normal_(std=0.02)
+                p.normal_(std=0.02)                 # (peft starts B at zero: then dA = 0 at step 1 -- non-zero exercises every path twice)
         null = base.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
     ref.set_null_embedding(null)
     base.set_null_embedding(null)
+    teacher = ts.make_teacher(base)
     added = add_tokens(ref, [11, 22, 33])
     hip = HipTextEncoder(models.SD15_CLIP, csd, B, mode="autocast", lora_rank=4, n_slots=2, device=dev, seed=0)
     hip.set_null_embedding(null)
@@ -304,55 +310,103 @@ def test_sd15_full_step_at_the_metric_batch_vs_oracle():
     for i, layer in enumerate(ref.layers):
         hip.lora_A[i].copy_(torch.cat([layer.q.lora_A, layer.k.lora_A, layer.v.lora_A]).detach())
         hip.lora_B[i].copy_(torch.cat([layer.q.lora_B, layer.k.lora_B, layer.v.lora_B]).detach())
-    g = torch.Generator().manual_seed(6)
-    ids = ts.synthetic_ids(B, added, g)
-    pids = ts.synthetic_ids(B, added, g, prior=True)
-    pids[2, 1:] = 49407                              # one null prior prompt (--null_prob): pinned rows
-    x = torch.randn(B, 4, 64, 64, generator=g).half().float()
-    t = torch.tensor([999, 0, 611, 250, 17, 801, 500, 333])
-    dpred = torch.randn(B, 4, 64, 64, generator=g)
-    # ---- oracle, a few samples at a time (independent samples, accumulated parameter gradients; 2 per pass = two B=1 autograd graphs of host
-    # memory and ~25 % less CPU time than one at a time -- TB_TEST_ORACLE_CHUNK to change)
-    preds, dehs = [], []
+    hip_teacher = HipTextEncoder(models.SD15_CLIP, csd, B, mode="half", lora_rank=0, device=dev)
+    hip_teacher.set_null_embedding(null)
+    st_ref = ts.TrainState(ref, teacher, ref_unet, added, ts.StepConfig())
+    step = TextBoostStep(hip_unet, hip, hip_teacher, StepHyper(), (B, 4, 64, 64), device=dev)
+    step.external_noise = True
+    assert step.merge_teacher and abs(step.mean_norm - st_ref.mean_norm) < 1e-4 * st_ref.mean_norm
+    seen = {}
+    enc_bwd = step._phase_encoder_backward
+
+    def keep_d_ehs():   # (the encoder backward zeroes the pinned rows of its input in place: copy d(ehs) as the UNet backward delivered it)
+        seen["d_ehs"] = step.d_ehs.clone()
+        enc_bwd()
+    step._phase_encoder_backward = keep_d_ehs
     CH = int(os.environ.get("TB_TEST_ORACLE_CHUNK", "2"))
-    for b in range(0, B, CH):
-        h = ref(ids[b:b + CH])
-        h.retain_grad()
-        p = ref_unet(x[b:b + CH], t[b:b + CH], h)
-        (p * dpred[b:b + CH]).sum().backward()
-        preds.append(p.detach())
-        dehs.append(h.grad.detach())
-    pred_ref, dehs_ref = torch.cat(preds), torch.cat(dehs)
-    gA = torch.stack([torch.cat([l.q.lora_A.grad, l.k.lora_A.grad, l.v.lora_A.grad]) for l in ref.layers])
-    gB = torch.stack([torch.cat([l.q.lora_B.grad, l.k.lora_B.grad, l.v.lora_B.grad]) for l in ref.layers])
-    gE = ref.token_embedding.weight.grad[added]
+    g = torch.Generator().manual_seed(6)
+    w0 = ref.token_embedding.weight.detach().clone()
+    A0 = torch.stack([torch.cat([l.q.lora_A, l.k.lora_A, l.v.lora_A]) for l in ref.layers]).detach().clone()
+    B0 = torch.stack([torch.cat([l.q.lora_B, l.k.lora_B, l.v.lora_B]) for l in ref.layers]).detach().clone()
+    for it in range(2):
+        ids = ts.synthetic_ids(B, added, g)
+        pids = ts.synthetic_ids(B, added, g, prior=True)
+        if it == 0:
+            pids[2, 1:] = 49407                          # one null prior prompt (--null_prob): pinned rows
+        x0 = torch.randn(B, 4, 64, 64, generator=g)
+        noise = torch.randn(B, 4, 64, 64, generator=g)
+        t = torch.tensor([999, 0, 611, 250, 17, 801, 500, 333]) if it == 0 else torch.randint(0, 1000, (B,), generator=g)
+        out = st_ref.step(x0, noise, t, ids, pids, chunk=CH)
+        step.x0.copy_(x0); step.noise.copy_(noise); step.timesteps.copy_(t)
+        step.input_ids.copy_(ids); step.prior_ids.copy_(pids)
+        step.step_eager()
+        torch.cuda.synchronize()
+        sc = step.scalars()
+        assert sc["found_inf"] == 0.0 and sc["opt_steps"] == float(it + 1) and sc["loss_scale"] == 65536.0, sc
+        print(f"[parity] B=8 step {it}: mse {sc['loss_mse']:.6f} (oracle {out['mse']:.6f})  kpl {sc['loss_kpl']:.6e} (oracle {out['kpl']:.6e})  "
+              f"grad norm {sc['grad_norm']:.5e} (oracle {out['lora_grad_norm']:.5e})")
+        assert abs(sc["loss_mse"] - out["mse"]) < 1e-2 * abs(out["mse"]), (sc, out["mse"])
+        assert abs(sc["loss_kpl"] - out["kpl"]) < 5e-2 * abs(out["kpl"]) + 1e-5, (sc, out["kpl"])
+        assert abs(sc["grad_norm"] - out["lora_grad_norm"]) < 2e-2 * out["lora_grad_norm"]
+        inv = 1.0 / 65536.0
+        if it == 0:   # every intermediate of the differentiable chain, no sample hiding behind the others (each has its own timestep)
+            parity("B=8 step: UNet pred", step.pred, out["pred"], rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
+            d_ehs = seen["d_ehs"].view(B, T, D) * inv
+            parity("B=8 step: d_ehs", d_ehs, out["d_ehs"], rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
+            for b in range(B):
+                parity(f"  pred sample {b} (t={int(t[b])})", step.pred[b], out["pred"][b], rel=3e-3, maxabs=5e-3, verbose=False)
+                parity(f"  d_ehs sample {b}", d_ehs[b], out["d_ehs"][b], rel=6e-3, maxabs=8e-3, verbose=False)
+            nb = step.ids_all.shape[0]
+            assert torch.equal(step.h_teacher.view(B, T, D)[2].cpu(), null)       # the null prior prompt of the teacher rows: pinned, bit-exact
+        # gradients (the flat buffer holds loss_scale * grad; the oracle's LoRA gradients are post-clip)
+        nl = len(ref.layers)
+        gA = torch.stack([torch.cat(out["g_lora"][6 * l + 0: 6 * l + 6: 2]) for l in range(nl)])
+        gB = torch.stack([torch.cat(out["g_lora"][6 * l + 1: 6 * l + 6: 2]) for l in range(nl)])
+        clip = min(1.0, 1.0 / (out["lora_grad_norm"] + 1e-6))
+        parity(f"B=8 step {it}: grad lora_A", step.te.grad_A * inv * clip, gA, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+        parity(f"B=8 step {it}: grad lora_B", step.te.grad_B * inv * clip, gB, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+        parity(f"B=8 step {it}: grad added rows", step.te.grad_added * inv, out["g_emb_added"], rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+        # ---- the parameters after the update, ELEMENTWISE (the optimizer tail :1128-1149 at full size)
+        w, wr = step.te.token_table.cpu(), ref.token_embedding.weight.detach()
+        torch.testing.assert_close(w[:49408], wr[:49408], rtol=1e-6, atol=1e-7)                       # decay-only rows
+        assert (w[added] - wr[added]).abs().max().item() < 2.5e-3                                     # <= ~2 * emb_lr (Adam step-1 sign flips)
+        assert rel_err(w[added], wr[added]) < 2e-3
+        A_ref = torch.stack([torch.cat([l.q.lora_A, l.k.lora_A, l.v.lora_A]) for l in ref.layers]).detach()
+        B_ref = torch.stack([torch.cat([l.q.lora_B, l.k.lora_B, l.v.lora_B]) for l in ref.layers]).detach()
+        A_hip, B_hip = step.te.lora_A.cpu(), step.te.lora_B.cpu()
+        assert (A_hip - A_ref).abs().max().item() < 1.5e-4 and (B_hip - B_ref).abs().max().item() < 1.5e-4      # <= ~2 * lr
+        # the MOVES themselves: Adam's first steps are ~lr * sign(g), so an element whose gradient is inside the fp16 path's noise can flip --
+        # the update vectors as a whole must still point the oracle's way (measured: see the printed values)
+        dA, dB, dE = rel_err(A_hip - A0, A_ref - A0), rel_err(B_hip - B0, B_ref - B0), rel_err(w[added] - w0[added], wr[added] - w0[added])
+        print(f"[parity] B=8 after step {it}: rel-L2 of the parameter MOVES  lora_A {dA:.3e}  lora_B {dB:.3e}  added rows {dE:.3e};  "
+              f"max |param - oracle| lora_A {(A_hip - A_ref).abs().max().item():.2e} lora_B {(B_hip - B_ref).abs().max().item():.2e} "
+              f"added {(w[added] - wr[added]).abs().max().item():.2e}")
+        assert dA < 8e-2 and dB < 8e-2 and dE < 2e-2      # measured 2.5e-2 / 3.9e-2 / 4.8e-4 after step 1, 1.4e-2 / 2.1e-2 / 2.6e-3 after step 2
+    assert step.scalars()["opt_steps"] == 2.0
+    # ---- the two teachers (frozen encoder on the prior prompts, :939 / :1096-1100) at full size
+    pids_d = step.prior_ids
     with torch.no_grad():
-        teacher_ref = base(pids)
-    # ---- HIP path: the step's own call sequence (trainer._phase_student / _phase_unet_* / _phase_encoder_backward)
-    from textboost_amd import ops
+        t_ref = teacher(pids.clone())
+        h_ref = ref(pids.clone()).float()
+        kpl_ref = (1 - torch.nn.functional.cosine_similarity(h_ref, t_ref.float(), dim=-1)).mean().item()
     hip.pack_lora()
-    table0 = torch.empty(49408, D)
-    table0.copy_(csd["text_model.embeddings.token_embedding.weight"])
-    out = hip.forward(ids.to(dev), slot=0, extra_ids=pids.to(dev), extra_table=table0.to(dev))
-    h_hip, h_teacher = out[:B * T], out[B * T:]
-    parity("B=8 teacher rows inside the student pass (CLIP-L)", h_teacher.view(B, T, D), teacher_ref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-2)
-    assert torch.equal(h_teacher.view(B, T, D)[2].cpu(), null)
-    ehs16 = torch.empty(B * T, D, device=dev, dtype=torch.float16)
-    ops.convert(h_hip, ehs16)
-    pred = hip_unet.forward(x.half().to(dev), t.to(dev), ehs16)
-    parity("B=8 step: UNet pred", pred, pred_ref, rel=3e-3, maxabs=4e-3, ch_dim=1, ch_rel=4e-3)
-    for b in range(B):  # no sample may hide behind the others (every sample has its own timestep); this is also the round-2 "UNet forward at the
-        # metric batch" check -- same launches, folded into this test so that the suite builds ONE full-size B=8 CPU oracle pass, not two
-        parity(f"  pred sample {b} (t={int(t[b])})", pred[b], pred_ref[b], rel=3e-3, maxabs=5e-3, verbose=False)
-    d_ehs = hip_unet.backward(dpred.to(dev))
-    parity("B=8 step: d_ehs", d_ehs.view(B, T, D), dehs_ref, rel=5e-3, maxabs=6e-3, ch_dim=2, ch_rel=3e-2)
-    for b in range(B):  # no sample may hide behind the others
-        parity(f"  d_ehs sample {b}", d_ehs.view(B, T, D)[b], dehs_ref[b], rel=6e-3, maxabs=8e-3, verbose=False)
-    hip.zero_grad()
-    hip.backward(d_ehs.float().contiguous(), slot=0)
-    parity("B=8 step: grad lora_A", hip.grad_A, gA, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
-    parity("B=8 step: grad lora_B", hip.grad_B, gB, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
-    parity("B=8 step: grad added rows", hip.grad_added, gE, rel=4e-3, maxabs=6e-3, ch_dim=0, ch_rel=1e-2)
+    out_m = hip.forward(step.ids_all, slot=0, extra_ids=pids_d, extra_table=step.teacher_table32)
+    nb = step.ids_all.shape[0]
+    h_prior, h_merged = out_m[B * T:nb * T], out_m[nb * T:]
+    h_sep = hip_teacher.forward(pids_d, slot=0)
+    parity("teacher rows inside the student pass (default) vs fp32 oracle", h_merged.view(B, T, D), t_ref, rel=2e-3, maxabs=4e-3, ch_dim=2, ch_rel=3e-2)
+    parity("separate fp16 teacher module (TB_SEPARATE_TEACHER=1, the reference's :939) vs fp32 oracle", h_sep.view(B, T, D), t_ref, rel=3e-3,
+           maxabs=6e-3)                                  # measured 1.3e-3 / 2.4e-3 (the merged rows: 7.8e-4 / 1.0e-3)
+    parity("merged teacher vs separate fp16 teacher", h_merged.view(B, T, D), h_sep.view(B, T, D), rel=3e-3, maxabs=6e-3)   # measured 1.2e-3 / 2.6e-3
+    kl = []
+    for h0 in (h_merged, h_sep):
+        stt = torch.zeros(L.ST_COUNT, device=dev)
+        stt[L.ST_LOSS_SCALE] = 1.0
+        ops.kpl_cos(h_prior, h0, torch.empty(B * T, D, device=dev), torch.empty(B * T, device=dev), stt[L.ST_LOSS_KPL:], stt[L.ST_LOSS_SCALE:], 0.1)
+        kl.append(stt[L.ST_LOSS_KPL].item())
+    print(f"[parity] KPL loss at full size: merged teacher {kl[0]:.6e}, separate fp16 teacher {kl[1]:.6e}, fp32 oracle {kpl_ref:.6e}")
+    # measured: 2.528434e-01 / 2.528739e-01 / 2.528545e-01 -- the benchmarked (merged) teacher is the CLOSER one to the fp32 oracle
+    assert abs(kl[0] - kpl_ref) < 1e-3 * kpl_ref and abs(kl[1] - kpl_ref) < 2e-3 * kpl_ref and abs(kl[0] - kl[1]) < 2e-3 * kpl_ref
 
 
 def test_sd21_full_step_chain_at_96x96_vs_oracle():

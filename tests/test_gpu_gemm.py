@@ -958,3 +958,44 @@ def test_layernorm_folded_into_the_consuming_linear(M, C):
     # requests the tiles cannot serve are refused
     with pytest.raises(RuntimeError):
         ops.gemm(o[:512], Wo, x[:512], bias=bo, R=R[:512], rs_out=rs[:512].contiguous())      # 4 row tiles: not an 8-wave one-per-CU launch
+
+
+@pytest.mark.parametrize("M,C", [(8192, 640), (2048, 1280)])
+def test_layernorm_fold_with_a_large_row_mean_and_its_refusals(M, C):
+    """ The folded LayerNorm takes the row variance as E[x^2] - mean^2 in fp32 from the producer's tile sums and multiplies the RAW
+    stream: a residual stream whose row mean is ~50 standard deviations (the regime where a one-pass variance loses digits) must still match
+    torch's LayerNorm -> Linear.  And the protocol's refusals: a producer whose column tiles would fill another slot count than its consumer sums,
+    or more slots than a statistics row holds (tb_gemm8.hip launch8); a consumer while a profiling knob has its lean epilogue off (gemm.hip)."""
+    ops, L = _ops()
+    torch.manual_seed(43)
+    slots = ops.lnfold_slots(M, C)
+    o = torch.randn(M, C, device="cuda").half()
+    Wo = (torch.randn(C, C, device="cuda") / C ** 0.5).half()
+    R = (50.0 + 0.1 * torch.randn(M, 1, device="cuda")).expand(M, C).half()          # row mean ~50, row std ~1
+    gamma, beta = 1 + 0.5 * torch.randn(C, device="cuda"), 0.3 * torch.randn(C, device="cuda")
+    x = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    rs = torch.zeros(M, 16, 2, device="cuda")
+    ops.gemm(o, Wo, x, R=R, rs_out=rs, rs_slots=slots)
+    xf = x.float()
+    assert 30 < (xf.mean(1).abs() / xf.std(1)).median().item() < 80
+    ln_ref = F.layer_norm(xf.double(), (C,), gamma.double(), beta.double(), 1e-5).float()
+    W = (torch.randn(3 * C, C, device="cuda") / C ** 0.5).half()
+    Wp, c1, c2 = ops.fold_layernorm(W, gamma, beta, None)
+    out = torch.empty(M, 3 * C, device="cuda", dtype=torch.float16)
+    st = torch.zeros(M, 2, device="cuda")
+    ops.gemm(x, Wp, out, bias=c2, lnfold=(rs, slots, c1, st, 1e-5))
+    parity(f"folded LN -> Linear, row mean / std ~ 50, {M}x{3 * C}x{C}", out, ln_ref @ W.float().T, rel=3e-3, maxabs=6e-3, ch_dim=1, ch_rel=4e-3)
+    rstd_ref = (xf.double().var(1, unbiased=False) + 1e-5).rsqrt().float()
+    assert torch.allclose(st[:, 1], rstd_ref, rtol=2e-3, atol=0) and torch.allclose(st[:, 0], xf.mean(1), rtol=1e-5, atol=1e-3)
+    # ---- refusals
+    with pytest.raises(RuntimeError):
+        ops.gemm(o, Wo, x, R=R, rs_out=rs, rs_slots=slots + 1)                      # the consumer would sum another number of slots
+    with pytest.raises(RuntimeError):
+        ops.gemm(o, Wo, x, R=R, rs_out=torch.zeros(M, slots - 1, 2, device="cuda"))  # a statistics row narrower than the tile grid
+    L.lib().tb_gemm_set_variant(2000 + 8)                                            # profiling knob: the 4-wave kernels' lean epilogue off
+    try:
+        if C == 1280:   # (the 16x16-map qkv projection is the consumer that runs on the 4-wave tiles)
+            with pytest.raises(RuntimeError):
+                ops.gemm(x, Wp, out, bias=c2, lnfold=(rs, slots, c1, st, 1e-5))
+    finally:
+        L.lib().tb_gemm_set_variant(2000)                                            # (2000 + bits: all profiling bits off again)

@@ -292,3 +292,15 @@ def test_layernorm_epilogue_query_follows_the_row_spanning_tiles():
     assert not ok(4096, 320, 320) and not ok(199 * 64, 320, 320)                                 # less than one round: B = 1
     assert not ok(8 * 1024, 640, 640) and not ok(8 * 4096, 160, 320)                             # no tile spans N = 640; N must be 320
     assert not ok(8 * 4096, 320, 100) and not ok(8 * 4096 + 8, 320, 320)                         # K % 64, ragged M
+
+
+def test_bench_classifies_every_recorded_kernel_family():
+    """`roofline.classes` (bench.py): every launch record of the eager leg falls into conv / linear / attention / norm by its rocprofv3 symbol."""
+    b = _bench()
+    want = {"gemm8_kernel<4, 2, 4, 5, true, 3>": "conv", "gemm8_kernel<8, 1, 2, 5, true, 4>": "conv", "conv_halo_kernel<128>": "conv",
+            "gemm_kernel<128, 128, 1, 64, 2>": "conv", "gemm8_kernel<4, 2, 2, 5, false, 4>": "linear", "gemm_kernel<64, 64, 0, 64, 4>": "linear",
+            "lin320_kernel<true>": "linear", "ff_fused_kernel<false>": "linear", "gemm_f32_kernel": "linear", "attn_fwd_kernel": "attention",
+            "attn_bwd(delta+dq+dkv)": "attention", "groupnorm_fwd(splitk)": "norm", "groupnorm_bwd(stats+apply)": "norm",
+            "layernorm_fwd": "norm", "layernorm_bwd": "norm"}
+    for name, cls in want.items():
+        assert b.kernel_class(name) == cls, name

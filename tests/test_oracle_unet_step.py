@@ -139,6 +139,49 @@ def test_full_step_tiny_runs_and_respects_masks():
     assert any(p.abs().max() > 0 for n, p in te_l.named_parameters() if "lora_B" in n)
 
 
+def test_chunked_step_equals_the_whole_batch_step():
+    """TrainState.step(chunk=n) -- the batch evaluated n samples at a time, gradients of (n / B) * loss_chunk summed (how the full-size
+    `-m gpu` tests bound the oracle's host memory) -- is the same optimizer step as the whole-batch evaluation: losses, gradients, updated
+    parameters; and it reports the gradient w.r.t. the encoder hidden states."""
+    import copy
+    from oracle.clip_text import CLIPTextCfg, TextBoostEncoder, add_tokens
+    torch.manual_seed(0)
+    ccfg = CLIPTextCfg.tiny(64)
+    te = TextBoostEncoder(ccfg, r=0)
+    with torch.no_grad():
+        null = te.transformer(torch.tensor([[49406] + [49407] * 76]))[0]
+    te.set_null_embedding(null)
+    teacher = ts.make_teacher(te)
+    te_l = TextBoostEncoder(ccfg, r=4)
+    te_l.load_state_dict(te.state_dict(), strict=False)
+    te_l.set_null_embedding(null)
+    with torch.no_grad():
+        for n, p in te_l.named_parameters():
+            if "lora_B" in n:
+                p.normal_(std=0.05)
+    added = add_tokens(te_l, [100, 200, 300])
+    unet = UNet2DCondition(UNetConfig.tiny(64))
+    st_a = ts.TrainState(te_l, teacher, unet, added, ts.StepConfig())
+    st_b = ts.TrainState(copy.deepcopy(te_l), teacher, unet, added, ts.StepConfig())
+    g = torch.Generator().manual_seed(1)
+    B = 3
+    for _ in range(2):
+        ids, pids = ts.synthetic_ids(B, added, g), ts.synthetic_ids(B, added, g, prior=True)
+        x0, noise = torch.randn(B, 4, 16, 16, generator=g), torch.randn(B, 4, 16, 16, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        a = st_a.step(x0, noise, t, ids, pids)
+        b = st_b.step(x0, noise, t, ids, pids, chunk=2)   # chunks of 2 + 1 samples
+        assert a["d_ehs"] is None and b["d_ehs"].shape == (B, 77, 64)
+        for k in ("loss", "mse", "kpl", "lora_grad_norm"):
+            assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-7, (k, a[k], b[k])
+        torch.testing.assert_close(b["pred"], a["pred"], rtol=1e-5, atol=1e-5)   # (fp32 BLAS summation order changes with the batch size)
+        torch.testing.assert_close(b["g_emb_added"], a["g_emb_added"], rtol=1e-4, atol=1e-6)
+        for ga, gb in zip(a["g_lora"], b["g_lora"]):
+            torch.testing.assert_close(gb, ga, rtol=1e-4, atol=1e-6)
+    for pa, pb in zip(st_a.te.parameters(), st_b.te.parameters()):
+        torch.testing.assert_close(pb, pa, rtol=1e-5, atol=1e-6)
+
+
 def test_attention_block_equals_torch_sdpa_at_sd_dims():
     """diffusers AttnProcessor2_0 calls F.scaled_dot_product_attention (no mask, default scale hd^-0.5): the oracle's explicit
     softmax(QK^T / sqrt(hd)) V must equal the INSTALLED torch SDPA at the SD1.x head geometry (8 heads of 40 / 80 / 160) for self- and

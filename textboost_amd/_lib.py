@@ -2,6 +2,7 @@
 there is no CPU / eager fallback in the product path."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 
@@ -194,6 +195,20 @@ def set_half(kind: str):
     prev, _half = _half, kind
     _lib = _libs.get(kind)
     return prev
+
+
+@contextlib.contextmanager
+def use_half(kind: str):
+    """run a block on the other build of the library (host-side dispatch only: every op looks `lib()` up when it is called, so this also
+    works while a HIP graph is being captured).  The VAE encoder uses it to stay on the fp16 build in a bf16 run (vae.py)."""
+    if kind is None:   # "whatever the process runs"
+        yield
+        return
+    prev = set_half(kind)
+    try:
+        yield
+    finally:
+        set_half(prev)
 
 
 def half_kind() -> str:

@@ -76,14 +76,29 @@ def unet_peft_adapter_state_dict(unet) -> Dict[str, torch.Tensor]:
 
 
 def load_unet_peft_adapter_state_dict(unet, sd):
-    load_unet_lora_state_dict(unet, {k[len("base_model.model."):].replace(".weight", ".default.weight"): v for k, v in sd.items()})
+    """accepts peft's adapter layout (`base_model.model.<param>.lora_{A,B}.weight`, what `save_unet_adapters` writes since round 5) and the
+    in-model layout of earlier rounds' files (`<param>.lora_{A,B}.default.weight`, no prefix); anything else is refused by name."""
+    pre = "base_model.model."
+    keys = list(sd)
+    if keys and all(k.startswith(pre) for k in keys):
+        bad = [k for k in keys if ".default." in k or not k.endswith((".lora_A.weight", ".lora_B.weight"))]
+        if bad:
+            raise KeyError(f"not a peft adapter key (expected '{pre}<param>.lora_A|lora_B.weight'): {bad[0]}")
+        sd = {k[len(pre):-len(".weight")] + ".default.weight": v for k, v in sd.items()}
+    elif keys and all(k.endswith((".lora_A.default.weight", ".lora_B.default.weight")) for k in keys):
+        pass   # the in-model layout
+    else:
+        bad = next(k for k in keys if not k.startswith(pre)) if keys else "<empty state dict>"
+        raise KeyError(f"unrecognised UNet adapter layout (neither peft's '{pre}...lora_A.weight' nor '...lora_A.default.weight'): {bad}")
+    load_unet_lora_state_dict(unet, sd)
 
 
 def save_unet_adapters(unet, out_dir: str, base_model_name_or_path: str):
     """<out>/unet/ (:1237-1239).  The reference's `unet.save_pretrained` writes the WHOLE fp32 UNet (3.4 GB: the frozen base weights under
     `.base_layer.` names plus the adapters); no reader of the output layout loads it (inference.py / eval_dreambooth.py never open unet/).
     Written here in peft's adapter layout, so that the file name does not promise a loadable diffusers model: `adapter_model.safetensors` (the
-    adapter tensors under the parameter names `unet.add_adapter` gives them) + `adapter_config.json` naming the base model whose weights are unchanged."""
+    adapter tensors under peft's adapter keys, `unet_peft_adapter_state_dict`: `base_model.model.<module path>.lora_{A,B}.weight`) +
+    `adapter_config.json` naming the base model whose weights are unchanged + a README.txt saying so."""
     os.makedirs(out_dir, exist_ok=True)
     save_file(unet_peft_adapter_state_dict(unet), os.path.join(out_dir, "adapter_model.safetensors"), metadata={"format": "pt"})
     cfg = adapter_config(unet.kv_r, base_model_name_or_path)          # a pure peft LoraConfig: LoraConfig(**json) must accept every key

@@ -1317,6 +1317,9 @@ extern "C" int tb_gemm(const tb_gemm_desc* dp, tb_stream_t stream) {
         (d.R && (d.ldr % 8 || ((uintptr_t)d.R) % 16)) || d.N % 8 || !d.ln_gamma || d.rs_n < 1 || d.rs_n > 16 || d.rs_ld < d.rs_n ||
         ((uintptr_t)d.rs_in) % 8 || ((uintptr_t)d.ln_stats) % 8)
       return TB_EINVAL;
+    // the fold lives in the lean (`fast`) branch of tile_epilogue only; the conditions above imply it unless a profiling knob switches that branch
+    // or whole phases off (tb_gemm_set_variant(2000 + bits)): refuse rather than store un-normalised x W'^T + c2
+    if (g_ablate) return TB_EINVAL;
     d.ws = nullptr, d.ws_bytes = 0;   // never split K: the reducer does not know the fold
   }
   // the sub-pixel descs exist in the 8-wave kernel only: the 4-wave kernel would read `upsample != 0` as the folded 9-tap gather (wrong K / weight layout)

@@ -1352,6 +1352,9 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
       if (cost < best) xn = c, best = cost;
     }
   }
+  // producer of folded-LayerNorm statistics: slot tn < tiles_n of every row is written, the consumer sums rs_n slots -- both sides must mean the
+  // same tile width (it follows mutable dispatch knobs: tb_gemm8_set), and a row of rs_out holds rs_ld slots
+  if (d.rs_out && (tiles_n > d.rs_ld || (d.rs_n > 0 && tiles_n != d.rs_n))) return TB_EINVAL;
   G8Magic mg;
   {
     const int W_ = SUB == 1 ? d.Win : d.Wout, H_ = SUB == 1 ? d.Hin : d.Hout;

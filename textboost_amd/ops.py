@@ -180,20 +180,22 @@ DEFER_SPLITK = os.environ.get("TB_DEFER_SPLITK", "1") == "1"   # A/B switch: 0 =
 
 
 def gemm(A, W, out, *, K=None, A2=None, W2=None, bias=None, rowbias=None, rows_per_group=0, R=None, act=L.ACT_NONE,
-         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None, defer=False, rs_out=None, lnfold=None):
+         alpha=1.0, C2=None, conv=None, ln_fwd=None, ln_bwd=None, defer=False, rs_out=None, lnfold=None, rs_slots=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue). A/out/R may be column-slices of wider buffers (stride(0) = ld).
     conv = dict(B,Hin,Win,Cin,Hout,Wout,stride,sign,upsample,transposed) switches A to an NHWC 3x3 gather.
     ln_fwd = (gamma, beta, stats_out, y_out, eps): LayerNorm of the output row fused into the epilogue (only where `gemm_ln_ok`): `out` gets the
     Linear's result as usual, `y_out` = LN(out), `stats_out` [M,2] = (mean, rstd).
     ln_bwd = (gamma, stats, x): `out` = tb_layernorm_bwd(dy = A @ W^T, x, gamma, stats) + R -- the LayerNorm backward applied to the dgrad
     GEMM's accumulators (x = the LayerNorm's fp16 input).
-    rs_out = fp32 [M, slots, 2]: the launch also writes per-column-tile (sum, sum of squares) of its fp16 output rows (`lnfold_slots`).
+    rs_out = fp32 [M, slots, 2]: the launch also writes per-column-tile (sum, sum of squares) of its fp16 output rows (`lnfold_slots`);
+    rs_slots = the number of slots per row the consumer is going to sum (checked against the tile the launch takes).
     lnfold = (rs, n_slots, c1, stats_out_or_None, eps): W is a `fold_layernorm` weight, A the RAW LayerNorm input, bias = c2; the LayerNorm is
     applied as two per-row scalars in the epilogue (act NONE or GEGLU); stats_out [M, 2] receives (mean, rstd) for the backward."""
     d = L.GemmDesc()
     if rs_out is not None:
         assert rs_out.dtype == torch.float32 and rs_out.is_contiguous() and rs_out.shape[0] == out.shape[0] and rs_out.shape[2] == 2
         d.rs_out, d.rs_ld = L.ptr(rs_out), rs_out.shape[1]
+        d.rs_n = int(rs_slots or 0)   # the slot count the consumer will sum: the launch is refused (-22) if its tiles would fill another number
     if lnfold is not None:
         rs_, n_, c1_, st_, eps_ = lnfold
         assert rs_out is None and rs_.dtype == torch.float32 and rs_.is_contiguous() and c1_.dtype == torch.float32
@@ -360,6 +362,12 @@ def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5, lora_A=None, t=None, lora_
     """lora_A fp32 [R, C] + t fp16 [M, >=R]: also write the LoRA down projection of the normalised rows into t[:, :R]
     (only for rows < lora_rows when given: the rows behind them belong to a frozen batch and keep their zero t)."""
     M, Cc = y.shape
+    with _rec("layernorm_fwd", 0.0, float(M * Cc * (x.element_size() + y.element_size()))):
+        return _layernorm_fwd(x, y, gamma, beta, stats, eps, lora_A, t, lora_rows)
+
+
+def _layernorm_fwd(x, y, gamma, beta, stats, eps, lora_A, t, lora_rows):
+    M, Cc = y.shape
     if lora_A is not None and lora_rows is not None and lora_rows < M:
         L.check(L.lib().tb_layernorm_lora_rows_fwd(L.ptr(x), x.stride(0), _dt(x), L.ptr(y), y.stride(0), _dt(y), L.ptr(gamma), L.ptr(beta),
                                                    L.ptr(stats), M, Cc, eps, L.ptr(lora_A), lora_A.shape[0], L.ptr(t), t.stride(0), lora_rows,
@@ -377,9 +385,12 @@ def layernorm_fwd(x, y, gamma, beta, stats, eps=1e-5, lora_A=None, t=None, lora_
 
 def layernorm_bwd(dy, x, gamma, stats, dx, add=None, dx16=None):
     M, Cc = dx.shape
-    L.check(L.lib().tb_layernorm_bwd(L.ptr(dy), dy.stride(0), _dt(dy), L.ptr(x), x.stride(0), _dt(x), L.ptr(gamma), L.ptr(stats),
-                                     L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), L.ptr(dx16),
-                                     dx16.stride(0) if dx16 is not None else 0, M, Cc, L.stream()), "tb_layernorm_bwd")
+    byt = M * Cc * (dy.element_size() + x.element_size() + dx.element_size() + (add.element_size() if add is not None else 0)
+                    + (dx16.element_size() if dx16 is not None else 0))
+    with _rec("layernorm_bwd", 0.0, float(byt)):
+        L.check(L.lib().tb_layernorm_bwd(L.ptr(dy), dy.stride(0), _dt(dy), L.ptr(x), x.stride(0), _dt(x), L.ptr(gamma), L.ptr(stats),
+                                         L.ptr(add), add.stride(0) if add is not None else 0, L.ptr(dx), dx.stride(0), L.ptr(dx16),
+                                         dx16.stride(0) if dx16 is not None else 0, M, Cc, L.stream()), "tb_layernorm_bwd")
     return dx
 
 

@@ -416,7 +416,7 @@ class HipUNet:
         ls1 = self.buf(prefix + ".ls1", M, 2, torch.float32)
         qkv = self.buf(prefix + ".qkv", M, 3 * C)
         if fold:
-            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"], rs_out=rs)
+            ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"], rs_out=rs, rs_slots=fold)
             ops.gemm(t0, P[tb + ".attn1.qkv.w"], qkv, bias=P[tb + ".attn1.qkv.c2"], lnfold=(rs, fold, P[tb + ".attn1.qkv.c1"], ls1, 1e-5))
         else:
             l1 = self.scratch("a2" if fuse_ln else "a", M, C)   # (fused: written while n0 -- scratch "a" -- is still being read)
@@ -440,7 +440,7 @@ class HipUNet:
         ls2 = self.buf(prefix + ".ls2", M, 2, torch.float32)
         q2 = self.buf(prefix + ".q2", M, C)
         if fold:
-            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0, rs_out=rs)
+            ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0, rs_out=rs, rs_slots=fold)
             ops.gemm(t1, P[tb + ".attn2.to_q.w"], q2, bias=P[tb + ".attn2.to_q.c2"], lnfold=(rs, fold, P[tb + ".attn2.to_q.c1"], ls2, 1e-5))
         else:
             l2 = self.scratch("a", M, C)
@@ -462,7 +462,7 @@ class HipUNet:
         ls3 = self.buf(prefix + ".ls3", M, 2, torch.float32)
         l3 = None
         if fold:
-            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1, rs_out=rs)
+            ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1, rs_out=rs, rs_slots=fold)
         else:
             l3 = self.scratch("a", M, C)
             if fuse_ln:
@@ -566,8 +566,9 @@ class HipUNet:
             ops.gemm(ehs16, P["kv_all.w"], self.kv_all)
 
     def forward(self, sample, timesteps, ehs16, ehs_ready=None):
-        """ehs_ready: optional callable run right before the first kernel that reads `ehs16` (the hoisted K/V projection, in front of the first
-        cross-attention): lets the caller produce `ehs16` on another stream while the layers in front of it already run."""
+        """ehs_ready: optional callable run ONCE per forward, right before the first kernel that reads `ehs16` (the hoisted K/V projection, in front
+        of the first cross-attention; at the end of the forward at the latest): a stream join when the caller produces `ehs16` on another stream
+        while the layers in front of it already run, or the producer itself (the trainer issues the text-encoder forward from it)."""
         geo, B, P = self.geo, self.B, self.P
         ch = geo.block_out_channels
         nl = len(ch)
@@ -706,6 +707,9 @@ class HipUNet:
         ops.conv_to4(a, P["conv_out.wp"], P["conv_out.b"], pred, B, self.H, self.W, ch[0])
         self._saved = dict(final=x, sto=sto, cats=cats, cat_views=cat_views, down=down_records, mid=mid_records, up=up_records,
                            hw=hw, Ms=Ms, ehs16=ehs16)
+        # `ehs_ready` may carry compute (the trainer issues the whole text-encoder forward from it, TextBoostStep.te_fwd_late): a geometry
+        # without any cross-attention layer never reached `_ensure_kv` above -- run it here so that the callback is guaranteed to have happened
+        self._ensure_kv()
         return pred
 
     # ------------------------------------------------------------------ backward (dgrad only, down to d_ehs)

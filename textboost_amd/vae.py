@@ -87,7 +87,12 @@ class HipVAEEncoder:
         self.geo, self.B, self.H, self.W, self.dev = geo, batch, height, width, device
         self.dtype = torch.float32  # what `vae.dtype` reports in the reference (:1027 casts pixel_values to it)
         self._bufs: Dict[str, torch.Tensor] = {}
-        self._pack(state_dict)
+        # The reference keeps the VAE in fp32 in EVERY --mixed_precision mode (train_textboost.py:938).  This encoder multiplies 16-bit operands with
+        # fp32 accumulation / statistics; its 16-bit type is therefore pinned to IEEE half (11 significand bits; latents 1e-2 from an fp32 run at
+        # full size) also when the process trains with the bfloat16 build (8 bits): it packs and runs on the fp16 library whatever `_lib.half_kind()` is.
+        self.half = "fp16"
+        with L.use_half(self.half):
+            self._pack(state_dict)
         self.gn_ws = torch.empty((2048 + 2 * batch) * geo.norm_num_groups * 2, device=device, dtype=torch.float32)
         self.generator: Optional[torch.Generator] = None
 
@@ -210,6 +215,10 @@ class HipVAEEncoder:
     # ------------------------------------------------------------------ forward
     def moments(self, pixel_values):
         """fp32 [B*h*w, 2L] NHWC rows = (mean | logvar) before the clamp."""
+        with L.use_half(self.half):
+            return self._moments(pixel_values)
+
+    def _moments(self, pixel_values):
         geo, B, H, W = self.geo, self.B, self.H, self.W
         ch = geo.block_out_channels
         assert pixel_values.shape == (B, geo.in_channels, H, W) and pixel_values.dtype == torch.float32
@@ -242,7 +251,8 @@ class HipVAEEncoder:
         if noise is None:
             noise = torch.randn(self.B, geo.latent_channels, h, w, device=self.dev, generator=self.generator)
         lat = self.buf("latents", self.B * geo.latent_channels, h * w, torch.float32)
-        ops.vae_sample(mom, noise.contiguous(), lat, self.B, h * w, geo.latent_channels, geo.scaling_factor)
+        with L.use_half(self.half):
+            ops.vae_sample(mom, noise.contiguous(), lat, self.B, h * w, geo.latent_channels, geo.scaling_factor)
         return lat.view(self.B, geo.latent_channels, h, w)
 
 
@@ -251,6 +261,7 @@ class HipVAEDecoder(HipVAEEncoder):
     validation (`log_validation`, train_textboost.py:453-531) and inference.py -- `vae.decode(latents / scaling_factor).sample`, then
     `(image / 2 + 0.5).clamp(0, 1)`.  diffusers keys `post_quant_conv.*`, `decoder.*`.  Same kernels and precision policy as the
     encoder; Upsample2D (nearest x2 + 3x3 conv) is the conv gather with `upsample = 1` (no upsampled tensor is materialised)."""
+    half = None   # the validation pipeline's VAE follows the run's weight_dtype (train_textboost.py:469-479 `torch_dtype=weight_dtype`): the active library
 
     def __init__(self, geo: VAEGeometry, state_dict: Dict[str, torch.Tensor], batch: int, latent_h: int, latent_w: int, device="cuda"):
         assert all(c % 64 == 0 for c in geo.block_out_channels)
