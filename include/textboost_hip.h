@@ -373,6 +373,30 @@ int tb_weight_decay(float* p, int64_t n, float factor, const float* state, tb_st
 /* added-row norm clamp (:1138-1149) and row norms for mean_norm (:1017) */
 int tb_renorm_rows(float* rows, int n_rows, int D, float mean_norm, float* norms, tb_stream_t stream);
 int tb_row_norms(const float* w, int64_t rows, int D, float* norms, tb_stream_t stream);
+/* The whole optimizer tail above (train_textboost.py:1128-1149: unscale + inf check + GradScaler.update, clip_grad_norm_, lr_scheduler, AdamW of
+ * both text-encoder groups [+ the UNet adapter group], the decoupled decay of the rows that never get a gradient, the added-row norm clamp) as TWO
+ * launches instead of ten (round 6; same arithmetic in the same order: bit-equal to the separate entry points, which stay as the reference form):
+ *   launch 1: per-block partial sums of squares of both gradient segments of `grad` ([0, n_lora) and [n_lora, n_lora + n_emb)) and a SNAPSHOT of the
+ *             state fields launch 2 is going to overwrite (loss scale, step count, growth tracker);
+ *   launch 2: every workgroup derives the step's scalars from the partials + the snapshot itself (so no workgroup reads a state field another one
+ *             writes), then does its share: LoRA elements, one added row each (AdamW, then the norm clamp of that row), UNet adapter elements,
+ *             a slab of the decay-only rows; workgroup 0 publishes the new state.
+ * ws = 2 * 64 + 4 floats of scratch.  lr_table may be NULL (state[TB_ST_LR_MULT] as the host left it). */
+typedef struct {
+  float* state;                       /* fp32[TB_ST_COUNT] */
+  const float* grad;                  /* flat [lora | added rows | unet adapters], loss-scaled (and summed over ranks) */
+  float* p_lora; float* m_lora; float* v_lora; int64_t n_lora;        /* group 1 (clipped) */
+  float* p_added; float* m_emb; float* v_emb; int32_t n_added; int32_t D;   /* group 0, trainable rows [n_added][D]; n_emb = n_added * D */
+  float* p_unet; float* m_unet; float* v_unet; int64_t n_unet;        /* group 2 (unclipped, lr), may be empty */
+  float* p_decay; int64_t n_decay;    /* group 0, rows that only see the decoupled decay (n_decay % 4 == 0), may be empty */
+  float decay_factor;                 /* 1 - emb_lr * wd at the base lr, as tb_weight_decay takes it */
+  float* added_norms;                 /* [n_added] or NULL: row norms before the clamp */
+  const float* lr_table; int32_t lr_table_n;
+  float lr, emb_lr, beta1, beta2, eps, wd, max_norm, mean_norm;
+  float growth_factor, backoff_factor, growth_interval; int32_t use_scaler; float grad_div;
+  float* ws;
+} tb_opt_desc;
+int tb_optimizer_tail(const tb_opt_desc* d, tb_stream_t stream);
 
 /* ---- fp32 (no-AMP) numeric mode ------------------------------------------------------------------------------------------------------
  * The reference runs in full fp32 unless --mixed_precision fp16 is given (train_textboost.py:298-308 default None; :930-939 weight_dtype

@@ -80,6 +80,44 @@ def test_fp16_overflow_skips_the_step_and_halves_the_scale():
     assert sc["found_inf"] == 0.0 and sc["opt_steps"] == 2.0 and sc["loss_scale"] == 32768.0
 
 
+def test_optimizer_tail_in_two_launches_is_bit_equal_to_the_ten_separate_ones():
+    """round 6: `tb_optimizer_tail` (sums of squares of both groups + a snapshot of the scaler state | every workgroup derives the step's scalars
+    itself, then AdamW per group, the added rows' norm clamp, the decay of the untouched rows; train_textboost.py:1128-1149) against the entry
+    points it replaces -- tb_sumsq x2, tb_lr_from_table, tb_scaler_update, tb_adamw x2, tb_weight_decay, tb_renorm_rows -- over clean steps under
+    an lr schedule, an overflow step (skipped update, halved scale, the clamp still runs) and the recovery: state, parameters and both Adam
+    moments identical bit for bit."""
+    from oracle import train_step as ts
+    from tests.test_gpu_model import build_step
+    from textboost_amd.trainer import lr_lambda
+    B, hw, D = 2, 16, 64
+    runs = []
+    for fused in (True, False):
+        st_ref, step, added = build_step(B, hw, D)
+        step.fused_tail = fused
+        lam = lr_lambda("linear", 1, 6)
+        step.set_lr_table([lam(k) for k in range(8)])
+        g = torch.Generator().manual_seed(12)
+        snaps = []
+        for it in range(5):
+            step.input_ids.copy_(ts.synthetic_ids(B, added, g)); step.prior_ids.copy_(ts.synthetic_ids(B, added, g, prior=True))
+            step.noise.copy_(torch.randn(B, 4, hw, hw, generator=g)); step.timesteps.copy_(torch.randint(0, 1000, (B,), generator=g))
+            step.x0.copy_(torch.randn(B, 4, hw, hw, generator=g))
+            if it == 2:
+                step.x0.fill_(1e6)            # overflows fp16 inside the UNet -> non-finite gradients -> the step is skipped
+            step.step_eager()
+            torch.cuda.synchronize()
+            snaps.append([t.clone() for t in (step.state, step.flat_lora, step.te.token_table, step.m_lora, step.v_lora, step.m_emb, step.v_emb,
+                                              step.added_norms)])
+        sc = step.scalars()
+        assert sc["opt_steps"] == 4.0 and sc["loss_scale"] == 32768.0
+        runs.append(snaps)
+    names = ("state", "lora", "token_table", "m_lora", "v_lora", "m_emb", "v_emb", "added_norms")
+    for it, (a, b) in enumerate(zip(*runs)):
+        for n, x, y in zip(names, a, b):
+            same = torch.equal(x, y) or ((torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)))
+            assert same, (it, n, (x - y).abs().max().item(), x.flatten()[:16].tolist(), y.flatten()[:16].tolist())
+
+
 def test_cli_rejects_unbuilt_arithmetic_options(tmp_path):
     """Options that would change the step's arithmetic but are not built must fail loudly (the fp32 no-AMP mode is built: tests/test_gpu_f32.py)."""
     import os

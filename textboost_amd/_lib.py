@@ -82,6 +82,24 @@ class FfDesc(C.Structure):
     ]
 
 
+class OptDesc(C.Structure):
+    """tb_opt_desc (include/textboost_hip.h): the optimizer tail as two launches"""
+    _fields_ = [
+        ("state", C.c_void_p), ("grad", C.c_void_p),
+        ("p_lora", C.c_void_p), ("m_lora", C.c_void_p), ("v_lora", C.c_void_p), ("n_lora", C.c_int64),
+        ("p_added", C.c_void_p), ("m_emb", C.c_void_p), ("v_emb", C.c_void_p), ("n_added", C.c_int32), ("D", C.c_int32),
+        ("p_unet", C.c_void_p), ("m_unet", C.c_void_p), ("v_unet", C.c_void_p), ("n_unet", C.c_int64),
+        ("p_decay", C.c_void_p), ("n_decay", C.c_int64), ("decay_factor", C.c_float),
+        ("added_norms", C.c_void_p),
+        ("lr_table", C.c_void_p), ("lr_table_n", C.c_int32),
+        ("lr", C.c_float), ("emb_lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("wd", C.c_float),
+        ("max_norm", C.c_float), ("mean_norm", C.c_float),
+        ("growth_factor", C.c_float), ("backoff_factor", C.c_float), ("growth_interval", C.c_float), ("use_scaler", C.c_int32),
+        ("grad_div", C.c_float),
+        ("ws", C.c_void_p),
+    ]
+
+
 _lib = None
 
 _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -153,6 +171,7 @@ _SIGS = {
     "tb_weight_decay": ([_VP, _I64, _F, _VP, _VP], C.c_int),
     "tb_renorm_rows": ([_VP, _I, _I, _F, _VP, _VP], C.c_int),
     "tb_row_norms": ([_VP, _I64, _I, _VP, _VP], C.c_int),
+    "tb_optimizer_tail": ([C.POINTER(OptDesc), _VP], C.c_int),
     "tb_gemm_f32": ([C.POINTER(GemmDesc), _VP], C.c_int),
     "tb_gemm_f32_t": ([C.POINTER(GemmDesc), _I, _I, _VP], C.c_int),
     "tb_attention_f32_ws_floats": ([_I, _I, _I, _I], _I64),

@@ -749,6 +749,32 @@ def weight_decay(p, factor, state):
     L.check(L.lib().tb_weight_decay(L.ptr(p), p.numel(), factor, L.ptr(state), L.stream()), "tb_weight_decay")
 
 
+def optimizer_tail(state, grad, ws, *, lora=None, added=None, unet=None, decay=None, added_norms=None, lr_table=None, lr, emb_lr, beta1, beta2,
+                   eps, wd, max_norm, mean_norm, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, use_scaler=True, grad_div=1.0):
+    """The optimizer tail (sumsq x2, lr table, scaler update, AdamW per group, row decay, renorm) as two launches (tb_optimizer_tail).
+    lora / unet = (p, m, v) flat fp32; added = (rows [k, D], m, v); decay = the flat view of the rows that never get a gradient; ws = 132 floats."""
+    d = L.OptDesc()
+    d.state, d.grad, d.ws = L.ptr(state), L.ptr(grad), L.ptr(ws)
+    assert ws.numel() >= 132 and ws.dtype == torch.float32
+    if lora is not None and lora[0].numel():
+        d.p_lora, d.m_lora, d.v_lora, d.n_lora = L.ptr(lora[0]), L.ptr(lora[1]), L.ptr(lora[2]), lora[0].numel()
+    if added is not None and added[0].numel():
+        assert added[0].is_contiguous()
+        d.p_added, d.m_emb, d.v_emb, d.n_added, d.D = L.ptr(added[0]), L.ptr(added[1]), L.ptr(added[2]), added[0].shape[0], added[0].shape[1]
+    if unet is not None and unet[0].numel():
+        d.p_unet, d.m_unet, d.v_unet, d.n_unet = L.ptr(unet[0]), L.ptr(unet[1]), L.ptr(unet[2]), unet[0].numel()
+    if decay is not None and decay.numel():
+        d.p_decay, d.n_decay = L.ptr(decay), decay.numel()
+    d.decay_factor = 1.0 - emb_lr * wd
+    d.added_norms = L.ptr(added_norms)
+    if lr_table is not None:
+        d.lr_table, d.lr_table_n = L.ptr(lr_table), lr_table.numel()
+    d.lr, d.emb_lr, d.beta1, d.beta2, d.eps, d.wd, d.max_norm, d.mean_norm = lr, emb_lr, beta1, beta2, eps, wd, max_norm, mean_norm
+    d.growth_factor, d.backoff_factor, d.growth_interval, d.use_scaler, d.grad_div = growth_factor, backoff_factor, float(growth_interval), \
+        int(use_scaler), float(grad_div)
+    L.check(L.lib().tb_optimizer_tail(d, L.stream()), "tb_optimizer_tail")
+
+
 def renorm_rows(rows, mean_norm, norms=None):
     L.check(L.lib().tb_renorm_rows(L.ptr(rows), rows.shape[0], rows.shape[1], mean_norm, L.ptr(norms), L.stream()), "tb_renorm_rows")
 

@@ -243,6 +243,8 @@ class TextBoostStep:
             self.grads_p = ((self.flat_grad_p[:nA].view_as(te.lora_A), self.flat_grad_p[nA:nA + nB].view_as(te.lora_B)) if has_lora else (None, None)) \
                 + (self.flat_grad_p[nA + nB:].view(te.n_added, D),)
         self.vae = None  # attach_vae(): the step then starts from pixels (:1027-1037) instead of latents
+        self.fused_tail = os.environ.get("TB_OPT_TAIL", "1") == "1"   # the optimizer tail as two launches (round 6) instead of ten
+        self.opt_ws = torch.zeros(132, device=device)
         self.lr_table = None  # set_lr_table(): lambda(k) of --lr_scheduler on the device, indexed by the successful-step count
 
     def attach_vae(self, vae):
@@ -416,6 +418,19 @@ class TextBoostStep:
     def optimizer_step(self):
         hp, te, st = self.hp, self.te, self.state
         D = te.geo.hidden_size
+        if self.fused_tail:
+            # the ten launches below as two (tb_optimizer_tail: same arithmetic in the same order, bit-equal -- test_gpu_edge.py); TB_OPT_TAIL=0 keeps them
+            ne = self.n_emb
+            ops.optimizer_tail(
+                st, self.flat_grad, self.opt_ws,
+                lora=(self.flat_lora, self.m_lora, self.v_lora) if self.n_lora else None,
+                added=(te.token_table[te.first_added:], self.m_emb, self.v_emb) if te.n_added else None,
+                unet=(self.flat_unet, self.m_unet, self.v_unet) if self.n_unet else None,
+                decay=te.token_table[: te.first_added].view(-1), added_norms=self.added_norms if te.n_added else None,
+                lr_table=self.lr_table, lr=hp.lr, emb_lr=hp.emb_lr, beta1=hp.beta1, beta2=hp.beta2, eps=hp.eps, wd=hp.wd,
+                max_norm=hp.max_grad_norm, mean_norm=self.mean_norm, growth_interval=hp.growth_interval, use_scaler=hp.use_grad_scaler,
+                grad_div=float(self.world * self.accum))
+            return
         if self.n_lora:
             ops.sumsq(self.flat_grad[: self.n_lora], st[L.ST_SUMSQ_LORA:])
         if te.n_added:
