@@ -999,3 +999,34 @@ def test_layernorm_fold_with_a_large_row_mean_and_its_refusals(M, C):
                 ops.gemm(x, Wp, out, bias=c2, lnfold=(rs, slots, c1, st, 1e-5))
     finally:
         L.lib().tb_gemm_set_variant(2000)                                            # (2000 + bits: all profiling bits off again)
+
+
+def test_conv3x3_32x32_maps_as_two_k_slices_of_the_wide_tile():
+    """round-6 experiment behind tb_gemm8_set bit 524288 (measured a LOSS in the step, 28.12 -> 28.27 ms, so off by default): the 32x32-map
+    convolutions (M = 8192, N = 640: 128 tiles of 256 x 160) as two k-slices of the 256 x 160 tile + the reducer, instead of one round of
+    256 x 80 tiles.  Same result as the default path and as F.conv2d."""
+    import ctypes
+    ops, L = _ops()
+    torch.manual_seed(12)
+    B, Cin, Cout, H = 8, 640, 640, 32
+    x = torch.randn(B, Cin, H, H, device="cuda").half()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+    bias = torch.randn(Cout, device="cuda")
+    res = torch.randn(B * H * H, Cout, device="cuda").half()
+    xn = nhwc(x).view(B * H * H, Cin)
+    geo = dict(B=B, Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+    default_bits = L.lib().tb_gemm8_set(39)
+    outs = []
+    try:
+        for bits, want in ((39, [8, 1, 2, 5, 1, 4]), (39 | 524288, [4, 2, 4, 5, 1, 3])):
+            L.lib().tb_gemm8_set(bits)
+            out = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.float16)
+            ops.gemm(xn, pack_conv_w(w), out, bias=bias, R=res, conv=geo)
+            last = (ctypes.c_int * 6)()
+            assert L.lib().tb_gemm8_last(last) and list(last) == want, list(last)
+            outs.append(out)
+    finally:
+        L.lib().tb_gemm8_set(default_bits)
+    ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * H, Cout) + res.float()
+    parity("32x32-map conv as two k-slices of the 256 x 160 tile", outs[1], ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
+    assert rel_err(outs[0], outs[1]) < 1e-3

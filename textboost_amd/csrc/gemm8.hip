@@ -1521,6 +1521,13 @@ static int gemm8_try(const tb_gemm_desc& d, hipStream_t s) {
     // 256 pixels x 160 channels (one round of >= 200 blocks), else 256 x 80
     if (256 % TW == 0 && d.Hout % (256 / TW) == 0 && d.M % 256 == 0) {
       if (d.N % 160 == 0 && (d.M / 256) * (d.N / 160) >= 200) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift);
+      // (524288, round-6 experiment: the 32x32-map convolutions -- 128 tiles of 256 x 160 -- as TWO k-slices of the 256 x 160 tile (the 64 x 80 wave
+      //  tile: 9 fragment reads per 20 MFMAs) instead of one round of 256 x 80 tiles (32 x 80 wave tiles: 7 per 10); fp32 partials + the consumer's /
+      //  the caller's reduction, as on the 16x16 maps)
+      if ((g8_enable & 524288) && (g8_enable & 32) && d.N % 160 == 0 && d.ws) {
+        const int tiles = (int)((d.M / 256) * (d.N / 160)), kpt = d.Cin / 64;
+        if (tiles >= 100 && tiles < 200 && kpt >= 4) return launch8<4, 2, 4, 5, true, 3>(d, s, wshift, 2);
+      }
       if (d.N % 80 == 0 && (d.M / 256) * (d.N / 80) >= 200) {
         if (!(g8_enable & 32768)) {   // 4-slot weight ring with the pieces between the MFMAs (DMACH) where the LDS holds it (maps up to 32 wide)
           const int r = launch8<8, 1, 2, 5, true, 4>(d, s, wshift);

@@ -32,6 +32,9 @@ struct GnMap {  // thread -> (column-vector, row-lane) mapping shared by the fou
 // leaves >= 640 blocks over the batch (fatter blocks amortise the block reduction and shorten the per-block finalize loop over the
 // chunk partials; A/B on one MI355X, fwd+bwd: 4096x320 77 -> 61 us, 4096x640 113 -> 94 us, 1024x1280 85 -> 61 us; fewer than
 // ~600 blocks under-fills the 256 CUs and loses again)
+#ifndef TB_GN_RU
+#define TB_GN_RU 1   // rows per trip of the two-pass backward kernels' row loops (A/B build switch)
+#endif
 __host__ __device__ inline int gn_chunks(int B, int HW, int C) {
   int cols = C >> 3;
   int cw = cols < 256 ? cols : 256;
@@ -286,9 +289,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const f16* __restrict
         ga[e] = gamma[ch];
         be[e] = beta[ch];
       }
-      for (int r = r_begin + mp.rl; r < r_end; r += mp.nrl) {
-        f16x8 xv = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
-        f16x8 dv = *(const f16x8*)(dyb + (int64_t)r * lddy + cc * 8);
+      auto body = [&](const f16x8& xv, const f16x8& dv) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float xh = ((float)xv[e] - mu[e]) * rs[e];
@@ -298,6 +299,26 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const f16* __restrict
           s[k][e] += d;
           q[k][e] += d * xh;
         }
+      };
+      int r = r_begin + mp.rl;
+#if TB_GN_RU > 1
+      // TB_GN_RU rows per trip, every load of the trip issued before the first use: a thread of the rolled loop kept one row of x and dy in
+      // flight (32 B), i.e. ~20 KB per CU -- at ~2 us of memory latency that alone bounds the pass near 2.8 TB/s
+      for (; r + (TB_GN_RU - 1) * mp.nrl < r_end; r += TB_GN_RU * mp.nrl) {
+        f16x8 xv[TB_GN_RU], dv[TB_GN_RU];
+#pragma unroll
+        for (int u = 0; u < TB_GN_RU; ++u) {
+          xv[u] = *(const f16x8*)(xb + (int64_t)(r + u * mp.nrl) * ldx + cc * 8);
+          dv[u] = *(const f16x8*)(dyb + (int64_t)(r + u * mp.nrl) * lddy + cc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < TB_GN_RU; ++u) body(xv[u], dv[u]);
+      }
+#endif
+      for (; r < r_end; r += mp.nrl) {
+        f16x8 xv = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
+        f16x8 dv = *(const f16x8*)(dyb + (int64_t)r * lddy + cc * 8);
+        body(xv, dv);
       }
     }
   }
@@ -347,11 +368,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict
       m1[e] = s1_s[g];
       m2[e] = s2_s[g];
     }
-    for (int r = r_begin + mp.rl; r < r_end; r += mp.nrl) {
-      f16x8 xv = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
-      f16x8 dv = *(const f16x8*)(dyb + (int64_t)r * lddy + cc * 8);
-      f16x8 av;
-      if (ab) av = *(const f16x8*)(ab + (int64_t)r * ldadd + cc * 8);
+    auto body = [&](int r, const f16x8& xv, const f16x8& dv, const f16x8& av) {
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -364,6 +381,27 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict
         o[e] = (f16)dx;
       }
       *(f16x8*)(dxb + (int64_t)r * lddx + cc * 8) = o;
+    };
+    int r = r_begin + mp.rl;
+#if TB_GN_RU > 1
+    for (; r + (TB_GN_RU - 1) * mp.nrl < r_end; r += TB_GN_RU * mp.nrl) {   // (see gn_bwd_stats_kernel)
+      f16x8 xv[TB_GN_RU], dv[TB_GN_RU], av[TB_GN_RU];
+#pragma unroll
+      for (int u = 0; u < TB_GN_RU; ++u) {
+        xv[u] = *(const f16x8*)(xb + (int64_t)(r + u * mp.nrl) * ldx + cc * 8);
+        dv[u] = *(const f16x8*)(dyb + (int64_t)(r + u * mp.nrl) * lddy + cc * 8);
+        if (ab) av[u] = *(const f16x8*)(ab + (int64_t)(r + u * mp.nrl) * ldadd + cc * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < TB_GN_RU; ++u) body(r + u * mp.nrl, xv[u], dv[u], av[u]);
+    }
+#endif
+    for (; r < r_end; r += mp.nrl) {
+      f16x8 xv = *(const f16x8*)(xb + (int64_t)r * ldx + cc * 8);
+      f16x8 dv = *(const f16x8*)(dyb + (int64_t)r * lddy + cc * 8);
+      f16x8 av;
+      if (ab) av = *(const f16x8*)(ab + (int64_t)r * ldadd + cc * 8);
+      body(r, xv, dv, av);
     }
   }
 }
