@@ -90,7 +90,7 @@ def roofline_leg(step):
     # HBM traffic per launch of that kernel: PMC passes cannot run inside this process (separate rocprofv3 --pmc runs, FETCH_SIZE and
     # WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md); the committed summary of those passes (scratch/pmc_bench.sh ->
     # scratch/pmc_traffic.py) is quoted when it has the same kernel symbol
-    for pf in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for pf in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
             cands = [name] + ([name[:-1] + ", 0>", name[:-1] + ", 0, 1>"] if name.endswith(">") else [])   # (the trace's symbol carries the
@@ -180,7 +180,7 @@ def sustained_mfma_peak(ms_target=15.0, reps=3):
 def mfma_busy_table():
     """Per kernel family MFMA-pipe busy fraction from the committed SQ counter pass of the same bench command (profiles/rNN_mfma_busy.json:
     SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); PMC passes cannot run inside this process).  None when no file matches."""
-    for pf in ("r05_mfma_busy.json", "r04_mfma_busy.json", "r03_mfma_busy.json"):
+    for pf in ("r06_mfma_busy.json", "r05_mfma_busy.json", "r04_mfma_busy.json", "r03_mfma_busy.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", pf)))
             return {"source": f"profiles/{pf}", "families": d}
