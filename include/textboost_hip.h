@@ -160,6 +160,19 @@ typedef struct tb_ff_desc {
   const void* ln_x; int64_t ld_lnx;   /* fp16 [M, C]: the LayerNorm's input */
   const float* ln_stats;              /* fp32 [M, 2] (mean, rstd) */
   const float* ln_gamma;              /* fp32 [C] */
+  /* tb_ff_fwd only (round 6): the row-local neighbours of the feed-forward in the SAME launch (a 128-row tile spans the 320-wide rows of all of them).
+   *   pre_W != NULL: X is the input of attn2.to_out (the cross-attention output); the launch first computes
+   *       t2 = X pre_W^T + pre_b (+ pre_R), stores it to pre_Y (the residual stream: set R = pre_Y for the feed-forward's own residual),
+   *       l3 = LayerNorm(t2; pre_gamma, pre_beta, pre_eps) with (mean, rstd) to pre_stats -- and feeds l3 to ff.net.0.proj straight from the LDS:
+   *       diffusers BasicTransformerBlock: attn2.to_out.0 + residual, norm3, ff  (train_textboost.py:1063-1067).
+   *   post_W != NULL: the block's output t3 = ff(...) + b2 + R goes through one more Linear before it leaves the launch,
+   *       post_Y = t3 post_W^T + post_b (+ post_R): Transformer2DModel.proj_out + the block input (1x1 conv = Linear over NHWC rows);
+   *       Y may then be NULL (nothing reads t3: no weight gradients exist in this path).
+   * Weights fp16 [C, C] row-major (out, in), 16-byte aligned rows.  Same arithmetic as the launches this replaces: every intermediate is rounded to
+   * fp16 where they stored it; the LayerNorm statistics are two-pass fp32 over the fp16-rounded t2. */
+  const void* pre_W; int64_t ld_prew; const float* pre_b; const void* pre_R; int64_t ld_prer; void* pre_Y; int64_t ld_prey;
+  const float* pre_gamma; const float* pre_beta; float* pre_stats; float pre_eps;
+  const void* post_W; int64_t ld_postw; const float* post_b; const void* post_R; int64_t ld_postr; void* post_Y; int64_t ld_posty;
 } tb_ff_desc;
 int tb_ff_fused_ok(int64_t M, int C, int inner);
 int tb_ff_fwd(const tb_ff_desc* d, tb_stream_t stream);

@@ -7,6 +7,10 @@ from textboost_amd.workload import build_step
 step, _ = build_step(batch=8, latent=64, data_seed=1000, world_size=1, device=torch.device("cuda", 0))
 for _ in range(2): step.step_eager()
 def setattr_dotted(obj, path, val):
+    if path.startswith("unetmod."):   # a module global of textboost_amd.unet (read at issue time), e.g. unetmod.FF_CHAIN=0
+        import textboost_amd.unet as U
+        setattr(U, path.split(".", 1)[1], val)
+        return
     parts = path.split(".")
     for p in parts[:-1]: obj = getattr(obj, p)
     setattr(obj, parts[-1], val)

@@ -132,6 +132,72 @@ def test_ff_backward_with_the_layernorm_backward_in_its_epilogue(M):
     parity("ff_bwd + LayerNorm backward", dres, xr.grad + dy.float(), 2e-3, 3e-3, ch_dim=1, ch_rel=3e-3)
 
 
+@pytest.mark.parametrize("M,mode", [(128, 3), (384, 1), (384, 2), (4096, 3), (32768, 3)])
+def test_ff_forward_with_its_row_local_neighbours_in_the_same_launch(M, mode):
+    """round 6 (tb_ff_desc.pre_W / post_W): attn2.to_out + residual + norm3 in FRONT of the fused feed-forward (mode bit 1) and proj_out + the block
+    input BEHIND it (bit 2) -- diffusers BasicTransformerBlock / Transformer2DModel, train_textboost.py:1063-1067 -- against torch fp32 on the same
+    fp16-rounded intermediates and against the launches this replaces (tb_gemm with the LayerNorm epilogue, tb_ff_fwd, tb_gemm): the residual stream
+    t2, the LayerNorm statistics, the stored pre-gate projections and the final output; strided views stay untouched outside their columns."""
+    ops, L = _ops()
+    torch.manual_seed(M + 11 * mode)
+    w1, b1, w2, b2 = _weights(5)
+    g = torch.Generator().manual_seed(9)
+    wpre = (torch.randn(C, C, generator=g) / C ** 0.5).half().cuda()
+    bpre = (torch.randn(C, generator=g) * 0.3).cuda()
+    wpost = (torch.randn(C, C, generator=g) / C ** 0.5).half().cuda()
+    bpost = (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma, beta = 1 + 0.4 * torch.randn(C, device="cuda"), 0.2 * torch.randn(C, device="cuda")
+    o2 = torch.randn(M, C, device="cuda").half()                                                   # the cross-attention output
+    t1 = (torch.randn(M, C, device="cuda") * 0.8 + torch.randn(M, 1, device="cuda") * 0.5).half()  # the residual stream in front of attn2.to_out
+    xin = torch.randn(M, C, device="cuda").half()                                                  # the transformer's input (proj_out's residual)
+    w1p, b1p = pack_geglu(w1).contiguous(), pack_geglu(b1).contiguous()
+    # ---- the launches this replaces
+    t2_old = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    l3_old = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    st_old = torch.empty(M, 2, device="cuda")
+    if ops.gemm_ln_ok(M, C, C):
+        ops.gemm(o2, wpre, t2_old, bias=bpre, R=t1, ln_fwd=(gamma, beta, st_old, l3_old, 1e-5))
+    else:
+        ops.gemm(o2, wpre, t2_old, bias=bpre, R=t1)
+        ops.layernorm_fwd(t2_old, l3_old, gamma, beta, st_old)
+    hg_old = torch.empty(M, 2 * INNER, device="cuda", dtype=torch.float16)
+    t3_old = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.ff_fwd(l3_old, w1p, b1p, w2, b2, hg_old, t3_old, R=t2_old)
+    out_old = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    ops.gemm(t3_old, wpost, out_old, bias=bpost, R=xin)
+    # ---- one launch
+    t2buf = torch.full((M, C + 8), 7.0, device="cuda", dtype=torch.float16)
+    outbuf = torch.full((M, C + 16), 7.0, device="cuda", dtype=torch.float16)
+    t2, out = t2buf[:, :C], outbuf[:, 8:8 + C]
+    st = torch.zeros(M, 2, device="cuda")
+    hg = torch.empty(M, 2 * INNER, device="cuda", dtype=torch.float16)
+    t3 = torch.empty(M, C, device="cuda", dtype=torch.float16) if not (mode & 2) or M == 384 else None
+    pre = (wpre, bpre, t1, t2, gamma, beta, st, 1e-5) if mode & 1 else None
+    post = (wpost, bpost, xin, out) if mode & 2 else None
+    if not (mode & 1):
+        t2.copy_(t2_old)
+    ops.ff_fwd(o2 if mode & 1 else l3_old, w1p, b1p, w2, b2, hg, t3, R=t2, pre=pre, post=post)
+    # ---- torch fp32 on the fp16-rounded intermediates
+    t2_ref = (o2.float() @ wpre.float().T + bpre + t1.float())
+    t2h = t2_ref.half().float()
+    l3_ref = F.layer_norm(t2h, (C,), gamma, beta, 1e-5).half().float()
+    proj, t3_ref = _ref_fwd(l3_ref, w1, b1, w2, b2, t2h)
+    out_ref = t3_ref.half().float() @ wpost.float().T + bpost + xin.float()
+    if mode & 1:
+        parity("chain: t2 = attn2.to_out + residual", t2, t2_ref, 1e-3, 2e-3, ch_dim=1, ch_rel=2e-3)
+        assert torch.allclose(st[:, 0], t2h.mean(1), rtol=1e-4, atol=2e-4) and torch.allclose(st[:, 1], (t2h.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=3e-4, atol=0)
+        assert rel_err(t2, t2_old) < 3e-4 and torch.allclose(st, st_old, rtol=5e-4, atol=3e-4)
+        assert (t2buf[:, C:] == 7).all()
+    parity("chain: pre-gate projections (packed)", hg, pack_geglu(proj.T).T, 2e-3, 4e-3, ch_dim=1, ch_rel=3e-3)
+    assert rel_err(hg, hg_old) < 1.5e-3   # (a 1-ulp difference of a t2 element moves its whole LayerNorm row by an fp16 ulp)
+    if t3 is not None:
+        parity("chain: t3 = ff + residual", t3, t3_ref, 2e-3, 4e-3, ch_dim=1, ch_rel=3e-3)
+    if mode & 2:
+        parity("chain: proj_out + block input", out, out_ref, 2e-3, 4e-3, ch_dim=1, ch_rel=3e-3)
+        assert rel_err(out, out_old) < 1e-3
+        assert (outbuf[:, :8] == 7).all() and (outbuf[:, 8 + C:] == 7).all()
+
+
 def test_ff_fused_rejects_what_it_does_not_cover():
     ops, L = _ops()
     d = L.FfDesc()

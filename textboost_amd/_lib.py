@@ -79,6 +79,12 @@ class FfDesc(C.Structure):
         ("R", C.c_void_p), ("ldr", C.c_int64),
         ("Y", C.c_void_p), ("ldy", C.c_int64),
         ("ln_x", C.c_void_p), ("ld_lnx", C.c_int64), ("ln_stats", C.c_void_p), ("ln_gamma", C.c_void_p),
+        # round 6, tb_ff_fwd only: attn2.to_out + residual + norm3 in front of the feed-forward, proj_out + residual behind it, same launch
+        ("pre_W", C.c_void_p), ("ld_prew", C.c_int64), ("pre_b", C.c_void_p), ("pre_R", C.c_void_p), ("ld_prer", C.c_int64),
+        ("pre_Y", C.c_void_p), ("ld_prey", C.c_int64), ("pre_gamma", C.c_void_p), ("pre_beta", C.c_void_p), ("pre_stats", C.c_void_p),
+        ("pre_eps", C.c_float),
+        ("post_W", C.c_void_p), ("ld_postw", C.c_int64), ("post_b", C.c_void_p), ("post_R", C.c_void_p), ("ld_postr", C.c_int64),
+        ("post_Y", C.c_void_p), ("ld_posty", C.c_int64),
     ]
 
 

@@ -78,8 +78,83 @@ __device__ unsigned long long* g_ff_dbg = nullptr;
 #define FF_PF(k)
 #endif
 
-template <bool BWD>
+// ---- round 6: the feed-forward's row-local neighbours in the same launch (tb_ff_desc.pre_W / post_W; forward only).
+// A "chain stage" is one more [128 x 320] x [320 x 320]^T product on the workgroup's rows with the 128 x 320 operand in the SAME 80 registers the
+// feed-forward keeps its input in: ten 32-column weight tiles (20 KB each, the backward's phase-A image: five [32 rows][128 B] slabs, chunk ^= row & 7)
+// through two LDS slots at the bottom of ring slot 0, phase A's k-loop per tile (20 MFMAs per wave), a per-tile epilogue on (rows 32 wm + 16 i + l15,
+// columns 32 tile + 16 wn + 4 lq .. + 3).  Results change hands through a [128][320] fp16 LDS IMAGE (656-byte pitch: the b128 reads of 16 consecutive
+// rows at one column land on 16 distinct bank quads) behind ring slot 0, from which the next product's operand fragments are read back:
+//   PRE : X -> t2 = X Wpre^T + b (+ R) -> pre_Y and the image -> two-pass LayerNorm of the image rows in place (+ stats) -> the feed-forward's operand
+//   POST: t3 = ff + b2 + R -> the image (-> Y when asked for) -> operand -> post_Y = t3 Wpost^T + b (+ R)
+constexpr int FFC_WT = 5 * 32 * 128;                      // one chain weight tile: 20 KB
+constexpr int FFC_IMG = 60 * 1024, FFC_PITCH = 656;       // the image: [60 KB, 60 KB + 128 * 656) = up to 142 KB (over slot 1 and the exchange buffer)
+constexpr int FFC_BIAS_OFF = 146 * 1024;                  // the packed proj bias of the chained launches sits behind it
+constexpr int FFC_CB_OFF = FFC_BIAS_OFF + 2 * FF_INNER * 4;   // 156 KB: a chain stage's own bias (320 floats)
+constexpr int FFC_LDS = FFC_CB_OFF + FF_C * 4;
+static_assert(FFC_IMG + FF_BM * FFC_PITCH <= FFC_BIAS_OFF && 3 * FFC_WT <= FFC_IMG && FFC_LDS <= 160 * 1024, "chain LDS map");
+template <int OFF>
+__device__ __forceinline__ void ff_write16(uint32_t addr, f16x8 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+// One chain stage's weight stream: every wave issues exactly THREE 1 KB pieces per 20 KB tile (q = wave, wave + 8, wave + 16; waves 4-7 have only
+// two and repeat their second: same bytes to the same place), so that the counted waits below are wave-independent.  Three ring slots at the bottom
+// of the LDS; tile t lives in slot t % 3 and is requested two tiles ahead: a tile's k-loop is ~0.3 us, an L2 round trip ~1 us.
+struct FfChain {
+  uint32_t off[3], dst[3];
+  const char* W;
+  int64_t tile_stride;
+  unsigned char* smem;
+  __device__ __forceinline__ FfChain(unsigned char* smem_raw, const void* W_, int64_t ldw, int wave, int lane) {
+    smem = smem_raw, W = (const char*)W_, tile_stride = 32 * ldw * 2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int q = wave + 8 * k < 20 ? wave + 8 * k : wave + 8 * (k - 1);
+      const int sl = q >> 2, rgp = q & 3;
+      const int row = rgp * 8 + (lane >> 3), cc = (lane & 7) ^ (lane >> 3);
+      off[k] = (uint32_t)(((int64_t)row * ldw + sl * 64 + cc * 8) * 2);
+      dst[k] = (uint32_t)(sl * 4096 + rgp * 1024);
+    }
+  }
+  __device__ __forceinline__ void issue(int tile) const {
+    const char* base = W + tile * tile_stride;
+    unsigned char* slot = smem + (tile % 3) * FFC_WT;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) glds16((const f16*)(base + off[k]), reinterpret_cast<f16*>(slot + dst[k]));
+  }
+};
+// acc = X[rows 32 wm + 16 i + l15] . Wtile^T (columns 16 wn + 4 lq .. + 3 of the tile): phase A of the backward on the 20 KB image at `slot_addr`
+__device__ __forceinline__ void ff_chain_tile(uint32_t a0, const f16x8 (&xf)[2][10], f32x4_t (&acc)[2]) {
+  const uint32_t a1 = a0 ^ 64;
+  acc[0] = f32x4_t{0.f, 0.f, 0.f, 0.f}, acc[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f16x8 wf[3];
+  auto rd = [&](auto ksc) {
+    constexpr int ks = decltype(ksc)::value;
+    wf[ks % 3] = ff_read16<(ks >> 1) * 4096>((ks & 1) ? a1 : a0);
+  };
+  rd(std::integral_constant<int, 0>{});
+  rd(std::integral_constant<int, 1>{});
+  FF_SB();
+  auto step = [&](auto ksc) {
+    constexpr int ks = decltype(ksc)::value;
+    if constexpr (ks + 2 < 10) rd(std::integral_constant<int, ks + 2>{});
+    constexpr int later = (ks + 2 < 10 ? 1 : 0) + (ks + 1 < 10 ? 1 : 0);
+    ff_wait_lgkm<later>();
+    FF_SB();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = TB_MFMA_16x16x32(wf[ks % 3], xf[i][ks], acc[i]);
+    FF_SB();
+  };
+  step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+  step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+  step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+  step(std::integral_constant<int, 9>{});
+}
+template <bool BWD, bool PRE = false, bool POST = false>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
+  static_assert(!BWD || (!PRE && !POST), "the chained stages exist in the forward only");
+  constexpr bool CHAIN = PRE || POST;
+  constexpr int BIAS_OFF = CHAIN ? FFC_BIAS_OFF : FF_BIAS_OFF;
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -94,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
 
   // ---- the forward's packed projection bias through LDS (a tile's 8 values per lane seed the accumulators)
   if (!BWD) {
-    float* bias_s = reinterpret_cast<float*>(smem_raw + FF_BIAS_OFF);
+    float* bias_s = reinterpret_cast<float*>(smem_raw + BIAS_OFF);
     for (int i = t; i < 2 * FF_INNER; i += 512) bias_s[i] = p.b1 ? p.b1[i] : 0.f;
   }
 
@@ -135,11 +210,124 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) glds16((const f16*)((d_isb[k] ? wb : wa) + d_off[k]), dst + (d_dst[k] >> 1));
   };
-  issue_tile(0, 0);
+  f16x8 xf[2][10];
+  if constexpr (!PRE) issue_tile(0, 0);
 
   // ---- the register-resident operand: rows 32 wm + 16 i + l15, k = 32 ks + 8 lq .. + 7
-  f16x8 xf[2][10];
-  {
+  if constexpr (PRE) {
+    // ---- round 6: attn2.to_out + bias + residual -> t2 (pre_Y and the LDS image) -> norm3 in place -> the feed-forward's operand
+    const FfChain ch(smem_raw, p.pre_W, p.ld_prew, wave, lane);
+    ch.issue(0);
+    ch.issue(1);
+    const uint32_t lds0c = ff_lds_addr(smem_raw);
+    const int64_t row0 = m0 + wm * 32 + l15;
+    {
+      const f16* xr = (const f16*)p.X + row0 * p.ldx + 8 * lq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) xf[i][ks] = *(const f16x8*)(xr + (int64_t)i * 16 * p.ldx + 32 * ks);
+    }
+    // the residual of all ten tiles is requested before the tile loop (inside it only the weight DMA may be on the vector-memory queue: loads return
+    // in order, so the counted wait of a tile means "this tile has landed"); the stage's bias goes through the LDS
+    f16x4 rr[10][2];
+#pragma unroll
+    for (int tl = 0; tl < 10; ++tl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        rr[tl][i] = p.pre_R ? *(const f16x4*)((const f16*)p.pre_R + (row0 + 16 * i) * p.ld_prer + tl * 32 + wn * 16 + 4 * lq) : f16x4{0, 0, 0, 0};
+    if (t < FF_C) reinterpret_cast<float*>(smem_raw + FFC_CB_OFF)[t] = p.pre_b ? p.pre_b[t] : 0.f;
+    const uint32_t fa = lds0c + (wn * 16 + l15) * 128 + ((lq ^ (l15 & 7)) << 4);
+    const uint32_t img_w = lds0c + FFC_IMG + (wm * 32 + l15) * FFC_PITCH + (wn * 16 + 4 * lq) * 2;   // + i * 16 rows, + 64 B per tile
+    const uint32_t cb_a = lds0c + FFC_CB_OFF + (wn * 16 + 4 * lq) * 4;                               // + 128 B per tile
+    // (the tile loop unrolled by hand: rr is a register array and must be indexed by constants)
+    auto run = [&](auto tlc) {
+      constexpr int tile = decltype(tlc)::value;
+      if constexpr (tile + 1 < 10) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile landed for every wave (tile 0: so has the
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                            // bias above); tile - 1's slot is free
+      if constexpr (tile + 2 < 10) ch.issue(tile + 2);
+      FF_SB();
+      const f32x4_t pb = ff_read16f<tile * 128>(cb_a);   // (waited for with the k-loop's first fragments)
+      f32x4_t acc[2];
+      ff_chain_tile(fa + (tile % 3) * FFC_WT, xf, acc);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)(acc[i][e] + pb[e] + (float)rr[tile][i][e]);   // tb_gemm's epilogue arithmetic
+        if (i == 0) ff_write8<0>(img_w + tile * 64, o);
+        else ff_write8<16 * FFC_PITCH>(img_w + tile * 64, o);
+      }
+    };
+    run(std::integral_constant<int, 0>{}); run(std::integral_constant<int, 1>{}); run(std::integral_constant<int, 2>{});
+    run(std::integral_constant<int, 3>{}); run(std::integral_constant<int, 4>{}); run(std::integral_constant<int, 5>{});
+    run(std::integral_constant<int, 6>{}); run(std::integral_constant<int, 7>{}); run(std::integral_constant<int, 8>{});
+    run(std::integral_constant<int, 9>{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the image is complete; the chain's weight slots are free
+    issue_tile(0, 0);                                                   // the feed-forward's first tile streams in under the LayerNorm
+    // ---- norm3 on the image rows, in place: four threads per row (80 columns each), tb_layernorm_fwd's two-pass arithmetic; the rows also leave for pre_Y here
+    {
+      const int lrow = t >> 2, lqr = t & 3;
+      const uint32_t la = lds0c + FFC_IMG + lrow * FFC_PITCH + lqr * 160;
+      f16x8 v[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = ff_read16<0>(la + 16 * j);
+      ff_wait_lgkm<0>();
+      FF_SB();
+      {   // t2 leaves for the residual stream from here: 160 contiguous bytes per thread, a whole 640-byte row per four lanes
+        f16* yp = (f16*)p.pre_Y + (m0 + lrow) * p.ld_prey + lqr * 80;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) *(f16x8*)(yp + 8 * j) = v[j];
+      }
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += (float)v[j][e];
+      sm += __shfl_xor(sm, 1, 64);
+      sm += __shfl_xor(sm, 2, 64);
+      const float mean = sm / (float)FF_C;
+      float qq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = (float)v[j][e] - mean;
+          qq += dlt * dlt;
+        }
+      qq += __shfl_xor(qq, 1, 64);
+      qq += __shfl_xor(qq, 2, 64);
+      const float rstd = rsqrtf(qq / (float)FF_C + p.pre_eps);
+      if (lqr == 0 && p.pre_stats) {
+        p.pre_stats[2 * (m0 + lrow)] = mean;
+        p.pre_stats[2 * (m0 + lrow) + 1] = rstd;
+      }
+      const float* gp = p.pre_gamma + lqr * 80;
+      const float* bp = p.pre_beta + lqr * 80;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const f32x4_t g0 = *(const f32x4_t*)(gp + 8 * j), g1 = *(const f32x4_t*)(gp + 8 * j + 4);
+        const f32x4_t b0 = *(const f32x4_t*)(bp + 8 * j), b1 = *(const f32x4_t*)(bp + 8 * j + 4);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (f16)(((float)v[j][e] - mean) * rstd * g0[e] + b0[e]);
+          o[4 + e] = (f16)(((float)v[j][4 + e] - mean) * rstd * g1[e] + b1[e]);
+        }
+        ff_write16<0>(la + 16 * j, o);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // l3 is in the image
+    {
+      const uint32_t img_x = lds0c + FFC_IMG + (wm * 32 + l15) * FFC_PITCH + lq * 16;   // operand fragments: + i * 16 rows, + 64 B per k-step
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) xf[i][ks] = ff_read16<0>(img_x + i * 16 * FFC_PITCH + ks * 64);
+      ff_wait_lgkm<0>();
+      FF_SB();
+    }
+  } else {
     const f16* xr = (const f16*)p.X + (m0 + wm * 32 + l15) * p.ldx + 8 * lq;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -160,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
   const uint32_t fu0 = lds0 + FF_U_OFF + wm * U_BAND + l15 * U_ROWB + (BWD ? ((lq ^ swz8) << 4) : ((lq ^ swz4) << 4));  // + i * 16 * U_ROWB
   const int uc = wn * 2 + (lq >> 1);   // 16-byte chunk of this lane's four exchange columns (backward: the dg copy is chunk uc + 4, i.e. ^ 64)
   const uint32_t uw0 = lds0 + FF_U_OFF + wm * U_BAND + l15 * U_ROWB + ((uc ^ (BWD ? swz8 : swz4)) << 4) + (lq & 1) * 8;
-  const uint32_t bias_a = lds0 + FF_BIAS_OFF + (wn * 16 + 4 * lq) * 4;
+  const uint32_t bias_a = lds0 + BIAS_OFF + (wn * 16 + 4 * lq) * 4;
   f16* const hg_lane = (f16*)p.HG + (m0 + wm * 32 + l15) * p.ldhg + wn * 16 + 4 * lq;
 
 #if FF_PROF
@@ -320,8 +508,12 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's dummy prefetch
   // ---- epilogue: rows 32 wm + 16 i + l15, columns wn 160 + 16 jj + 4 lq .. + 3
-  const int64_t mrow = m0 + wm * 32 + l15;
-  const int ncol = wn * 160 + 4 * lq;
+  // (PRE + POST: the two stages compute the same lane constants; left to itself hipcc keeps PRE's copies alive ACROSS the main loop for POST --
+  // the loop sits at 248 of 256 registers -- and spills inside it, +30 us.  Opaque copies of the lane indices cut the common subexpressions.)
+  int l15e = l15, lqe = lq;
+  if constexpr (PRE && POST) asm volatile("" : "+v"(l15e), "+v"(lqe));
+  const int64_t mrow = m0 + wm * 32 + l15e;
+  const int ncol = wn * 160 + 4 * lqe;
   if constexpr (BWD) {
     if (p.ln_x) {
       // LayerNorm backward of norm3 on the accumulators (round 5; it had been a launch of its own since the feed-forward was fused): the 320-wide row of
@@ -384,6 +576,18 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
       return;
     }
   }
+  const uint32_t lds0c = ff_lds_addr(smem_raw);
+  f16x4 qr[10][2];   // POST: proj_out's residual (the block input) for this lane's (row, tile) units -- requested here, waited for with rv below
+  if constexpr (POST) {
+    // every wave has left the main loop (ring slot 1 and the exchange buffer lie under the image) and the dummy prefetch into slot 0 has landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int tl = 0; tl < 10; ++tl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        qr[tl][i] = p.post_R ? *(const f16x4*)((const f16*)p.post_R + (mrow + 16 * i) * p.ld_postr + tl * 32 + wn * 16 + 4 * lqe) : f16x4{0, 0, 0, 0};
+    if (t < FF_C) reinterpret_cast<float*>(smem_raw + FFC_CB_OFF)[t] = p.post_b ? p.post_b[t] : 0.f;   // (t: live anyway)
+  }
   f16x4 rv[2][10];
   if (p.R) {
 #pragma unroll
@@ -391,6 +595,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
 #pragma unroll
       for (int jj = 0; jj < 10; ++jj) rv[i][jj] = *(const f16x4*)((const f16*)p.R + (mrow + 16 * i) * p.ldr + ncol + 16 * jj);
   }
+  const uint32_t img_o = lds0c + FFC_IMG + (wm * 32 + l15e) * FFC_PITCH + (wn * 160 + 4 * lqe) * 2;   // + i * 16 rows, + 32 B per jj
 #pragma unroll
   for (int jj = 0; jj < 10; ++jj) {
     f32x4_t b = {0.f, 0.f, 0.f, 0.f};
@@ -404,27 +609,100 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
         if (p.R) v += (float)rv[i][jj][e];
         o[e] = (f16)v;
       }
-      *(f16x4*)((f16*)p.Y + (mrow + 16 * i) * p.ldy + ncol + 16 * jj) = o;
+      if (!POST || p.Y) *(f16x4*)((f16*)p.Y + (mrow + 16 * i) * p.ldy + ncol + 16 * jj) = o;
+      if constexpr (POST) {
+        if (i == 0) ff_write8<0>(img_o + jj * 32, o);
+        else ff_write8<16 * FFC_PITCH>(img_o + jj * 32, o);
+      }
+    }
+  }
+  if constexpr (POST) {
+    // ---- proj_out + bias + the block input: t3 (fp16, as the separate launch would have read it back) -> operand -> ten tiles -> the image again
+    // (the output tile by tile, fp16) -> post_Y in whole rows
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the image is complete; nothing of this wave is on the memory queue
+    const FfChain ch(smem_raw, p.post_W, p.ld_postw, wave, lane);
+    ch.issue(0);
+    ch.issue(1);
+    {
+      const uint32_t img_x = lds0c + FFC_IMG + (wm * 32 + l15e) * FFC_PITCH + lqe * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) xf[i][ks] = ff_read16<0>(img_x + i * 16 * FFC_PITCH + ks * 64);
+      ff_wait_lgkm<0>();
+      FF_SB();
+    }
+    const uint32_t fa = lds0c + (wn * 16 + l15e) * 128 + ((lqe ^ (l15e & 7)) << 4);
+    const uint32_t img_w = lds0c + FFC_IMG + (wm * 32 + l15e) * FFC_PITCH + (wn * 16 + 4 * lqe) * 2;
+    const uint32_t cb_a = lds0c + FFC_CB_OFF + (wn * 16 + 4 * lqe) * 4;
+    auto run = [&](auto tlc) {
+      constexpr int tile = decltype(tlc)::value;
+      // (tile 0's barrier also orders every wave's operand reads of the image in front of the first output write into it)
+      if constexpr (tile + 1 < 10) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (tile + 2 < 10) ch.issue(tile + 2);
+      FF_SB();
+      const f32x4_t pb = ff_read16f<tile * 128>(cb_a);
+      f32x4_t acc[2];
+      ff_chain_tile(fa + (tile % 3) * FFC_WT, xf, acc);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)(acc[i][e] + pb[e] + (float)qr[tile][i][e]);
+        if (i == 0) ff_write8<0>(img_w + tile * 64, o);
+        else ff_write8<16 * FFC_PITCH>(img_w + tile * 64, o);
+      }
+    };
+    run(std::integral_constant<int, 0>{}); run(std::integral_constant<int, 1>{}); run(std::integral_constant<int, 2>{});
+    run(std::integral_constant<int, 3>{}); run(std::integral_constant<int, 4>{}); run(std::integral_constant<int, 5>{});
+    run(std::integral_constant<int, 6>{}); run(std::integral_constant<int, 7>{}); run(std::integral_constant<int, 8>{});
+    run(std::integral_constant<int, 9>{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the output image is complete
+    {
+      int te = t;
+      if constexpr (PRE && POST) asm volatile("" : "+v"(te));
+      const int lrow = te >> 2, lqr = te & 3;
+      const uint32_t la = lds0c + FFC_IMG + lrow * FFC_PITCH + lqr * 160;
+      f16x8 v[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = ff_read16<0>(la + 16 * j);
+      ff_wait_lgkm<0>();
+      FF_SB();
+      f16* yp = (f16*)p.post_Y + (m0 + lrow) * p.ld_posty + lqr * 80;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) *(f16x8*)(yp + 8 * j) = v[j];
     }
   }
 }
 
-template <bool BWD>
+template <bool BWD, bool PRE = false, bool POST = false>
 int ff_launch(const tb_ff_desc& d, hipStream_t s) {
+  constexpr int LDS = (PRE || POST) ? FFC_LDS : FF_LDS;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)ff_fused_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess) return TB_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)ff_fused_kernel<BWD, PRE, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return TB_ELAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL((ff_fused_kernel<BWD>), dim3((unsigned)(d.M / FF_BM)), dim3(512), FF_LDS, s, d);
+  hipLaunchKernelGGL((ff_fused_kernel<BWD, PRE, POST>), dim3((unsigned)(d.M / FF_BM)), dim3(512), LDS, s, d);
   TB_CHECK_LAUNCH();
   return TB_OK;
 }
 
 int ff_check(const tb_ff_desc* d, bool bwd) {
   if (!d || !tb_ff_fused_ok(d->M, d->C, d->inner)) return TB_EINVAL;
-  if (!d->X || !d->W1 || !d->W2 || !d->HG || !d->Y) return TB_EINVAL;
-  if (d->ldx % 8 || d->ldw1 % 8 || d->ldw2 % 8 || d->ldhg % 4 || d->ldy % 4 || (d->R && d->ldr % 4)) return TB_EINVAL;
+  if (!d->X || !d->W1 || !d->W2 || !d->HG || (!d->Y && !(d->post_W && !bwd))) return TB_EINVAL;
+  if (bwd && (d->pre_W || d->post_W)) return TB_EINVAL;   // the chained stages exist in the forward only
+  if (d->pre_W && (!d->pre_Y || !d->pre_gamma || !d->pre_beta || d->ld_prew % 8 || d->ld_prey % 8 || (d->pre_R && d->ld_prer % 4) ||
+                   ((uintptr_t)d->pre_W) % 16 || ((uintptr_t)d->pre_Y) % 16 || ((uintptr_t)d->pre_R) % 8 || ((uintptr_t)d->pre_b) % 16 ||
+                   ((uintptr_t)d->pre_gamma) % 16 || ((uintptr_t)d->pre_beta) % 16 || ((uintptr_t)d->pre_stats) % 8 ||
+                   (int64_t)FF_C * d->ld_prew * 2 >= ((int64_t)1 << 31)))
+    return TB_EINVAL;
+  if (d->post_W && (!d->post_Y || d->ld_postw % 8 || d->ld_posty % 8 || (d->post_R && d->ld_postr % 4) || ((uintptr_t)d->post_W) % 16 ||
+                    ((uintptr_t)d->post_Y) % 16 || ((uintptr_t)d->post_R) % 8 || ((uintptr_t)d->post_b) % 16 ||
+                    (int64_t)FF_C * d->ld_postw * 2 >= ((int64_t)1 << 31)))
+    return TB_EINVAL;
+  if (d->ldx % 8 || d->ldw1 % 8 || d->ldw2 % 8 || d->ldhg % 4 || (d->Y && d->ldy % 4) || (d->R && d->ldr % 4)) return TB_EINVAL;
   if (((uintptr_t)d->X) % 16 || ((uintptr_t)d->W1) % 16 || ((uintptr_t)d->W2) % 16 || ((uintptr_t)d->HG) % 8 || ((uintptr_t)d->Y) % 8 ||
       ((uintptr_t)d->R) % 8 || ((uintptr_t)d->b2) % 16)
     return TB_EINVAL;
@@ -447,6 +725,9 @@ extern "C" int tb_ff_fwd(const tb_ff_desc* d, tb_stream_t stream) {
   (void)hipGetLastError();
   const int r = ff_check(d, false);
   if (r != TB_OK) return r;
+  if (d->pre_W && d->post_W) return ff_launch<false, true, true>(*d, (hipStream_t)stream);
+  if (d->pre_W) return ff_launch<false, true, false>(*d, (hipStream_t)stream);
+  if (d->post_W) return ff_launch<false, false, true>(*d, (hipStream_t)stream);
   return ff_launch<false>(*d, (hipStream_t)stream);
 }
 

@@ -577,16 +577,44 @@ def _ff_desc(x, w1, w2, hg, y, R, b1=None, b2=None):
     return d
 
 
-def ff_fwd(x, w1p, b1p, w2, b2, hg, y, R=None):
+def ff_fwd(x, w1p, b1p, w2, b2, hg, y, R=None, pre=None, post=None):
     """BasicTransformerBlock.ff in one launch: hg[M, 2 inner] = x @ w1p^T + b1p (packed [h32|g32] rows, kept for the backward),
-    y = (h * gelu(g)) @ w2^T + b2 (+ R).  Same operands as gemm(act=ACT_GEGLU, C2=hg) followed by gemm(R=...)."""
+    y = (h * gelu(g)) @ w2^T + b2 (+ R).  Same operands as gemm(act=ACT_GEGLU, C2=hg) followed by gemm(R=...).
+    Round 6 -- the feed-forward's row-local neighbours ride in the same launch:
+      pre  = (W, b, R_in, t_out, gamma, beta, stats, eps): x is the input of one more Linear in FRONT: t_out = x @ W^T + b (+ R_in) is stored (the
+             residual stream), LayerNorm(t_out; gamma, beta, eps) feeds ff.net.0.proj straight from the LDS, stats [M, 2] gets (mean, rstd); pass
+             R = t_out for the feed-forward's own residual (attn2.to_out.0 + residual, norm3, ff of diffusers BasicTransformerBlock);
+      post = (W, b, R_out, out): out = (ff result) @ W^T + b (+ R_out) -- Transformer2DModel.proj_out + the block input; y may then be None."""
     M, C = x.shape
     inner = hg.shape[1] // 2
-    d = _ff_desc(x, w1p, w2, hg, y, R, b1p, b2)
-    byt = 2.0 * (M * C + 3 * C * inner + M * 2 * inner + M * C * (2 if R is not None else 1))
-    with _rec("ff_fused_kernel<false>", 2.0 * M * C * 3 * inner, byt):
+    d = _ff_desc(x, w1p, w2, hg, y if y is not None else x, R, b1p, b2)
+    if y is None:
+        assert post is not None
+        d.Y, d.ldy = None, 0
+    flops, byt = 2.0 * M * C * 3 * inner, 2.0 * (M * C + 3 * C * inner + M * 2 * inner + M * C * (2 if R is not None else 1))
+    name = "ff_fused_kernel<false>"
+    if pre is not None:
+        W_, b_, Rin_, t_, g_, be_, st_, eps_ = pre
+        assert W_.shape == (C, C) and t_.shape == (M, C)
+        d.pre_W, d.ld_prew, d.pre_b = L.ptr(W_), W_.stride(0), L.ptr(b_)
+        d.pre_R, d.ld_prer = L.ptr(Rin_), (Rin_.stride(0) if Rin_ is not None else 0)
+        d.pre_Y, d.ld_prey = L.ptr(t_), t_.stride(0)
+        d.pre_gamma, d.pre_beta, d.pre_stats, d.pre_eps = L.ptr(g_), L.ptr(be_), L.ptr(st_), eps_
+        flops += 2.0 * M * C * C
+        byt += 2.0 * (C * C + M * C * (2 if Rin_ is not None else 1))
+        name = "ff_fused_kernel<false, chain>"
+    if post is not None:
+        W_, b_, Rout_, o_ = post
+        assert W_.shape == (C, C) and o_.shape == (M, C)
+        d.post_W, d.ld_postw, d.post_b = L.ptr(W_), W_.stride(0), L.ptr(b_)
+        d.post_R, d.ld_postr = L.ptr(Rout_), (Rout_.stride(0) if Rout_ is not None else 0)
+        d.post_Y, d.ld_posty = L.ptr(o_), o_.stride(0)
+        flops += 2.0 * M * C * C
+        byt += 2.0 * (C * C + M * C * (2 if Rout_ is not None else 1)) - (2.0 * M * C if y is None else 0.0)
+        name = "ff_fused_kernel<false, chain>"
+    with _rec(name, flops, byt):
         L.check(L.lib().tb_ff_fwd(d, L.stream()), "tb_ff_fwd")
-    return y
+    return y if post is None else post[3]
 
 
 def ff_bwd(dy, w2d, w1d, hg, dx, R=None, ln=None):

@@ -33,6 +33,9 @@ FUSE_GEGLU_BWD = _os.environ.get("TB_FUSE_GEGLU_BWD", "1") == "1"
 # the whole GEGLU feed-forward of the C = 320 blocks as one launch per direction (csrc/ff_fused.hip): the gated tensor / d(proj) never go to memory
 FUSE_FF = _os.environ.get("TB_FUSE_FF", "1") == "1"
 FUSE_FF_LN = _os.environ.get("TB_FUSE_FF_LN", "1") == "1"   # the fused feed-forward backward also applies norm3's LayerNorm backward (A/B switch)
+# round 6: the fused feed-forward's launch also runs its row-local neighbours (ops.ff_fwd pre / post): bit 1 = attn2.to_out + residual + norm3 in
+# front, bit 2 = proj_out + residual behind (A/B switch)
+FF_CHAIN = int(_os.environ.get("TB_FF_CHAIN", "3"))
 MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  # A/B switch (see the up-block forward)
 # LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
 # residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
@@ -461,8 +464,14 @@ class HipUNet:
         # --- GEGLU feed-forward
         ls3 = self.buf(prefix + ".ls3", M, 2, torch.float32)
         l3 = None
+        fuse_ff = FUSE_FF and not fold and ops.ff_fused_ok(M, C, 4 * C, self.dtype)
+        # round 6 (FF_CHAIN bits: 1 = attn2.to_out + residual + norm3 in FRONT of the fused feed-forward, 2 = proj_out + residual BEHIND it, in the same
+        # launch): a 128-row tile spans the 320-wide rows of all four layers, so l3 and t3 never leave the CU
+        chain = FF_CHAIN if (fuse_ff and fuse_ln and self.dtype != torch.float32) else 0
         if fold:
             ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1, rs_out=rs, rs_slots=fold)
+        elif chain & 1:
+            pass   # (issued with the feed-forward below)
         else:
             l3 = self.scratch("a", M, C)
             if fuse_ln:
@@ -472,8 +481,13 @@ class HipUNet:
                 ops.gemm(o2, P[tb + ".attn2.to_out.0.w"], t2, bias=P[tb + ".attn2.to_out.0.b"], R=t1)
                 ops.layernorm_fwd(t2, l3, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3)
         raw = self.buf(prefix + ".raw", M, 8 * C)
-        fuse_ff = FUSE_FF and not fold and ops.ff_fused_ok(M, C, 4 * C, self.dtype)
-        if fold:
+        if chain:
+            pre = (P[tb + ".attn2.to_out.0.w"], P[tb + ".attn2.to_out.0.b"], t1, t2, P[tb + ".norm3.g"], P[tb + ".norm3.b"], ls3, 1e-5) if chain & 1 else None
+            post = (P[prefix + ".proj_out.w"], P[prefix + ".proj_out.b"], x, out) if chain & 2 else None
+            t3 = None if chain & 2 else self.scratch("a2", M, C)
+            ops.ff_fwd(o2 if chain & 1 else l3, P[tb + ".ff1.w"], P[tb + ".ff1.b"], P[tb + ".ff.net.2.w"], P[tb + ".ff.net.2.b"], raw, t3, R=t2,
+                       pre=pre, post=post)
+        elif fold:
             gated = self.scratch("b", M, 4 * C)
             ops.gemm(t2, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.c2"], act=L.ACT_GEGLU, C2=raw, lnfold=(rs, fold, P[tb + ".ff1.c1"], ls3, 1e-5))
             t3 = self.scratch("a", M, C)
@@ -486,7 +500,8 @@ class HipUNet:
             ops.gemm(l3, P[tb + ".ff1.w"], gated, bias=P[tb + ".ff1.b"], act=L.ACT_GEGLU, C2=raw)
             t3 = self.scratch("a", M, C)
             ops.gemm(gated, P[tb + ".ff.net.2.w"], t3, bias=P[tb + ".ff.net.2.b"], R=t2)
-        ops.gemm(t3, P[prefix + ".proj_out.w"], out, bias=P[prefix + ".proj_out.b"], R=x)
+        if not (chain & 2):
+            ops.gemm(t3, P[prefix + ".proj_out.w"], out, bias=P[prefix + ".proj_out.b"], R=x)
         stop_after_cross = (tb + ".attn2") == self.first_xattn
 
         def bwd(dout, dx):
