@@ -177,6 +177,24 @@ typedef struct tb_ff_desc {
 int tb_ff_fused_ok(int64_t M, int C, int inner);
 int tb_ff_fwd(const tb_ff_desc* d, tb_stream_t stream);
 int tb_ff_bwd(const tb_ff_desc* d, tb_stream_t stream);
+/* Linear -> LayerNorm -> Linear on 128-row tiles of a C = 320 residual stream in ONE launch (round 6, csrc/chain320.hip): the pairs
+ * proj_in -> norm1 -> attn1.to_q|to_k|to_v and attn1.to_out.0 + residual -> norm2 -> attn2.to_q of diffusers Transformer2DModel /
+ * BasicTransformerBlock on the SD1.x 64x64 maps (train_textboost.py:1063-1067); replaces tb_gemm(TB_ACT_LN_FWD) + tb_gemm.
+ *     T = X W1^T + b1 (+ R1)                      fp16 [M, 320], stored (the residual stream; NULL: not stored)
+ *     stats[m] = (mean, rstd) of the fp16 row T[m]   two-pass, fp32 (NULL: not stored)
+ *     Y = LayerNorm(T; gamma, beta, eps) W2^T + b2   fp16 [M, N2];  LayerNorm(T) itself never exists in memory
+ * W1 fp16 [320, 320], W2 fp16 [N2, 320] row-major (out, in), rows 16-byte aligned.  tb_chain320_ok: M % 128 == 0, N2 a multiple of 320 (<= 2560). */
+typedef struct tb_chain_desc {
+  int64_t M;
+  const void* X; int64_t ldx;
+  const void* W1; int64_t ldw1; const float* b1; const void* R1; int64_t ldr1;
+  void* T; int64_t ldt;
+  const float* gamma; const float* beta; float eps; float* stats;
+  const void* W2; int64_t ldw2; int32_t N2; const float* b2;
+  void* Y; int64_t ldy;
+} tb_chain_desc;
+int tb_chain320_ok(int64_t M, int N2);
+int tb_chain320(const tb_chain_desc* d, tb_stream_t stream);
 /* profiling aid (builds with -DFF_PROF=1 only): device buffer of 16 x uint64 (NULL = off) that receives per-phase s_memtime sums of waves 0 and 4 of workgroup 0 */
 int tb_ff_debug(void* buf16);
 

@@ -48,3 +48,14 @@ def chain(mode):
 for name, fn in (("attn2.to_out + LN3 (gemm8 LN epilogue)", pre_old), ("ff_fwd", ff_old), ("proj_out (lin320)", post_old),
                  ("ff_fwd + pre", chain(1)), ("ff_fwd + post", chain(2)), ("ff_fwd + pre + post", chain(3))):
     print(f"{name:44s} {timeit(fn):7.1f} us")
+# ---- the Linear -> LayerNorm -> Linear pairs
+for N2 in (960, 320):
+    w2c = (torch.randn(N2, C, device=dev) / C ** 0.5).half()
+    ys = [torch.empty(M, N2, device=dev, dtype=torch.float16) for _ in range(NB)]
+    def old1():
+        b = nxt(); ops.gemm(b["o2"], wpre, b["t2"], bias=bpre, R=b["t1"] if N2 == 320 else None, ln_fwd=(gamma, beta, b["st"], b["l3"], 1e-5))
+    def old2():
+        b = nxt(); ops.gemm(b["l3"], w2c, ys[k[0]])
+    def new():
+        b = nxt(); ops.chain320(b["o2"], wpre, bpre, b["t1"] if N2 == 320 else None, b["t2"], gamma, beta, b["st"], w2c, None, ys[k[0]])
+    print(f"N2={N2}: Linear+LN epilogue {timeit(old1):6.1f} us + Linear {timeit(old2):6.1f} us   ->  chain320 {timeit(new):6.1f} us")

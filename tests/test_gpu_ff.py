@@ -203,3 +203,50 @@ def test_ff_fused_rejects_what_it_does_not_cover():
     d = L.FfDesc()
     d.M, d.C, d.inner = 100, C, INNER
     assert L.lib().tb_ff_fwd(d, None) == -22 and L.lib().tb_ff_bwd(d, None) == -22
+
+
+@pytest.mark.parametrize("M,N2,with_r", [(128, 320, True), (384, 960, False), (4096, 320, False), (32768, 960, False), (32768, 320, True)])
+def test_linear_layernorm_linear_in_one_launch(M, N2, with_r):
+    """round 6 (tb_chain320, csrc/chain320.hip): proj_in -> norm1 -> attn1.qkv (N2 = 960) and attn1.to_out + residual -> norm2 -> attn2.to_q (N2 = 320)
+    of a 64x64-map transformer block (diffusers Transformer2DModel / BasicTransformerBlock, train_textboost.py:1063-1067) as ONE launch -- against torch
+    fp32 on the fp16-rounded residual stream and against the two launches it replaces (tb_gemm with the LayerNorm epilogue + tb_gemm); strided views."""
+    ops, L = _ops()
+    assert ops.chain320_ok(M, N2) and not ops.chain320_ok(M + 64, N2) and not ops.chain320_ok(M, 480)
+    torch.manual_seed(M + N2)
+    g = torch.Generator().manual_seed(21)
+    w1 = (torch.randn(C, C, generator=g) / C ** 0.5).half().cuda()
+    b1 = (torch.randn(C, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(N2, C, generator=g) / C ** 0.5).half().cuda()
+    b2 = (torch.randn(N2, generator=g) * 0.3).cuda() if N2 == 320 else None        # (the qkv projection has no bias)
+    gamma, beta = 1 + 0.4 * torch.randn(C, device="cuda"), 0.2 * torch.randn(C, device="cuda")
+    x = torch.randn(M, C, device="cuda").half()
+    R = (torch.randn(M, C, device="cuda") * 0.8 + torch.randn(M, 1, device="cuda") * 0.5).half() if with_r else None
+    tbuf = torch.full((M, C + 8), 7.0, device="cuda", dtype=torch.float16)
+    ybuf = torch.full((M, N2 + 16), 7.0, device="cuda", dtype=torch.float16)
+    t, y = tbuf[:, :C], ybuf[:, 8:8 + N2]
+    st = torch.zeros(M, 2, device="cuda")
+    ops.chain320(x, w1, b1, R, t, gamma, beta, st, w2, b2, y)
+    t_ref = x.float() @ w1.float().T + b1 + (R.float() if with_r else 0)
+    th = t_ref.half().float()
+    l_ref = F.layer_norm(th, (C,), gamma, beta, 1e-5).half().float()
+    y_ref = l_ref @ w2.float().T + (b2 if b2 is not None else 0)
+    parity("chain320: t = x W1^T + b (+ R)", t, t_ref, 1e-3, 2e-3, ch_dim=1, ch_rel=2e-3)
+    assert torch.allclose(st[:, 0], th.mean(1), rtol=1e-4, atol=2e-4) and torch.allclose(st[:, 1], (th.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=3e-4, atol=0)
+    parity("chain320: y = LN(t) W2^T + b", y, y_ref, 2e-3, 4e-3, ch_dim=1, ch_rel=3e-3)
+    assert (tbuf[:, C:] == 7).all() and (ybuf[:, :8] == 7).all() and (ybuf[:, 8 + N2:] == 7).all()
+    # the launches it replaces
+    t_old = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    l_old = torch.empty(M, C, device="cuda", dtype=torch.float16)
+    st_old = torch.empty(M, 2, device="cuda")
+    if ops.gemm_ln_ok(M, C, C):
+        ops.gemm(x, w1, t_old, bias=b1, R=R, ln_fwd=(gamma, beta, st_old, l_old, 1e-5))
+    else:
+        ops.gemm(x, w1, t_old, bias=b1, R=R)
+        ops.layernorm_fwd(t_old, l_old, gamma, beta, st_old)
+    y_old = torch.empty(M, N2, device="cuda", dtype=torch.float16)
+    ops.gemm(l_old, w2, y_old, bias=b2)
+    assert rel_err(t, t_old) < 3e-4 and torch.allclose(st, st_old, rtol=5e-4, atol=3e-4)
+    assert rel_err(y, y_old) < 1.5e-3   # (a 1-ulp difference of a t element moves its whole LayerNorm row by an fp16 ulp)
+    d = L.ChainDesc()
+    d.M, d.N2 = 100, 320
+    assert L.lib().tb_chain320(d, None) == -22

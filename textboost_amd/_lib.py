@@ -88,6 +88,19 @@ class FfDesc(C.Structure):
     ]
 
 
+class ChainDesc(C.Structure):
+    """tb_chain_desc (include/textboost_hip.h): Linear -> LayerNorm -> Linear on the C = 320 residual stream in one launch"""
+    _fields_ = [
+        ("M", C.c_int64),
+        ("X", C.c_void_p), ("ldx", C.c_int64),
+        ("W1", C.c_void_p), ("ldw1", C.c_int64), ("b1", C.c_void_p), ("R1", C.c_void_p), ("ldr1", C.c_int64),
+        ("T", C.c_void_p), ("ldt", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("stats", C.c_void_p),
+        ("W2", C.c_void_p), ("ldw2", C.c_int64), ("N2", C.c_int32), ("b2", C.c_void_p),
+        ("Y", C.c_void_p), ("ldy", C.c_int64),
+    ]
+
+
 class OptDesc(C.Structure):
     """tb_opt_desc (include/textboost_hip.h): the optimizer tail as two launches"""
     _fields_ = [
@@ -118,6 +131,8 @@ _SIGS = {
     "tb_ff_fwd": ([C.POINTER(FfDesc), _VP], C.c_int),
     "tb_ff_bwd": ([C.POINTER(FfDesc), _VP], C.c_int),
     "tb_ff_debug": ([_VP], C.c_int),
+    "tb_chain320_ok": ([C.c_int64, _I], C.c_int),
+    "tb_chain320": ([C.POINTER(ChainDesc), _VP], C.c_int),
     "tb_last_hip_error": ([], C.c_char_p),
     "tb_mfma_peak_probe": ([_VP, _I, _I, _VP], C.c_int),
     "tb_gemm_set_variant": ([_I], C.c_int),

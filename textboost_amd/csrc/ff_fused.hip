@@ -24,42 +24,10 @@
 // W2 / u tiles use chunk ^= SWZ4[(row >> 2) & 3] with SWZ4 = {0, 2, 3, 1} (every 16-lane group of a ds_read_b128 then touches all 64 banks once).
 // All LDS accesses inside the main loop are inline asm: hipcc cannot prove that a read does not alias an LDS-DMA destination and drains
 // vmcnt(0) -- the prefetched tile -- in front of every compiler-visible LDS access.
-#include "gemm_epi.h"
-#include <type_traits>
+#include "ff_chain.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-constexpr int FF_C = 320, FF_INNER = 1280, FF_BM = 128, FF_NT = FF_INNER / 32;   // 40 tiles of 32 intermediate columns
-constexpr int FF_SLOT = 60 * 1024;            // one ring slot: phase-A weight tile + phase-B weight tile
-constexpr int FF_NDMA = 60;                   // LDS-DMA wave instructions (1 KB each) per tile
-constexpr int FF_U_OFF = 2 * FF_SLOT;         // exchange buffer: forward [4][32][32] fp16 (8 KB), backward [4][32][64] fp16 (16 KB)
-constexpr int FF_BIAS_OFF = FF_U_OFF + 16 * 1024;   // forward: the packed proj bias, 2560 floats
-constexpr int FF_LDS = FF_BIAS_OFF + 2 * FF_INNER * 4;
-
-__device__ __forceinline__ uint32_t ff_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
-template <int OFF>
-__device__ __forceinline__ f16x8 ff_read16(uint32_t addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-template <int OFF>
-__device__ __forceinline__ f32x4_t ff_read16f(uint32_t addr) {
-  f32x4_t v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-template <int OFF>
-__device__ __forceinline__ void ff_write8(uint32_t addr, f16x4 v) {
-  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void ff_wait_lgkm() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-#define FF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifndef FF_DMAC
 #define FF_DMAC 1   // 0 (TB_CFLAGS=-DFF_DMAC=0): the tile's LDS-DMA pieces in front of phase A, as in round 4
 #endif
@@ -78,78 +46,6 @@ __device__ unsigned long long* g_ff_dbg = nullptr;
 #define FF_PF(k)
 #endif
 
-// ---- round 6: the feed-forward's row-local neighbours in the same launch (tb_ff_desc.pre_W / post_W; forward only).
-// A "chain stage" is one more [128 x 320] x [320 x 320]^T product on the workgroup's rows with the 128 x 320 operand in the SAME 80 registers the
-// feed-forward keeps its input in: ten 32-column weight tiles (20 KB each, the backward's phase-A image: five [32 rows][128 B] slabs, chunk ^= row & 7)
-// through two LDS slots at the bottom of ring slot 0, phase A's k-loop per tile (20 MFMAs per wave), a per-tile epilogue on (rows 32 wm + 16 i + l15,
-// columns 32 tile + 16 wn + 4 lq .. + 3).  Results change hands through a [128][320] fp16 LDS IMAGE (656-byte pitch: the b128 reads of 16 consecutive
-// rows at one column land on 16 distinct bank quads) behind ring slot 0, from which the next product's operand fragments are read back:
-//   PRE : X -> t2 = X Wpre^T + b (+ R) -> pre_Y and the image -> two-pass LayerNorm of the image rows in place (+ stats) -> the feed-forward's operand
-//   POST: t3 = ff + b2 + R -> the image (-> Y when asked for) -> operand -> post_Y = t3 Wpost^T + b (+ R)
-constexpr int FFC_WT = 5 * 32 * 128;                      // one chain weight tile: 20 KB
-constexpr int FFC_IMG = 60 * 1024, FFC_PITCH = 656;       // the image: [60 KB, 60 KB + 128 * 656) = up to 142 KB (over slot 1 and the exchange buffer)
-constexpr int FFC_BIAS_OFF = 146 * 1024;                  // the packed proj bias of the chained launches sits behind it
-constexpr int FFC_CB_OFF = FFC_BIAS_OFF + 2 * FF_INNER * 4;   // 156 KB: a chain stage's own bias (320 floats)
-constexpr int FFC_LDS = FFC_CB_OFF + FF_C * 4;
-static_assert(FFC_IMG + FF_BM * FFC_PITCH <= FFC_BIAS_OFF && 3 * FFC_WT <= FFC_IMG && FFC_LDS <= 160 * 1024, "chain LDS map");
-template <int OFF>
-__device__ __forceinline__ void ff_write16(uint32_t addr, f16x8 v) {
-  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-
-// One chain stage's weight stream: every wave issues exactly THREE 1 KB pieces per 20 KB tile (q = wave, wave + 8, wave + 16; waves 4-7 have only
-// two and repeat their second: same bytes to the same place), so that the counted waits below are wave-independent.  Three ring slots at the bottom
-// of the LDS; tile t lives in slot t % 3 and is requested two tiles ahead: a tile's k-loop is ~0.3 us, an L2 round trip ~1 us.
-struct FfChain {
-  uint32_t off[3], dst[3];
-  const char* W;
-  int64_t tile_stride;
-  unsigned char* smem;
-  __device__ __forceinline__ FfChain(unsigned char* smem_raw, const void* W_, int64_t ldw, int wave, int lane) {
-    smem = smem_raw, W = (const char*)W_, tile_stride = 32 * ldw * 2;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int q = wave + 8 * k < 20 ? wave + 8 * k : wave + 8 * (k - 1);
-      const int sl = q >> 2, rgp = q & 3;
-      const int row = rgp * 8 + (lane >> 3), cc = (lane & 7) ^ (lane >> 3);
-      off[k] = (uint32_t)(((int64_t)row * ldw + sl * 64 + cc * 8) * 2);
-      dst[k] = (uint32_t)(sl * 4096 + rgp * 1024);
-    }
-  }
-  __device__ __forceinline__ void issue(int tile) const {
-    const char* base = W + tile * tile_stride;
-    unsigned char* slot = smem + (tile % 3) * FFC_WT;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) glds16((const f16*)(base + off[k]), reinterpret_cast<f16*>(slot + dst[k]));
-  }
-};
-// acc = X[rows 32 wm + 16 i + l15] . Wtile^T (columns 16 wn + 4 lq .. + 3 of the tile): phase A of the backward on the 20 KB image at `slot_addr`
-__device__ __forceinline__ void ff_chain_tile(uint32_t a0, const f16x8 (&xf)[2][10], f32x4_t (&acc)[2]) {
-  const uint32_t a1 = a0 ^ 64;
-  acc[0] = f32x4_t{0.f, 0.f, 0.f, 0.f}, acc[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  f16x8 wf[3];
-  auto rd = [&](auto ksc) {
-    constexpr int ks = decltype(ksc)::value;
-    wf[ks % 3] = ff_read16<(ks >> 1) * 4096>((ks & 1) ? a1 : a0);
-  };
-  rd(std::integral_constant<int, 0>{});
-  rd(std::integral_constant<int, 1>{});
-  FF_SB();
-  auto step = [&](auto ksc) {
-    constexpr int ks = decltype(ksc)::value;
-    if constexpr (ks + 2 < 10) rd(std::integral_constant<int, ks + 2>{});
-    constexpr int later = (ks + 2 < 10 ? 1 : 0) + (ks + 1 < 10 ? 1 : 0);
-    ff_wait_lgkm<later>();
-    FF_SB();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) acc[i] = TB_MFMA_16x16x32(wf[ks % 3], xf[i][ks], acc[i]);
-    FF_SB();
-  };
-  step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-  step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-  step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-  step(std::integral_constant<int, 9>{});
-}
 template <bool BWD, bool PRE = false, bool POST = false>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
   static_assert(!BWD || (!PRE && !POST), "the chained stages exist in the forward only");
@@ -237,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
       for (int i = 0; i < 2; ++i)
         rr[tl][i] = p.pre_R ? *(const f16x4*)((const f16*)p.pre_R + (row0 + 16 * i) * p.ld_prer + tl * 32 + wn * 16 + 4 * lq) : f16x4{0, 0, 0, 0};
     if (t < FF_C) reinterpret_cast<float*>(smem_raw + FFC_CB_OFF)[t] = p.pre_b ? p.pre_b[t] : 0.f;
+    ff_chain_stage_gamma_beta(smem_raw, t, p.pre_gamma, p.pre_beta);
     const uint32_t fa = lds0c + (wn * 16 + l15) * 128 + ((lq ^ (l15 & 7)) << 4);
     const uint32_t img_w = lds0c + FFC_IMG + (wm * 32 + l15) * FFC_PITCH + (wn * 16 + 4 * lq) * 2;   // + i * 16 rows, + 64 B per tile
     const uint32_t cb_a = lds0c + FFC_CB_OFF + (wn * 16 + 4 * lq) * 4;                               // + 128 B per tile
@@ -265,58 +162,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const tb_ff_desc p) {
     run(std::integral_constant<int, 9>{});
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the image is complete; the chain's weight slots are free
     issue_tile(0, 0);                                                   // the feed-forward's first tile streams in under the LayerNorm
-    // ---- norm3 on the image rows, in place: four threads per row (80 columns each), tb_layernorm_fwd's two-pass arithmetic; the rows also leave for pre_Y here
-    {
-      const int lrow = t >> 2, lqr = t & 3;
-      const uint32_t la = lds0c + FFC_IMG + lrow * FFC_PITCH + lqr * 160;
-      f16x8 v[10];
-#pragma unroll
-      for (int j = 0; j < 10; ++j) v[j] = ff_read16<0>(la + 16 * j);
-      ff_wait_lgkm<0>();
-      FF_SB();
-      {   // t2 leaves for the residual stream from here: 160 contiguous bytes per thread, a whole 640-byte row per four lanes
-        f16* yp = (f16*)p.pre_Y + (m0 + lrow) * p.ld_prey + lqr * 80;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) *(f16x8*)(yp + 8 * j) = v[j];
-      }
-      float sm = 0.f;
-#pragma unroll
-      for (int j = 0; j < 10; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sm += (float)v[j][e];
-      sm += __shfl_xor(sm, 1, 64);
-      sm += __shfl_xor(sm, 2, 64);
-      const float mean = sm / (float)FF_C;
-      float qq = 0.f;
-#pragma unroll
-      for (int j = 0; j < 10; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float dlt = (float)v[j][e] - mean;
-          qq += dlt * dlt;
-        }
-      qq += __shfl_xor(qq, 1, 64);
-      qq += __shfl_xor(qq, 2, 64);
-      const float rstd = rsqrtf(qq / (float)FF_C + p.pre_eps);
-      if (lqr == 0 && p.pre_stats) {
-        p.pre_stats[2 * (m0 + lrow)] = mean;
-        p.pre_stats[2 * (m0 + lrow) + 1] = rstd;
-      }
-      const float* gp = p.pre_gamma + lqr * 80;
-      const float* bp = p.pre_beta + lqr * 80;
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        const f32x4_t g0 = *(const f32x4_t*)(gp + 8 * j), g1 = *(const f32x4_t*)(gp + 8 * j + 4);
-        const f32x4_t b0 = *(const f32x4_t*)(bp + 8 * j), b1 = *(const f32x4_t*)(bp + 8 * j + 4);
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (f16)(((float)v[j][e] - mean) * rstd * g0[e] + b0[e]);
-          o[4 + e] = (f16)(((float)v[j][4 + e] - mean) * rstd * g1[e] + b1[e]);
-        }
-        ff_write16<0>(la + 16 * j, o);
-      }
-    }
+    // ---- norm3 on the image rows, in place; the rows also leave for pre_Y from there
+    ff_chain_layernorm(smem_raw, t, m0, (f16*)p.pre_Y, p.ld_prey, p.pre_eps, p.pre_stats);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // l3 is in the image
     {
       const uint32_t img_x = lds0c + FFC_IMG + (wm * 32 + l15) * FFC_PITCH + lq * 16;   // operand fragments: + i * 16 rows, + 64 B per k-step

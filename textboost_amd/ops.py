@@ -577,6 +577,32 @@ def _ff_desc(x, w1, w2, hg, y, R, b1=None, b2=None):
     return d
 
 
+def chain320_ok(M, N2, dtype=None):
+    """can Linear(320 -> 320) + residual -> LayerNorm -> Linear(320 -> N2) over M rows run as ONE launch (csrc/chain320.hip)?"""
+    return dtype in (None, L.half_dtype()) and bool(L.lib().tb_chain320_ok(M, N2))
+
+
+def chain320(x, w1, b1, R1, t_out, gamma, beta, stats, w2, b2, y, eps=1e-5):
+    """t_out = x @ w1^T + b1 (+ R1) (stored: the residual stream); y = LayerNorm(t_out; gamma, beta, eps) @ w2^T + b2; stats [M, 2] = (mean, rstd).
+    Replaces gemm(..., ln_fwd=...) + gemm(...) on the 64x64-map transformer blocks: LayerNorm(t_out) never goes to memory."""
+    M, C = x.shape
+    N2 = w2.shape[0]
+    assert C == 320 and w1.shape == (C, C) and w2.shape[1] == C and y.shape == (M, N2) and t_out.shape == (M, C)
+    d = L.ChainDesc()
+    d.M = M
+    d.X, d.ldx = L.ptr(x), x.stride(0)
+    d.W1, d.ldw1, d.b1 = L.ptr(w1), w1.stride(0), L.ptr(b1)
+    d.R1, d.ldr1 = L.ptr(R1), (R1.stride(0) if R1 is not None else 0)
+    d.T, d.ldt = L.ptr(t_out), t_out.stride(0)
+    d.gamma, d.beta, d.eps, d.stats = L.ptr(gamma), L.ptr(beta), eps, L.ptr(stats)
+    d.W2, d.ldw2, d.N2, d.b2 = L.ptr(w2), w2.stride(0), N2, L.ptr(b2)
+    d.Y, d.ldy = L.ptr(y), y.stride(0)
+    byt = 2.0 * (M * C * (3 if R1 is not None else 2) + C * C + N2 * C + M * N2)
+    with _rec("chain320_kernel", 2.0 * M * C * (C + N2), byt):
+        L.check(L.lib().tb_chain320(d, L.stream()), "tb_chain320")
+    return y
+
+
 def ff_fwd(x, w1p, b1p, w2, b2, hg, y, R=None, pre=None, post=None):
     """BasicTransformerBlock.ff in one launch: hg[M, 2 inner] = x @ w1p^T + b1p (packed [h32|g32] rows, kept for the backward),
     y = (h * gelu(g)) @ w2^T + b2 (+ R).  Same operands as gemm(act=ACT_GEGLU, C2=hg) followed by gemm(R=...).

@@ -36,6 +36,9 @@ FUSE_FF_LN = _os.environ.get("TB_FUSE_FF_LN", "1") == "1"   # the fused feed-for
 # round 6: the fused feed-forward's launch also runs its row-local neighbours (ops.ff_fwd pre / post): bit 1 = attn2.to_out + residual + norm3 in
 # front, bit 2 = proj_out + residual behind (A/B switch)
 FF_CHAIN = int(_os.environ.get("TB_FF_CHAIN", "3"))
+# ... and the two Linear -> LayerNorm -> Linear pairs of a 64x64-map block as one launch each (ops.chain320): bit 1 = proj_in -> norm1 -> qkv,
+# bit 2 = attn1.to_out + residual -> norm2 -> attn2.to_q
+ROW_CHAIN = int(_os.environ.get("TB_ROW_CHAIN", "3"))
 MATERIALIZE_UPSAMPLE = _os.environ.get("TB_MATERIALIZE_UPSAMPLE", "1") == "1"  # A/B switch (see the up-block forward)
 # LayerNorm fused into the neighbouring Linear's epilogue where a tile spans the row (C = 320, the 64x64 maps): forward into the producer of the
 # residual stream, backward onto the accumulators of the dgrad GEMM that feeds it (round 3; 28 LayerNorm launches per step fewer)
@@ -422,14 +425,21 @@ class HipUNet:
             ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"], rs_out=rs, rs_slots=fold)
             ops.gemm(t0, P[tb + ".attn1.qkv.w"], qkv, bias=P[tb + ".attn1.qkv.c2"], lnfold=(rs, fold, P[tb + ".attn1.qkv.c1"], ls1, 1e-5))
         else:
-            l1 = self.scratch("a2" if fuse_ln else "a", M, C)   # (fused: written while n0 -- scratch "a" -- is still being read)
-            if fuse_ln:
-                ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"],
-                         ln_fwd=(P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1, l1, 1e-5))
+            # round 6 (ROW_CHAIN): proj_in -> norm1 -> qkv as ONE launch on the 64x64 maps (csrc/chain320.hip): a 128-row tile spans the 320-wide rows of
+            # all three layers, LayerNorm(t0) never goes to memory
+            chain_a = ROW_CHAIN & 1 and fuse_ln and ops.chain320_ok(M, 3 * C, self.dtype)
+            if chain_a:
+                ops.chain320(n0, P[prefix + ".proj_in.w"], P[prefix + ".proj_in.b"], None, t0, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1,
+                             P[tb + ".attn1.qkv.w"], None, qkv)
             else:
-                ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
-                ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
-            ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
+                l1 = self.scratch("a2" if fuse_ln else "a", M, C)   # (fused: written while n0 -- scratch "a" -- is still being read)
+                if fuse_ln:
+                    ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"],
+                             ln_fwd=(P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1, l1, 1e-5))
+                else:
+                    ops.gemm(n0, P[prefix + ".proj_in.w"], t0, bias=P[prefix + ".proj_in.b"])
+                    ops.layernorm_fwd(t0, l1, P[tb + ".norm1.g"], P[tb + ".norm1.b"], ls1)
+                ops.gemm(l1, P[tb + ".attn1.qkv.w"], qkv)
         o1 = self.buf(prefix + ".o1", M, C)
         lse1 = self.buf(prefix + ".lse1", B * heads, HW, torch.float32)
         fp8_ws = None
@@ -446,14 +456,19 @@ class HipUNet:
             ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0, rs_out=rs, rs_slots=fold)
             ops.gemm(t1, P[tb + ".attn2.to_q.w"], q2, bias=P[tb + ".attn2.to_q.c2"], lnfold=(rs, fold, P[tb + ".attn2.to_q.c1"], ls2, 1e-5))
         else:
-            l2 = self.scratch("a", M, C)
-            if fuse_ln:
-                ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0,
-                         ln_fwd=(P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2, l2, 1e-5))
+            chain_b = ROW_CHAIN & 2 and fuse_ln and ops.chain320_ok(M, C, self.dtype)   # attn1.to_out + residual -> norm2 -> attn2.to_q, one launch
+            if chain_b:
+                ops.chain320(o1, P[tb + ".attn1.to_out.0.w"], P[tb + ".attn1.to_out.0.b"], t0, t1, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2,
+                             P[tb + ".attn2.to_q.w"], None, q2)
             else:
-                ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
-                ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
-            ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
+                l2 = self.scratch("a", M, C)
+                if fuse_ln:
+                    ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0,
+                             ln_fwd=(P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2, l2, 1e-5))
+                else:
+                    ops.gemm(o1, P[tb + ".attn1.to_out.0.w"], t1, bias=P[tb + ".attn1.to_out.0.b"], R=t0)
+                    ops.layernorm_fwd(t1, l2, P[tb + ".norm2.g"], P[tb + ".norm2.b"], ls2)
+                ops.gemm(l2, P[tb + ".attn2.to_q.w"], q2)
         self._ensure_kv()
         ko = self.kv_off[tb + ".attn2"]
         k2, v2 = self.kv_all[:, ko:ko + C], self.kv_all[:, ko + C:ko + 2 * C]
