@@ -7,9 +7,9 @@ gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols e
 wx = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else None)
 sel = "name, start, end" + (f", {gx}" if gx else ", 0") + (f", {wx}" if wx else ", 1")
 rows = cur.execute(f"select {sel} from kernels order by start").fetchall()
-# a step = the launches between two consecutive renorm_rows_kernel launches (the step's last kernel); graph replays are the steps whose kernels abut
+# a step = the launches between two consecutive launches of the step's last kernel (opt_apply_kernel; renorm_rows_kernel until round 5); graph replays are the steps whose kernels abut
 # (span close to the sum of the durations) -- the last such step is printed whole (round 5: independent of the > 100 us gaps inside a replay)
-ends = [i for i, r in enumerate(rows) if 'renorm_rows_kernel' in r[0]]
+ends = [i for i, r in enumerate(rows) if 'opt_apply_kernel' in r[0] or 'renorm_rows_kernel' in r[0]]   # (round 6: the tail's last kernel is opt_apply_kernel)
 steps = [rows[a + 1:b + 1] for a, b in zip(ends, ends[1:])]
 steps = [x for x in steps if len(x) > 300 and not any('spin_kernel' in r[0] or 'mfma_peak' in r[0] for r in x)]   # (not the eager roofline leg)
 tight = [x for x in steps if (x[-1][2] - x[0][1]) < 1.10 * sum(r[2] - r[1] for r in x)]

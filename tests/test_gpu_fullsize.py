@@ -369,8 +369,14 @@ def test_sd15_full_step_at_the_metric_batch_vs_oracle():
         # ---- the parameters after the update, ELEMENTWISE (the optimizer tail :1128-1149 at full size)
         w, wr = step.te.token_table.cpu(), ref.token_embedding.weight.detach()
         torch.testing.assert_close(w[:49408], wr[:49408], rtol=1e-6, atol=1e-7)                       # decay-only rows
-        assert (w[added] - wr[added]).abs().max().item() < 2.5e-3                                     # <= ~2 * emb_lr (Adam step-1 sign flips)
-        assert rel_err(w[added], wr[added]) < 2e-3
+        # added rows: Adam's first moves are ~emb_lr * sign(g), so an element whose gradient sits inside the fp16 path's noise may move the other way
+        # (|difference| = 2 * emb_lr; one such element of the 3 x 768 is already a whole-tensor rel-L2 of 2.1e-3 here).  Bound the NUMBER of such
+        # elements and hold everything else tight (measured: 0 or 1 flipped element, the others within 2.5e-5)
+        dE_abs = (w[added] - wr[added]).abs()
+        assert dE_abs.max().item() < 2.5e-3                                                           # <= ~2 * emb_lr
+        flipped = dE_abs > 1e-3
+        assert int(flipped.sum()) <= max(2, int(0.002 * flipped.numel())), int(flipped.sum())
+        assert rel_err(torch.where(flipped, wr[added], w[added]), wr[added]) < 5e-4
         A_ref = torch.stack([torch.cat([l.q.lora_A, l.k.lora_A, l.v.lora_A]) for l in ref.layers]).detach()
         B_ref = torch.stack([torch.cat([l.q.lora_B, l.k.lora_B, l.v.lora_B]) for l in ref.layers]).detach()
         A_hip, B_hip = step.te.lora_A.cpu(), step.te.lora_B.cpu()
@@ -381,7 +387,7 @@ def test_sd15_full_step_at_the_metric_batch_vs_oracle():
         print(f"[parity] B=8 after step {it}: rel-L2 of the parameter MOVES  lora_A {dA:.3e}  lora_B {dB:.3e}  added rows {dE:.3e};  "
               f"max |param - oracle| lora_A {(A_hip - A_ref).abs().max().item():.2e} lora_B {(B_hip - B_ref).abs().max().item():.2e} "
               f"added {(w[added] - wr[added]).abs().max().item():.2e}")
-        assert dA < 8e-2 and dB < 8e-2 and dE < 2e-2      # measured 2.5e-2 / 3.9e-2 / 4.8e-4 after step 1, 1.4e-2 / 2.1e-2 / 2.6e-3 after step 2
+        assert dA < 8e-2 and dB < 8e-2 and dE < 8e-2      # measured 2.5e-2 / 3.9e-2 / 4.8e-4 (3.5e-2 with one flipped element) after step 1, 1.4e-2 / 2.1e-2 / 2.6e-3 after step 2
     assert step.scalars()["opt_steps"] == 2.0
     # ---- the two teachers (frozen encoder on the prior prompts, :939 / :1096-1100) at full size
     pids_d = step.prior_ids
