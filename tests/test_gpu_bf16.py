@@ -162,6 +162,44 @@ def test_bf16_fused_feed_forward():
     parity("bf16 fused feed-forward backward", dx, refd, rel=6e-3, maxabs=2e-2)
 
 
+def test_bf16_row_chains_of_the_64x64_maps():
+    """round 6: the chained launches (tb_chain320; tb_ff_fwd with pre_W / post_W) in the bfloat16 build -- the same sources, bf16 operands and bf16 LDS
+    image -- against torch fp32 on the bf16-rounded intermediates (fp16 bounds x 8)."""
+    from textboost_amd import ops
+    from test_gpu_gemm import pack_geglu
+    M, C, I = 384, 320, 1280
+    torch.manual_seed(14)
+    r = lambda *sh, s=1.0: torch.randn(*sh, device=dev) * s   # noqa: E731
+    wa, ba, wb = (r(C, C) / C ** 0.5).to(BF), r(C, s=0.3), (r(960, C) / C ** 0.5).to(BF)
+    gamma, beta = 1 + 0.4 * r(C), 0.2 * r(C)
+    x, R = r(M, C).to(BF), (r(M, C) * 0.8 + r(M, 1) * 0.5).to(BF)
+    t = torch.empty(M, C, device=dev, dtype=BF)
+    y = torch.empty(M, 960, device=dev, dtype=BF)
+    st = torch.zeros(M, 2, device=dev)
+    ops.chain320(x, wa, ba, R, t, gamma, beta, st, wb, None, y)
+    t_ref = x.float() @ wa.float().T + ba + R.float()
+    th = t_ref.to(BF).float()
+    l_ref = F.layer_norm(th, (C,), gamma, beta, 1e-5).to(BF).float()
+    parity("bf16 chain320: t", t, t_ref, rel=4e-3, maxabs=1.6e-2)
+    parity("bf16 chain320: y = LN(t) W2^T", y, l_ref @ wb.float().T, rel=1.2e-2, maxabs=4e-2)
+    assert torch.allclose(st[:, 0], th.mean(1), rtol=1e-3, atol=2e-3)
+    # the feed-forward with both neighbours
+    w1, b1 = (r(2 * I, C) / C ** 0.5).to(BF), r(2 * I, s=0.3)
+    w2, b2 = (r(C, I) / I ** 0.5).to(BF), r(C, s=0.3)
+    wp, bp = (r(C, C) / C ** 0.5).to(BF), r(C, s=0.3)
+    xin = r(M, C).to(BF)
+    hg = torch.empty(M, 2 * I, device=dev, dtype=BF)
+    t2 = torch.empty(M, C, device=dev, dtype=BF)
+    out = torch.empty(M, C, device=dev, dtype=BF)
+    ops.ff_fwd(x, pack_geglu(w1).contiguous(), pack_geglu(b1).contiguous(), w2, b2, hg, None, R=t2,
+               pre=(wa, ba, R, t2, gamma, beta, st, 1e-5), post=(wp, bp, xin, out))
+    assert torch.equal(t2, t)                                   # the same stage, the same bits
+    proj = l_ref @ w1.float().T + b1
+    h, g = proj[:, :I].to(BF).float(), proj[:, I:].to(BF).float()
+    t3 = ((h * F.gelu(g)).to(BF).float() @ w2.float().T + b2 + th).to(BF).float()
+    parity("bf16 feed-forward chain: proj_out + block input", out, t3 @ wp.float().T + bp + xin.float(), rel=1.6e-2, maxabs=5e-2)
+
+
 def test_bf16_unet_and_text_encoder_match_oracle():
     from test_gpu_model import make_unet, make_encoders, lora_grads_from_oracle
     from oracle import train_step as ts
