@@ -128,8 +128,7 @@ def test_cli_rejects_unbuilt_arithmetic_options(tmp_path):
     base = ["--pretrained_model_name_or_path", "/nonexistent/sd15", "--output_dir", str(tmp_path / "o"), "--train_batch_size", "1",
             "--resolution", "128", "--max_train_steps", "1"]
     for extra in (["--mixed_precision", "fp16", "--text_encoder_use_attention_mask"],
-                  ["--mixed_precision", "fp16", "--unet_params_to_train", "crossattn_kv"],
-                  ["--mixed_precision", "bf16", "--unet_params_to_train", "crossattn_kv"]):   # (bf16 itself is built: tests/test_gpu_bf16.py)
+                  ["--mixed_precision", "fp16", "--unet_params_to_train", "crossattn_kv"]):   # (bf16 + crossattn_kv is built: tests/test_gpu_bf16.py)
         with pytest.raises(NotImplementedError):
             T.main(T.parse_args(base + extra))
 

@@ -148,10 +148,13 @@ class HipUNet:
     def enable_kv_lora(self, r: int, alpha: Optional[float] = None, seed: Optional[int] = None):
         """--unet_params_to_train crossattn_kv (train_textboost.py:712-721): peft LoraConfig(r, lora_alpha=r, "gaussian",
         target_modules=["attn2.to_k", "attn2.to_v"]) on the otherwise frozen UNet; its parameters are the optimizer's third group
-        (:838-841).  fp32 mode only -- under --mixed_precision fp16 the reference casts these parameters to fp16 (:937) and GradScaler
-        refuses them.  Layout: kv_lora_A [n_layers, 2r, Dc] (k rows, then v rows), kv_lora_B [kv_total, r] (row n = output feature n of the
-        concatenated K/V projections, i.e. aligned with the columns of the hoisted kv_all GEMM)."""
-        assert self.dtype == torch.float32, "UNet adapters need the fp32 (no-AMP) mode"
+        (:838-841).  fp32 and bf16 modes -- under --mixed_precision fp16 the reference casts these parameters to fp16 (:937) and GradScaler
+        refuses them, so that combination cannot run there either.  Layout: kv_lora_A [n_layers, 2r, Dc] (k rows, then v rows), kv_lora_B
+        [kv_total, r] (row n = output feature n of the concatenated K/V projections, i.e. aligned with the columns of the hoisted kv_all GEMM).
+        bf16 mode (round 6; the reference trains bf16 adapter PARAMETERS there, :937): fp32 masters like the text encoder's LoRA, the forward
+        multiplies bf16 copies of A_all / W2 as the hoisted GEMM's operands (the adapter output is rounded to bf16 like peft's bf16 module), the
+        parameter gradients are the fp32 path's products on fp32 copies of the bf16 operands."""
+        assert self.dtype == torch.float32 or L.half_kind() == "bf16", "UNet adapters: fp32 (no-AMP) or bf16 mode (fp16: GradScaler refuses fp16 parameters)"
         dev, Dc, n = self.dev, self.geo.cross_attention_dim, len(self.xattn)
         g = torch.Generator(device="cpu")
         if seed is not None:
@@ -169,11 +172,20 @@ class HipUNet:
             cb[ko + C:ko + 2 * C] = l * 2 * r + r
         self.kv_col_base = cb.to(dev)
         self.kv_w2 = torch.zeros(self.kv_total, n * 2 * r, device=dev)
+        if self.dtype != torch.float32:   # 16-bit operand copies, the K extension padded to whole 64-wide k-tiles (zero columns / rows)
+            n2r = n * 2 * r
+            self.kv_n2r_pad = (n2r + 63) // 64 * 64
+            self.kv_A16 = torch.zeros(self.kv_n2r_pad, Dc, device=dev, dtype=self.dtype)
+            self.kv_w2_16 = torch.zeros(self.kv_total, self.kv_n2r_pad, device=dev, dtype=self.dtype)
 
     def pack_kv_lora(self):
         """refresh the K-extension operand from the adapter masters (once per optimizer step, like HipTextEncoder.pack_lora)"""
         if getattr(self, "kv_r", 0):
             ops.kv_lora_pack(self.kv_lora_B, self.kv_col_base, self.kv_w2, self.kv_r, self.kv_scaling)
+            if self.dtype != torch.float32:
+                n2r = self.kv_w2.shape[1]
+                ops.convert(self.kv_w2, self.kv_w2_16[:, :n2r])
+                ops.convert(self.kv_lora_A.view(n2r, -1), self.kv_A16[:n2r])
 
     def merged_kv_weight(self):
         """attn2.to_k / to_v weights with the adapters folded in, fp32 [kv_total, Dc]: W + W2 A_all (W2 = the block-structured scaling * B of
@@ -587,7 +599,11 @@ class HipUNet:
         if ehs_ready is not None:
             ehs_ready()   # e.g. torch.cuda.current_stream().wait_stream(text-encoder stream)
         B, P = self.B, self.P
-        if getattr(self, "kv_r", 0):  # adapters: kv = ehs W^T + (ehs A_all^T) W2^T, W2 = block-structured scaling * B (pack_kv_lora)
+        if getattr(self, "kv_r", 0) and self.dtype != torch.float32:   # bf16 mode: the same two products on the 16-bit operand copies
+            self.kv_t = self.buf("kv_t", B * self.T, self.kv_n2r_pad)
+            ops.gemm(ehs16, self.kv_A16, self.kv_t)
+            ops.gemm(ehs16, P["kv_all.w"], self.kv_all, A2=self.kv_t, W2=self.kv_w2_16)
+        elif getattr(self, "kv_r", 0):  # adapters: kv = ehs W^T + (ehs A_all^T) W2^T, W2 = block-structured scaling * B (pack_kv_lora)
             n2r = self.kv_w2.shape[1]
             self.kv_t = self.buf("kv_t", B * self.T, n2r)
             ops.gemm(ehs16, self.kv_lora_A.view(n2r, -1), self.kv_t)
@@ -839,15 +855,23 @@ class HipUNet:
             #   dt = dkv W2                       dB[rows of (layer, proj)] += scaling * dkv[:, rows]^T t[:, cols]
             #   dA_all += dt^T ehs                d_ehs += dt A_all
             M, r, n2r, Dc = B * self.T, self.kv_r, self.kv_w2.shape[1], geo.cross_attention_dim
-            ehs = S["ehs16"]
-            dt = self.buf("kv_dt", M, n2r)
-            ops.gemm_f32_t(self.dkv_all, self.kv_w2, dt, M, n2r, self.kv_total, w_trans=True)
+            ehs, dkv, kv_t = S["ehs16"], self.dkv_all, self.kv_t
+            if self.dtype != torch.float32:   # bf16 mode: the fp32 path's (exact-fp32 MFMA) products on fp32 copies of the 16-bit operands
+                dkv = self.buf("kv_dkv32", M, self.kv_total, torch.float32)
+                ops.convert(self.dkv_all, dkv)
+                kv_t = self.buf("kv_t32", M, n2r, torch.float32)
+                ops.convert(self.kv_t[:, :n2r], kv_t)
+                e32 = self.buf("kv_ehs32", M, Dc, torch.float32)
+                ops.convert(ehs, e32)
+                ehs = e32
+            dt = self.buf("kv_dt", M, n2r, torch.float32)
+            ops.gemm_f32_t(dkv, self.kv_w2, dt, M, n2r, self.kv_total, w_trans=True)
             for l, (p, C) in enumerate(self.xattn):
                 ko = self.kv_off[p]
                 for proj in range(2):
                     rows = slice(ko + proj * C, ko + (proj + 1) * C)
                     cols = slice(l * 2 * r + proj * r, l * 2 * r + (proj + 1) * r)
-                    ops.gemm_f32_t(self.dkv_all[:, rows], self.kv_t[:, cols], self.kv_grad_B[rows], C, r, M, a_trans=True, w_trans=True,
+                    ops.gemm_f32_t(dkv[:, rows], kv_t[:, cols], self.kv_grad_B[rows], C, r, M, a_trans=True, w_trans=True,
                                    R=self.kv_grad_B[rows], alpha=self.kv_scaling)
             gA = self.kv_grad_A.view(n2r, Dc)
             ops.gemm_f32_t(dt, ehs, gA, n2r, Dc, M, a_trans=True, w_trans=True, R=gA)

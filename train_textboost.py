@@ -244,13 +244,9 @@ def main(args):
         raise NotImplementedError(f"--unet_params_to_train {args.unet_params_to_train}: the reference adds adapters only for 'crossattn_kv' (:712); "
                                   "every other value trains nothing in the UNet and only writes an unchanged copy of it to <output_dir>/unet")
     if args.unet_params_to_train == "crossattn_kv":
-        if not fp32_mode:
-            if args.mixed_precision == "bf16":
-                raise NotImplementedError("--unet_params_to_train crossattn_kv under --mixed_precision bf16 is not built here (the reference trains the "
-                                          "bf16-cast adapter parameters directly, :937, no GradScaler): a capability gap, listed in INTEGRATION.md; "
-                                          "run it without --mixed_precision (fp32)")
-            raise NotImplementedError("--unet_params_to_train crossattn_kv needs the fp32 (no --mixed_precision) mode: under fp16 the reference "
-                                      "casts the UNet's freshly added LoRA parameters to fp16 (:937) and GradScaler.unscale_ rejects them")
+        if not fp32_mode and args.mixed_precision != "bf16":   # (bf16: the reference trains the bf16-cast adapters, no GradScaler; built in round 6)
+            raise NotImplementedError("--unet_params_to_train crossattn_kv needs the fp32 (no --mixed_precision) or the bf16 mode: under fp16 the "
+                                      "reference casts the UNet's freshly added LoRA parameters to fp16 (:937) and GradScaler.unscale_ rejects them")
         if args.lora_rank <= 0:
             raise ValueError("--unet_params_to_train crossattn_kv is only reached with --lora_rank > 0 (:700-721)")
         unet.enable_kv_lora(args.lora_rank, seed=None if args.seed is None else args.seed + 1)
