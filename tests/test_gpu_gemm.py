@@ -1030,3 +1030,45 @@ def test_conv3x3_32x32_maps_as_two_k_slices_of_the_wide_tile():
     ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * H, Cout) + res.float()
     parity("32x32-map conv as two k-slices of the 256 x 160 tile", outs[1], ref, rel=2e-3, maxabs=4e-3, ch_dim=1, ch_rel=3e-3)
     assert rel_err(outs[0], outs[1]) < 1e-3
+
+
+def test_conv3x3_wide_tile_as_one_stream_per_wave_equals_the_phase_form():
+    """round 6, tb_gemm8_set bit 1048576 (opt-in: isolated launches -4 ... -6 %, the sustained step 27.92 -> 27.99 ms -- these tiles sit at the board's
+    power limit, see launch8): the 256 x 160 and 256 x 128 convolution tiles with the next k-step's fragment reads between this step's MFMAs and
+    one barrier per tap.  Both forms add the same products in the same order: bit-equal outputs -- forward with bias + residual, dgrad (flipped
+    taps), the split-K slices of the 16x16 maps, the 128-wide tile -- and both match torch."""
+    import ctypes
+    ops, L = _ops()
+    torch.manual_seed(13)
+    cases = [(8, 320, 320, 64, 1, [4, 2, 4, 5, 1, 3]), (8, 320, 320, 64, -1, [4, 2, 4, 5, 1, 3]), (2, 960, 320, 64, 1, [4, 2, 4, 5, 1, 3]),
+             (8, 1280, 1280, 16, 1, [4, 2, 4, 5, 1, 3]), (8, 128, 256, 64, 1, None)]
+    default_bits = L.lib().tb_gemm8_set(39)
+    try:
+        for B, Cin, Cout, H, sign, want in cases:
+            w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).half()
+            if sign > 0:
+                x = torch.randn(B, Cin, H, H, device="cuda").half()
+                bias = torch.randn(Cout, device="cuda")
+                res = torch.randn(B * H * H, Cout, device="cuda").half()
+                a, wp, n_in, n_out = nhwc(x).view(B * H * H, Cin), pack_conv_w(w), Cin, Cout
+                ref = nhwc(F.conv2d(x.float(), w.float(), bias, padding=1)).view(B * H * H, Cout) + res.float()
+            else:
+                dy = torch.randn(B, Cout, H, H, device="cuda").half()
+                bias, res = None, None
+                a, wp, n_in, n_out = nhwc(dy).view(B * H * H, Cout), pack_conv_w_dgrad(w), Cout, Cin
+                ref = nhwc(F.conv_transpose2d(dy.float(), w.float(), padding=1)).view(B * H * H, Cin)
+            geo = dict(B=B, Hin=H, Win=H, Cin=n_in, Hout=H, Wout=H, stride=1, sign=sign, upsample=0, transposed=0)
+            outs = []
+            for bits in (39, 39 | 1048576):
+                L.lib().tb_gemm8_set(bits)
+                out = torch.empty(B * H * H, n_out, device="cuda", dtype=torch.float16)
+                ops.gemm(a, wp, out, bias=bias, R=res, conv=geo)
+                last = (ctypes.c_int * 6)()
+                used = L.lib().tb_gemm8_last(last)
+                if want is not None:
+                    assert used and list(last) == want, (B, Cin, Cout, H, list(last))
+                outs.append(out)
+            parity(f"stream conv {Cin}->{Cout}@{H} sign {sign}", outs[1], ref, rel=2e-3, maxabs=6e-3, ch_dim=1, ch_rel=3e-3)
+            assert torch.equal(outs[0], outs[1]), (B, Cin, Cout, H, sign, rel_err(outs[0], outs[1]))
+    finally:
+        L.lib().tb_gemm8_set(default_bits)

@@ -39,6 +39,9 @@
 #else
 #define G8_ST(ptr, val) (*(ptr) = (val))
 #endif
+#ifndef G8_STREAM
+#define G8_STREAM 1  // the 256 x 160 / 256 x 128 convolution tiles (MT >= 4, 3-slot weight ring) as ONE instruction stream per wave: the fragments of the next 32-wide k-step are read between the MFMAs of this one, one barrier per tap (0: the round-2 LOAD / COMPUTE phases of two barrier-shifted wave groups)
+#endif
 #ifndef G8_ABL
 #define G8_ABL 0  // profiling builds (TB_CFLAGS=-DG8_ABL=bits): 1 = no MFMAs, 2 = no in-loop global->LDS loads, 4 = no fragment reads
 #endif
@@ -144,7 +147,7 @@ inline uint32_t mg_of(int d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + 
 // outputs and split every 64-wide k-step between them (32 k each), their accumulators are added through the LDS in front of the epilogue.  A wave
 // tile twice as tall for the same register tile per wave: the 128 x 80 one-per-CU tile read (16 + 80) fragment rows per 5 MFMAs (LDS-read bound,
 // 0.65 us per k-step at one tile per CU), as 4 x 1 x 2 waves it reads (32 + 80) rows per 10.
-template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0, int KH = 1>
+template <int WM, int WN, int MT, int NT, bool CONV, int NS, int SUB = 0, int KH = 1, bool ST = true>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int a_rows8,
                                                           unsigned long long* dbg, int S, float* __restrict__ ws, int64_t npad, int xn, G8Magic mg) {
   static_assert(WM * WN * KH == 8, "8 waves");
@@ -312,9 +315,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
   G8_STAMP(7)
 #endif
   const int cp = lane & 7, rl = lane >> 3;
+  // STREAM: see the main loop
+  constexpr bool STREAM = G8_STREAM && ST && CONV && SUB == 0 && MT >= 4 && NT <= 5 && NS == 3 && KH == 1 && !G8_PROF;
   // ---- A-panel sources of this lane (fixed across chunks, + 64 halfs per chunk)
   const f16* h_ptr[MAXHI];
   int h_step[MAXHI];
+  uint32_t h_off[STREAM ? MAXHI : 1];   // STREAM keeps 32-bit byte offsets from p.A across its main loop (~0: a row outside the map) instead of pointer + step: 13 registers
   const f16* zero = g_zero_line;
 #pragma unroll
   for (int i = 0; i < MAXHI; ++i) {
@@ -334,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
     h_ptr[i] = ok ? (const f16*)p.A + grow * p.lda + ((cp ^ (hr & 7)) << 3) : zero;
     h_step[i] = ok ? BK : 0;
+    if constexpr (STREAM) h_off[i] = ok ? (uint32_t)((grow * p.lda + ((cp ^ (hr & 7)) << 3)) * 2) : ~0u;
   }
   uint32_t w_off[WI];
 #pragma unroll
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     for (int i = 0; i < MAXHI; ++i) stage_a_piece(c_begin, i, false);
   }
 #pragma unroll
-  for (int st = 0; st < NS - 1; ++st) {  // stages 0 .. NS-2; the youngest one's loads may stay in flight at step 0 (NS = 3)
+  for (int st = 0; st < (STREAM ? NS : NS - 1); ++st) {  // stages 0 .. NS-2 (STREAM: the whole ring); the youngest one's loads may stay in flight at step 0 (NS = 3)
     const int lc = c_begin + st / TAPS, ltap = st % TAPS;
     cnt_prev = lc < nchunk ? n_w + (CONV ? 0 : n_a) : 0;
 #pragma unroll
@@ -582,8 +589,140 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
 #else
 #define G8_PF(k)
 #endif
-  if (group == 1) asm volatile("s_barrier" ::: "memory");  // phase shift of the second wave group
   const uint32_t as_addr = lds_addr(As), ws_addr = lds_addr(Ws);
+  if constexpr (STREAM) {
+    // ---- STREAM main loop (round 6).  scratch/r6/ldsmfma.hip: 9 fragment reads issued BETWEEN the 20 MFMAs of a 32-wide k-step cost nothing -- two waves per
+    // SIMD run at 296 ns per step against 285 ns for the bare MFMAs (one wave per SIMD with 128 x 80 tiles the same), while the LOAD / COMPUTE phase
+    // pairs below measured LOAD 527 cycles against COMPUTE 365.  So every wave runs ONE stream: the fragments of the next k-step are read into the
+    // other register buffer while this step's MFMAs issue, and the only barrier is the one per tap that hands over a weight-ring slot:
+    //   sub-step 0 of tap T: MFMAs (T, k 0..31)  | reads (T, k 32..63)
+    //   sub-step 1 of tap T: wait for T + 1's weights, barrier -- every wave has now READ all of T's slot (its second half went into registers during
+    //                        sub-step 0), so the slot is refilled at once with tap T + 3: the 3-slot ring runs three taps ahead, ~2 taps (2.6 k cycles)
+    //                        of lead on the wait;  MFMAs (T, k 32..63) | the refill pieces, one halo piece of the next chunk, reads (T + 1, k 0..31)
+    f16x8 af[2][MT], bf[2][NT];
+    const uint32_t bb0 = ws_addr + boff0;   // (k 32..63: ^ 64)
+    uint32_t a0[MT];
+    auto frag_rows = [&](int cc, int tap) {   // a0[]: this lane's fragment addresses of (chunk cc, tap), k 0..31 (k 32..63: ^ 64)
+      const int shift = (tap / 3) * HC + (tap % 3);
+      const uint32_t ab = as_addr + (uint32_t)(cc & 1) * (uint32_t)(a_elems * 2) + (uint32_t)shift * 128u;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        uint32_t ar = (uint32_t)arow0[i];
+        asm volatile("" : "+v"(ar));   // opaque: left to itself hipcc hoists the 9 x MT tap addresses out of the chunk loop (36 registers, spills)
+        a0[i] = ab + (ar << 7) + ((lq ^ ((ar + shift) & 7)) << 4);
+      }
+    };
+    int abl_c = c_begin;
+    uint32_t wb = bb0;   // weight-fragment base of the sub-step being read (slot and k-half folded in, set once per sub-step)
+    if (G8_ABL & 4) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(bf[s][j]));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(af[s][i]));
+      }
+    }
+    auto read_frag = [&](int r, int s) {   // fragment read r of a sub-step: r < NT weights, then activations
+      if (G8_ABL & 4) return;
+      if ((G8_ABL & 64) && abl_c > c_begin) return;   // (as bit 32) fragment reads in the first chunk only
+      if (r < NT) bf[s][r] = lds_read16_off<2048>(wb, r);
+      else af[s][r - NT] = lds_read16(s ? (a0[r - NT] ^ 64) : a0[r - NT]);
+    };
+    // Pieces of a tap, oldest first: the next chunk's halo piece, the weight pieces only some waves have (k >= NI_W / 8), then the NI_W / 8 every wave
+    // has.  No run-time counting: past the last chunk the refill re-reads the last chunk's stage (never read again), so every wave issues at least NWALL
+    // pieces per tap and the wait in front of the barrier is the immediate vmcnt(NWALL) -- a branch between MFMAs costs ~25 cycles of the stream (the
+    // counted form had ~10 per tap: the switch over the count, the conditions of every piece).
+    constexpr int NWALL = NI_W / 8;
+    uint32_t hmask = 0, wmask = 0;   // wave-uniform: bit tap: this wave has halo piece `tap`; bit k: weight piece k
+#pragma unroll
+    for (int q = 0; q < MAXHI; ++q) hmask |= (wave + 8 * q < NI_H ? 1u : 0u) << q;
+#pragma unroll
+    for (int k = 0; k < WI; ++k) wmask |= (wave + 8 * k < NI_W ? 1u : 0u) << k;
+    hmask = __builtin_amdgcn_readfirstlane(hmask), wmask = __builtin_amdgcn_readfirstlane(wmask);
+    auto issue_piece = [&](int q, int lc, int ltap, int lslot, int c, int tap) {   // q: 0 the halo piece, then weight pieces WI - 1 .. 0
+      if (G8_ABL & 2) return;
+      if ((G8_ABL & 32) && c > c_begin) return;   // (timing builds with REAL operand data: the matrix pipe's clock depends on it) pieces in the first chunk only
+      if (q == 0) {
+        if (tap < MAXHI && ((hmask >> tap) & 1)) {
+          const int j = wave + 8 * tap, cn = min(c + 1, nchunk - 1);
+          const uint32_t ho = h_off[tap < MAXHI ? tap : 0];
+          const char* srcp = ho != ~0u ? (const char*)p.A + ho + (int64_t)cn * (BK * 2) : (const char*)zero;
+          glds16_asm(srcp, as_addr + (uint32_t)(((c + 1) & 1) * a_elems + j * 8 * BK) * 2);
+        }
+      } else {
+        const int k = WI - q, j = wave + 8 * k;
+        if (k < NWALL || ((wmask >> k) & 1))
+          glds16_asm_so((const char*)p.W + (int64_t)((wtap0 + wtapd * ltap) * kpt + min(lc, nchunk - 1)) * BK * 2, w_off[k], ws_addr + (uint32_t)(lslot * (BN * BK) + j * 8 * BK) * 2);
+      }
+    };
+    constexpr int NR = MT + NT, NM = MT * NT;
+    frag_rows(c_begin, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_frag(r, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = c_begin; c < nchunk; ++c) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int wslot = tap % NS;
+        if (G8_ABL & 64) abl_c = c;
+        // ---- sub-step 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wb = (bb0 ^ 64u) + (uint32_t)(wslot * (BN * BK * 2));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (!(G8_ABL & 1)) acc[i][j] = TB_MFMA_16x16x32(bf[0][j], af[0][i], acc[i][j]);
+            else asm volatile("" ::"v"(bf[0][j]), "v"(af[0][i]));
+            const int mi = i * NT + j;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+              if (mi == (r * (NM - 4)) / NR) {   // spread over all but the last MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                read_frag(r, 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sub-step 1
+        const int ltap = (tap + NS) % TAPS, lc = c + (tap + NS) / TAPS;   // the stage that refills this tap's slot
+        if ((G8_ABL & 2) || ((G8_ABL & 32) && c > c_begin)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_vmcnt(NWALL);   // in flight: the previous tap's youngest pieces; landed (this wave's share): tap + 1's weights, every halo piece before them
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        frag_rows(tap + 1 < TAPS ? c : c + 1, tap + 1 < TAPS ? tap + 1 : 0);
+        wb = bb0 + (uint32_t)(((tap + 1) % NS) * (BN * BK * 2));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (!(G8_ABL & 1)) acc[i][j] = TB_MFMA_16x16x32(bf[1][j], af[1][i], acc[i][j]);
+            else asm volatile("" ::"v"(bf[1][j]), "v"(af[1][i]));
+            const int mi = i * NT + j;
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k)
+              if (mi == k) {   // the refill first: its latency is the ring's lead
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(k, lc, ltap, wslot, c, tap);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+              if (mi == NSLOT + (r * (NM - 4 - NSLOT)) / NR) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frag(r, 0);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+  if (group == 1) asm volatile("s_barrier" ::: "memory");  // phase shift of the second wave group
   int lin_slot = 0, lin_lslot = (NS - 1) % NS;  // Linear: ring slots of the current / the loaded stage (conv: tap % NS, compile-time)
   for (int c = c_begin; c < nchunk; ++c) {
     // SUB: halo position of the 2 x 2 window's first tap -- forward: (py, px) of the output class; dgrad: (1 - py, 1 - px) of the chunk's view
@@ -762,6 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const tb_gemm_desc p, int
     }
   }
   if (group == 0) asm volatile("s_barrier" ::: "memory");  // pairs with the second group's last barrier
+  }
 #if G8_PROF
   if (dbg && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256))
     for (int k = 0; k < 4; ++k) dbg[16 + group * 4 + k] = pf_sum[k];
@@ -1334,11 +1474,23 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
     lds += BN * 12 + BM * 8;  // the tile's bias values (+ LayerNorm gamma / beta of the fused-LN epilogues, c1 of a folded one) + (mean, rstd) per tile row
   }
   if (lds > 160 * 1024) return 1;
+  // tb_gemm8_set bit 1048576 (round 6, opt-in): the 256 x 160 / 256 x 128 convolution tiles as ONE instruction stream per wave (see STREAM in the
+  // kernel) instead of the LOAD / COMPUTE phases of two barrier-shifted wave groups.  Isolated launches 57.8 -> 54.5 us (320 -> 320 @ 64 x 64) and
+  // 162.4 -> 156 us (960 -> 320): 1800 -> 1546 shader cycles per tap against 1304 of MFMAs -- and the clock inside the launch falls from 1.63 to
+  // 1.46 GHz: on real operand data these tiles sit at the board's power limit, cycles saved come back as clock.  In the sustained step
+  // (scratch/ab_step.py): 27.92 ms with the phases, 27.99 ms with the stream.  Default: the phases.
+  constexpr bool CAN_ST = G8_STREAM && CONV && SUB == 0 && MT >= 4 && NT <= 5 && NS == 3 && KH == 1;
+  const bool phases = CAN_ST && !(g8_enable & 1048576);
   static bool attr_done = false;
   if (!attr_done && !g8_dry) {
     if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return TB_ELAUNCH;
+    if constexpr (CAN_ST) {
+      if (hipFuncSetAttribute((const void*)gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return TB_ELAUNCH;
+    }
     attr_done = true;
   }
   // XCD cut (see the kernel): fabric bytes = xn * A + (8 / xn) * W over the cuts that divide the tile grid
@@ -1367,8 +1519,12 @@ int launch8(const tb_gemm_desc& d, hipStream_t s, int wshift, int S = 1) {
     g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
     return TB_OK;
   }
-  hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
-                     wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn, mg);
+  if (phases)
+    hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH, !CAN_ST>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m,
+                       tiles_n, wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn, mg);
+  else
+    hipLaunchKernelGGL((gemm8_kernel<WM, WN, MT, NT, CONV, NS, SUB, KH>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(512), lds, s, d, tiles_m, tiles_n,
+                       wshift, a_rows8, g8_dbg, S, (float*)d.ws, npad, xn, mg);
   TB_CHECK_LAUNCH();
   g8_split = SUB == 1 ? 1 : S;
   g8_last[0] = 1, g8_last[1] = WM, g8_last[2] = WN, g8_last[3] = MT, g8_last[4] = NT, g8_last[5] = CONV, g8_last[6] = NS;
