@@ -93,8 +93,8 @@ def roofline_leg(step):
     for pf in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
-            cands = [name] + ([name[:-1] + ", 0>", name[:-1] + ", 0, 1>"] if name.endswith(">") else [])   # (the trace's symbol carries the
-            key = next((c for c in cands if c in pmc), None)                                                   # defaulted SUB / KH template arguments)
+            cands = [name] + ([name[:-1] + s_ for s_ in (", 0>", ", 0, 1>", ", 0, 1, false>", ", 0, 1, true>")] if name.endswith(">") else [])   # (the trace's symbol carries the
+            key = next((c for c in cands if c in pmc), None)                                                   # defaulted SUB / KH / ST template arguments)
             if key:
                 roof["traffic"] = round(pmc[key]["hbm_bytes_per_launch"])
                 roof["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
