@@ -177,6 +177,45 @@ def sustained_mfma_peak(ms_target=15.0, reps=3):
     return round(rates[len(rates) // 2], 1)
 
 
+def dominant_tile_clock(batch=8, reps=20):
+    """The dominant convolution tile against its own cycle counter: one ResnetBlock2D convolution of the metric's first UNet level (3x3, 320 -> 320,
+    64 x 64 maps: 256 tiles of gemm8_kernel<4, 2, 4, 5, true, 3>) on N(0,1) operands, HIP-event time per launch beside the s_memtime stamps of
+    workgroup 0 (tb_gemm8_debug: kernel start [0] .. last epilogue pass [3]; shader cycles).  cycles / time = the clock the chip holds INSIDE the
+    launch; 16.3 cycles x 1.25 K MFMAs per SIMD / cycles = the matrix pipe's duty in cycles.  On real operands the launch runs at ~1.6-1.75 GHz, not
+    at the 2.4 GHz the 2.5 PFLOP/s peak is quoted at: the tile is power-limited (profiles/r06_ldsmfma_probe.txt)."""
+    from textboost_amd import ops, _lib as L
+    H, C = 64, 320
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(batch * H * H, C, device="cuda", generator=g).to(L.half_dtype())
+    w = (torch.randn(C, 9 * C, device="cuda", generator=g) / (9 * C) ** 0.5).to(L.half_dtype())
+    out = torch.empty(batch * H * H, C, device="cuda", dtype=L.half_dtype())
+    geo = dict(B=batch, Hin=H, Win=H, Cin=C, Hout=H, Wout=H, stride=1, sign=1, upsample=0, transposed=0)
+    for _ in range(3):
+        ops.gemm(x, w, out, conv=geo)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        ops.gemm(x, w, out, conv=geo)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / reps * 1e3
+    dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
+    L.lib().tb_gemm8_debug(L.ptr(dbg))
+    try:
+        ops.gemm(x, w, out, conv=geo)
+        torch.cuda.synchronize()
+    finally:
+        L.lib().tb_gemm8_debug(None)
+    d = dbg.tolist()
+    cycles, loop = d[3] - d[0], d[2] - d[1]
+    if cycles <= 0:
+        return None
+    mfma = 16.3 * 1.25 * 9 * C   # per SIMD: 256 x 160 x K / (16 x 16 x 32) / 4 MFMAs of 16.3 cycles
+    return {"launch": f"conv3x3 {C}->{C} @ {H}x{H}, B={batch}", "us": round(us, 2), "cycles_workgroup0": cycles, "main_loop_cycles": loop,
+            "clock_ghz_inside_launch": round(cycles / (us * 1e3), 3), "mfma_cycles": round(mfma), "mfma_duty_main_loop": round(mfma / max(loop, 1), 3),
+            "tflops": round(2.0 * batch * H * H * C * 9 * C / us / 1e6, 1)}
+
+
 def mfma_busy_table():
     """Per kernel family MFMA-pipe busy fraction from the committed SQ counter pass of the same bench command (profiles/rNN_mfma_busy.json:
     SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); PMC passes cannot run inside this process).  None when no file matches."""
@@ -528,6 +567,7 @@ def main():
                 roof["sustained_peak"] = sp
                 roof["frac_of_sustained_peak"] = round(roof["mfma_frac" if "mfma_frac" in roof else "frac"] * MFMA_PEAK_TFLOPS / sp, 4)
                 roof["whole_step_frac_of_sustained_peak"] = round(out["alg_tflops_per_gpu"] / sp, 4)
+                roof["dominant_tile_clock"] = dominant_tile_clock(batch=args.batch if args.batch in (1, 2, 4, 8, 16) else 8)
         if table is not None:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
