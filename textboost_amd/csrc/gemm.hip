@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, (BKT == 32 ? 3 : (NST >= 4 && BM == 128 ? 1 : 
 // per-tap gather this moves 4.4x fewer activation bytes through the L2->LDS path that bounds the kernel.
 template <int BN, int NSW = 2>
 __global__ __launch_bounds__(256, (NSW > 2 ? 1 : 2)) void conv_halo_kernel(const tb_gemm_desc p, int tiles_m, int tiles_n, int wshift, int S,
-                                                             float* __restrict__ ws, int64_t npad) {
+                                                             float* __restrict__ ws, int64_t npad, int perm8) {
   extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
   f16* smem = reinterpret_cast<f16*>(smem_raw);
   constexpr int BM = 128, BK = 64;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256, (NSW > 2 ? 1 : 2)) void conv_halo_kernel(const
   const int TW = 1 << wshift, W = p.Wout, H = p.Hout, R = BM >> wshift;
   const int hw_img = H * W;
   const bool multi = hw_img < BM;                       // host: then W == TW and BM % hw_img == 0
-  const bool perm = multi && TW == 8 && (p.shift == 0x100);   // 8-wide maps: 12-pixel halo pitch + permuted lanes (halo_perm32)
+  const bool perm = multi && TW == 8 && perm8;   // 8-wide maps: 12-pixel halo pitch + permuted lanes (halo_perm32); the host's choice (launch_halo)
   const int HC = perm ? 12 : TW + 2, HIMG = (H + 2) * HC;           // halo pixels per image (multi)
   const int NH = multi ? (BM / hw_img) * HIMG : (R + 2) * HC, NH8 = (NH + 7) & ~7, NI = NH8 >> 3;
   // NSW > 2 (round 5, the 8x8-map launches): TWO halo panels and an NSW-slot weight ring with counted vmcnt, one workgroup per CU -- see the
@@ -1102,12 +1102,11 @@ int launch_halo(const tb_gemm_desc& d, hipStream_t s, int wshift, int S) {
     attr_done = true;
   }
   tb_gemm_desc dk = d;
-  if (perm8) dk.shift = 0x100;   // (the kernel's switch for the 12-pixel halo pitch + permuted lanes; `shift` itself is 0 for every launch that gets here)
   const bool defer = defer_reduce(d, S);
   const bool inkernel = S > 1 && !defer && g_inkernel_reduce && d.sync && (int64_t)tiles_m * tiles_n <= d.sync_count;
   if (!inkernel) dk.sync = nullptr;
   hipLaunchKernelGGL((conv_halo_kernel<BN, NSW>), dim3((unsigned)(tiles_m * tiles_n * S)), dim3(256), lds, s, dk, tiles_m, tiles_n, wshift, S,
-                     (float*)d.ws, npad);
+                     (float*)d.ws, npad, perm8 ? 1 : 0);
   if (defer) *d.split_out = S;
   else if (S > 1 && !inkernel)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M * (npad / 8) + 255) / 256)), dim3(256), 0, s, d, (const float*)d.ws, S,
