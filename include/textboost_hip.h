@@ -129,7 +129,7 @@ void tb_gemm_last_config(int* out5);
 /* 8-wave wide-tile path of tb_gemm (csrc/gemm8.hip; 256-pixel x 160-channel halo convolutions and 128 x 320 Linear tiles for the
  * 64x64 / 32x32 / 16x16 feature maps): tb_gemm8_set(bits) -- 1 = convolutions, 2 = Linear layers, 4 = fused GEGLU epilogues, 32 = split-K for
  * small conv grids (default 39); A/B switches: 8 = 64x320 instead of 128x320 Linear tiles, 16 = GEGLU layers on 128x320 tiles, 64 = no XCD rectangle
- * cut, 128 = no 128x160 tiles, 256 = 128x160 tiles also for N = 320, 1024 = no 256x128 convolution tiles (the VAE's 128 / 256 / 512-channel convolutions stay on the 4-wave halo kernel), 512 = 128x160 tiles from 256 (not 512) tiles on (the 32x32-map N = 640 layers: measured +0.27 ms), 2048 = no one-per-CU 128x80 / 128x160 four-stage Linear tiles (the 16x16- / 32x32-map layers with K <= 2560), 4096 = no 128x160 one only, 8192 = the long-K 16x16-map Linear layers (K >= 4096) stay on the 4-wave kernel's 128x128 split-K launches instead of two k-slices of 128x160 tiles -- returns the previous value;
+ * cut, 128 = no 128x160 tiles, 256 = 128x160 tiles also for N = 320, 1024 = no 256x128 convolution tiles (the VAE's 128 / 256 / 512-channel convolutions stay on the 4-wave halo kernel), 512 = 128x160 tiles from 256 (not 512) tiles on (the 32x32-map N = 640 layers: measured +0.27 ms), 2048 = no one-per-CU 128x80 / 128x160 four-stage Linear tiles (the 16x16- / 32x32-map layers with K <= 2560), 4096 = no 128x160 one only, 8192 = the long-K 16x16-map Linear layers (K >= 4096) stay on the 4-wave kernel's 128x128 split-K launches instead of two k-slices of 128x160 tiles, 131072 = CLIP's wide Linear layers on ragged 128x128 tiles (round 5, opt-in), 524288 = the 32x32-map convolutions as two k-slices of the 256x160 tile (round 6, measured +0.15 ms), 1048576 = the 256x160 / 256x128 convolution tiles as one instruction stream per wave (round 6: -4..6 % isolated, no gain in the sustained step -- power-limited; bit-equal results) -- returns the previous value;
  * tb_gemm8_last returns 1 when the most recent tb_gemm launched gemm8_kernel<WM, WN, MT, NT, CONV, NS> and writes those SIX ints to out5 */
 int tb_gemm8_set(int bits);
 int tb_gemm8_last(int* out5);
